@@ -1,0 +1,340 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.json from oracle/spec_model.py.   Run:  python tests/golden/make_golden.py
+
+Inputs that come from the reference (DATA only, transcribed as hex):
+  * the real RISC Zero proof     examples/risc0-verifier/examples/interact.rs:79-84,114-139
+  * the real SP1 v5.0.0 proof    examples/sp1-verifier/examples/interact.rs:97-99
+Expected result for both in the reference's own client script: success (ACCEPT).
+Everything else in the fixtures is derived with the slow big-int spec model and is
+therefore "parity unpinned" beyond those two proofs: precompile
+error paths, strict-decode length rule, signal >= R cases.
+"""
+import json, os, random, sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, '..', '..', 'oracle'))
+import spec_model as m  # noqa: E402
+
+RISC0_REAL = dict(
+    control_root='539032186827b06719244873b17b2d4c122e2d02cfb1994fe958b2523b844576',
+    bn254_control_id='04446e66d300eb7fb45c9726bb53c793dda407a62e9601618bb43c5c14657ac0',
+    seal=('9f39696c08b522a6c736627b0a445e8a7b01282742254793b97900972b1885f08aea3a6818cdb1e8a18a200c34b4dd2c96b5'
+          'cebc414becbd1ef304390de67acf17d777b12070f3c216c5236519405ff2b012d4c6cfc5df2882275f320c80453e53a0e324'
+          '0b7cdac29b24cd2d694d3ba6cdc85c0f6e08dc4f218998ba3ae169b13b0bb7fb0c1767d3a9b4cbfd6262af66be7b3d11d18c'
+          '323cda5db600e615110beb7d1e061ece06169517148a2ca2479fdf756f5f8dc7d555c4e4eb2b691487ac2be1f8430fedf6c4'
+          'd4bb7e42d79a6489ab3cee7d67efbd438fffbd626ca644aac725c15427df3b73288c2d37bba34f77b6a586a859f259d6d524'
+          '604a82d0c03b3158889f'),
+    image_id='886c206b82e4f2dbdc4220f32c3a278c357ddc31ea800574b850c93647ddb5ff',
+    journal_digest='d1ec675902ef1633427ca360b290b0b3045a0d9058ddb5e648b4c3c3224c5c68',
+)
+SP1_REAL = dict(
+    vkey='00d2f2f7952cbd9ececcf5303b2da21af20dc24953485d345df73c2854f498bc',
+    public_values=('0000000000000000000000000000000000000000000000000000000000000014'
+                   '0000000000000000000000000000000000000000000000000000000000001a6d'
+                   '0000000000000000000000000000000000000000000000000000000000002ac2'),
+    proof=('a4594c5929754e82587e66fd1bb8d8e4e98e6777a1adf400c405506a09173829f224450f1b17a81870ab2aef2fbbb236f1d397bb'
+           '6c4ff793bf0e350d58fc191b5e85d7233010220b72c9ee5cb184f6c2bf486f3cae5d21c1e7145e957f36d8716df245c7028365cb'
+           'ff8d03a827a8fcfadb43af2c15c7ca2434db227ab399719aeae87e2d111448ae96af93c333b0a23f9a4be33c6396d1ab823d927d'
+           '51153d05ec87df332988ebd31b243498e1cb1f8d97f84324ad242e7bc3ea9c1bf3165be46b8302952f3ea26440093819356240a7'
+           '00aa424487f6aab1eb664e5aed296c8356b252f11579161a3ec93bdb657e57ba9d5480195da51d0a74ea2f343f85a12f8d2477eb'),
+)
+
+
+def hx(b): return bytes(b).hex()
+def h32(x): return '%064x' % x
+
+
+# ---------------------------------------------------------------- helpers
+def f2sqrt(a):
+    """sqrt in Fp2 (p = 3 mod 4), or None."""
+    a0, a1 = a
+    if a1 == 0:
+        s = pow(a0, (m.P + 1) // 4, m.P)
+        if s * s % m.P == a0:
+            return (s, 0)
+        s = pow(-a0 % m.P, (m.P + 1) // 4, m.P)      # sqrt(-a0) * i
+        return (0, s) if s * s % m.P == -a0 % m.P else None
+    n = (a0 * a0 + a1 * a1) % m.P
+    s = pow(n, (m.P + 1) // 4, m.P)
+    if s * s % m.P != n:
+        return None
+    inv2 = pow(2, -1, m.P)
+    for sg in (s, -s % m.P):
+        t = (a0 + sg) * inv2 % m.P
+        x0 = pow(t, (m.P + 1) // 4, m.P)
+        if x0 * x0 % m.P == t and x0:
+            x1 = a1 * pow(2 * x0, -1, m.P) % m.P
+            r = (x0, x1)
+            if m.f2mul(r, r) == (a0 % m.P, a1 % m.P):
+                return r
+    return None
+
+
+def twist_point_from_x(x):
+    y = f2sqrt(m.f2add(m.f2mul(m.f2mul(x, x), x), m.B2))
+    return None if y is None else (x, y)
+
+
+def random_twist_point(rng):
+    while True:
+        pt = twist_point_from_x((rng.randrange(m.P), rng.randrange(m.P)))
+        if pt:
+            return pt
+
+
+def parse_seal(seal):
+    w = [int.from_bytes(seal[4 + 32 * i:36 + 32 * i], 'big') for i in range(8)]
+    return (w[0], w[1]), ((w[3], w[2]), (w[5], w[4])), (w[6], w[7])      # a, b ((re,im),(re,im)), c
+
+
+def put_word(seal, idx, value):
+    s = bytearray(seal)
+    s[4 + 32 * idx:36 + 32 * idx] = (value % (1 << 256)).to_bytes(32, 'big')
+    return bytes(s)
+
+
+# ---------------------------------------------------------------- fixture 1: real proofs + derived intermediates
+def real_proof_fixture():
+    cr = bytes.fromhex(RISC0_REAL['control_root']); cid = bytes.fromhex(RISC0_REAL['bn254_control_id'])
+    seal = bytes.fromhex(RISC0_REAL['seal'])
+    image_id = bytes.fromhex(RISC0_REAL['image_id']); jd = bytes.fromhex(RISC0_REAL['journal_digest'])
+    v = m.Risc0Verifier(); assert v.initialize(cr, cid) == m.OK
+    claim = m.receipt_claim_ok_digest(image_id, jd)
+    sig = v.signals(claim)
+    vkx = m.compute_vk_x(m.RISC0_VK, sig)
+    st, _ = v.verify(seal, image_id, jd)
+    assert st == m.OK, 'real RISC Zero proof must ACCEPT'
+    r0 = dict(RISC0_REAL, expected_status=st, selector=hx(v.selector), vk_digest=hx(m.risc0_vk_digest()),
+              control_root_0=hx(v.control_root_0), control_root_1=hx(v.control_root_1),
+              output_digest=hx(m.output_digest(jd)), claim_digest=hx(claim), signals=[h32(s) for s in sig],
+              vk_x=[h32(vkx[0]), h32(vkx[1])],
+              system_state_zero_digest=hx(m.SYSTEM_STATE_ZERO_DIGEST))
+    vkey = bytes.fromhex(SP1_REAL['vkey']); pv = bytes.fromhex(SP1_REAL['public_values'])
+    proof = bytes.fromhex(SP1_REAL['proof'])
+    st, _ = m.sp1_verify_proof(vkey, pv, proof)
+    assert st == m.OK, 'real SP1 proof must ACCEPT'
+    sig = [int.from_bytes(vkey, 'big'), m.sp1_hash_public_values(pv)]
+    vkx = m.compute_vk_x(m.SP1_VK, sig)
+    s1 = dict(SP1_REAL, expected_status=st, selector=hx(m.SP1_VERIFIER_HASH[:4]), verifier_hash=hx(m.SP1_VERIFIER_HASH),
+              version=m.SP1_VERSION, signals=[h32(s) for s in sig], vk_x=[h32(vkx[0]), h32(vkx[1])])
+    return dict(risc0=r0, sp1=s1)
+
+
+# ---------------------------------------------------------------- fixture 2: precompile-level KATs (EIP-196/197 semantics)
+def precompile_fixture(rng):
+    G1 = (1, 2)
+    out = dict(ecadd=[], ecmul=[], pairing=[], g2_subgroup=[])
+
+    def try_call(fn, data):
+        try:
+            return hx(fn(data))
+        except m.PrecompileError:
+            return None            # precompile failure
+
+    pts = [m.g1_mul(G1, rng.randrange(1, m.R)) for _ in range(6)]
+    enc = lambda p: m._wr_g1(p)
+    cases = [(pts[0], pts[1]), (pts[2], pts[2]), (pts[3], m.g1_neg(pts[3])), (None, pts[4]), (pts[5], None), (None, None)]
+    for a, b in cases:
+        d = enc(a) + enc(b)
+        out['ecadd'].append(dict(input=hx(d), output=try_call(m.ecadd, d)))
+    bad = [m.be32(1) + m.be32(3) + enc(pts[0]),                              # not on curve
+           m.be32(m.P) + m.be32(0) + enc(pts[0]),                            # x == Q
+           enc(pts[0]) + m.be32(pts[1][0]) + m.be32(pts[1][1] + m.P),       # y + Q
+           enc(pts[0])[:64] + enc(pts[1])[:40]]                             # short input is zero-padded
+    for d in bad:
+        out['ecadd'].append(dict(input=hx(d), output=try_call(m.ecadd, d)))
+    scalars = [0, 1, 2, m.R - 1, m.R, m.R + 5, (1 << 256) - 1, rng.randrange(1 << 256), rng.randrange(1 << 128)]
+    for k in scalars:
+        d = enc(pts[0]) + m.be32(k)
+        out['ecmul'].append(dict(input=hx(d), output=try_call(m.ecmul, d)))
+    for d in (bytes(64) + m.be32(7), m.be32(1) + m.be32(3) + m.be32(7), m.be32(1) + m.be32(2 + m.P) + m.be32(7)):
+        out['ecmul'].append(dict(input=hx(d), output=try_call(m.ecmul, d)))
+
+    # G2 subgroup membership: in-subgroup, random twist points (cofactor is huge => out), small-order points
+    g2gen = m.vk_g2_point(m.RISC0_VK['gamma2'])
+    h2 = 2 * m.P - m.R
+    def g2words(pt):
+        if pt is None:
+            return [h32(0)] * 4
+        (xr, xi), (yr, yi) = pt
+        return [h32(xi), h32(xr), h32(yi), h32(yr)]          # EIP-197 wire order
+    sub = []
+    for _ in range(3):
+        sub.append((m.g2_mul(g2gen, rng.randrange(1, m.R)), True, True))
+    for _ in range(4):
+        sub.append((random_twist_point(rng), True, False))
+    sub.append((twist_point_from_x((2, 1)), True, False))          # SURVEY 8c example x = 2 + i
+    for q in (10069, 5864401):
+        while True:
+            s = m.g2_mul(random_twist_point(rng), m.R * (h2 // q))
+            if s is not None:
+                break
+        assert m.g2_mul(s, q) is None
+        sub.append((s, True, False))                                  # small-order point
+        sub.append((m.g2_add(s, m.g2_mul(g2gen, rng.randrange(1, m.R))), True, False))
+    offx = (rng.randrange(m.P), rng.randrange(m.P))
+    sub.append(((offx, (5, 7)), False, False))                        # not on the twist
+    sub.append((None, True, True))                                    # infinity (all-zero encoding)
+    for pt, on, ins in sub:
+        if pt is not None:
+            assert m.g2_on_curve(pt) == on
+            if on:
+                assert m.g2_in_subgroup(pt) == ins
+        out['g2_subgroup'].append(dict(point=g2words(pt), on_twist=on, in_subgroup=ins))
+
+    # pairing precompile: bilinearity and degenerate inputs
+    def g2enc(pt): return b''.join(bytes.fromhex(w) for w in g2words(pt))
+    a = rng.randrange(1, m.R); b = rng.randrange(1, m.R)
+    Pa = m.g1_mul(G1, a); Qb = m.g2_mul(g2gen, b)
+    Pab = m.g1_mul(G1, a * b % m.R)
+    pcases = [
+        ('e(aP,bQ) e(-abP,Q) = 1', enc(Pa) + g2enc(Qb) + enc(m.g1_neg(Pab)) + g2enc(g2gen)),
+        ('e(aP,bQ) e(abP,Q) != 1', enc(Pa) + g2enc(Qb) + enc(Pab) + g2enc(g2gen)),
+        ('empty input = 1', b''),
+        ('(inf, Q) pair contributes 1', enc(None) + g2enc(Qb)),
+        ('(P, inf) pair contributes 1', enc(Pa) + g2enc(None)),
+        ('single non-degenerate pair != 1', enc(Pa) + g2enc(Qb)),
+        ('inf G1 paired with out-of-subgroup G2 still fails', enc(None) + g2enc(sub[3][0])),
+        ('length not multiple of 192 fails', (enc(Pa) + g2enc(Qb))[:-1]),
+        ('G2 coordinate >= Q fails', enc(Pa) + g2enc(Qb)[:96] + m.be32(Qb[1][0] + m.P)),
+    ]
+    for name, d in pcases:
+        out['pairing'].append(dict(name=name, input=hx(d), output=try_call(m.ecpairing, d)))
+    return out
+
+
+# ---------------------------------------------------------------- fixture 3: verify-level corpus (statuses in the reference's check order)
+def corpus_fixture(rng, real):
+    cases = []
+    cr = bytes.fromhex(RISC0_REAL['control_root']); cid = bytes.fromhex(RISC0_REAL['bn254_control_id'])
+    seal = bytes.fromhex(RISC0_REAL['seal'])
+    image_id = bytes.fromhex(RISC0_REAL['image_id']); jd = bytes.fromhex(RISC0_REAL['journal_digest'])
+    v = m.Risc0Verifier(); v.initialize(cr, cid)
+    a, b, c = parse_seal(seal)
+    delta = m.vk_g2_point(m.RISC0_VK['delta2'])
+    oos = random_twist_point(rng)
+
+    def r0(name, s, iid=image_id, j=jd):
+        st, recv = v.verify(s, iid, j)
+        cases.append(dict(vm='risc0', name=name, seal=hx(s), image_id=hx(iid), journal_digest=hx(j),
+                          status=st, received=hx(recv) if recv else None))
+
+    r0('real proof', seal)
+    for i in range(4):
+        a2, b2, c2 = m.rerandomize(a, b, c, delta, rng.randrange(1, m.R), rng.randrange(1, m.R))
+        r0('rerandomised %d' % i, m.seal_bytes(v.selector, a2, b2, c2))
+    r0('r2-walk (A same, B+delta, C+A)', m.seal_bytes(v.selector, a, m.g2_add(b, delta), m.g1_add(c, a)))
+    r0('flip bit in C.x', put_word(seal, 6, c[0] ^ 1))
+    r0('flip bit in A.y', put_word(seal, 1, a[1] ^ (1 << 77)))
+    r0('flip bit in B.y_re', put_word(seal, 5, b[1][0] ^ 2))
+    r0('flip bit in journal_digest', seal, j=bytes([jd[0] ^ 1]) + jd[1:])
+    r0('flip bit in image_id', seal, iid=image_id[:-1] + bytes([image_id[-1] ^ 0x80]))
+    r0('A.x += Q', put_word(seal, 0, a[0] + m.P))
+    r0('C.y += Q', put_word(seal, 7, c[1] + m.P))
+    r0('B.x_im += Q', put_word(seal, 2, b[0][1] + m.P))
+    r0('A not negated twice (A -> -A)', put_word(seal, 1, m.P - a[1]))
+    r0('A = (0,0) infinity', put_word(put_word(seal, 0, 0), 1, 0))
+    r0('A = (0,Q) -> wraps to infinity under negate_g1', put_word(put_word(seal, 0, 0), 1, m.P))
+    r0('A.y = Q+1 wraps above Q', put_word(seal, 1, m.P + 1))
+    r0('A.y = 2^256-1', put_word(seal, 1, (1 << 256) - 1))
+    r0('B = infinity', put_word(put_word(put_word(put_word(seal, 2, 0), 3, 0), 4, 0), 5, 0))
+    r0('C = infinity', put_word(put_word(seal, 6, 0), 7, 0))
+    r0('A = C = inf, B = inf', bytes(seal[:4]) + bytes(256))
+    r0('B out of subgroup (on twist)', m.seal_bytes(v.selector, a, oos, c))
+    r0('B off twist', put_word(seal, 4, b[1][1] ^ 1))
+    r0('A off curve', put_word(seal, 0, a[0] ^ 4))
+    r0('C valid point but wrong', m.seal_bytes(v.selector, a, b, m.g1_add(c, (1, 2))))
+    r0('B valid subgroup point but wrong', m.seal_bytes(v.selector, a, m.g2_add(b, delta), c))
+    r0('wrong selector', b'\x12\x34\x56\x78' + seal[4:])
+    r0('wrong selector, short', b'\x9f\x39\x69\x6d')
+    r0('sp1 selector on risc0', bytes.fromhex('a4594c59') + seal[4:])
+    r0('len 0', b'')
+    r0('len 3', seal[:3])
+    r0('len 4 (selector only)', seal[:4])
+    r0('len 259', seal[:259])
+    r0('len 261', seal + b'\0')
+    r0('len 292 (extra word)', seal + bytes(32))
+    # context-level cases
+    ctx_cases = []
+    v2 = m.Risc0Verifier()
+    st, recv = v2.verify(seal, image_id, jd)
+    ctx_cases.append(dict(name='not initialised', control_root=None, bn254_control_id=None, seal=hx(seal),
+                          image_id=hx(image_id), journal_digest=hx(jd), status=st, selector=None))
+    for name, cr2, cid2 in (('control id >= R', cr, m.be32(m.R + 3)), ('control id = 2^256-1', cr, b'\xff' * 32),
+                            ('different control root', bytes(range(32)), cid)):
+        v3 = m.Risc0Verifier(); v3.initialize(cr2, cid2)
+        s3 = v3.selector + seal[4:]
+        st, recv = v3.verify(s3, image_id, jd)
+        ctx_cases.append(dict(name=name, control_root=hx(cr2), bn254_control_id=hx(cid2), seal=hx(s3),
+                              image_id=hx(image_id), journal_digest=hx(jd), status=st, selector=hx(v3.selector)))
+    v4 = m.Risc0Verifier(); v4.initialize(cr, cid)
+    ctx_cases.append(dict(name='second initialize', status=v4.initialize(cr, cid)))
+
+    # SP1
+    vkey = bytes.fromhex(SP1_REAL['vkey']); pv = bytes.fromhex(SP1_REAL['public_values'])
+    proof = bytes.fromhex(SP1_REAL['proof'])
+    a, b, c = parse_seal(proof)
+    delta_true = m.g2_neg(m.vk_g2_point(m.SP1_VK['delta2']))      # the SP1 VK stores -delta
+
+    def s1(name, pr, vk=vkey, p=pv):
+        st, recv = m.sp1_verify_proof(vk, p, pr)
+        cases.append(dict(vm='sp1', name=name, proof=hx(pr), vkey=hx(vk), public_values=hx(p), status=st,
+                          received=hx(recv) if recv else None))
+
+    sel = m.SP1_VERIFIER_HASH[:4]
+    s1('real proof', proof)
+    for i in range(4):
+        a2, b2, c2 = m.rerandomize(a, b, c, delta_true, rng.randrange(1, m.R), rng.randrange(1, m.R))
+        s1('rerandomised %d' % i, m.seal_bytes(sel, a2, b2, c2))
+    s1('flip last public-values byte', proof, p=pv[:-1] + bytes([pv[-1] ^ 1]))
+    s1('public values empty', proof, p=b'')
+    s1('public values 55 bytes', proof, p=pv[:55])
+    s1('public values 56 bytes', proof, p=pv[:56])
+    s1('public values 64 bytes', proof, p=pv[:64])
+    s1('public values 200 bytes', proof, p=pv + bytes(range(104)))
+    s1('vkey flipped', proof, vk=vkey[:-1] + bytes([vkey[-1] ^ 1]))
+    s1('vkey >= R', proof, vk=m.be32(m.R))
+    s1('vkey = 2^256-1', proof, vk=b'\xff' * 32)
+    s1('A negated (risc0 convention on sp1)', put_word(proof, 1, m.P - a[1]))
+    s1('A = (0,Q) is NOT infinity on sp1', put_word(put_word(proof, 0, 0), 1, m.P))
+    s1('A = (0,0)', put_word(put_word(proof, 0, 0), 1, 0))
+    s1('flip bit in C.x', put_word(proof, 6, c[0] ^ 1))
+    s1('C.x += Q', put_word(proof, 6, c[0] + m.P))
+    s1('B out of subgroup', m.seal_bytes(sel, a, oos, c))
+    s1('B = infinity', put_word(put_word(put_word(put_word(proof, 2, 0), 3, 0), 4, 0), 5, 0))
+    s1('wrong selector', b'\xa4\x59\x4c\x58' + proof[4:])
+    s1('risc0 selector on sp1', bytes.fromhex('9f39696c') + proof[4:])
+    s1('len 2', proof[:2])
+    s1('len 4', proof[:4])
+    s1('len 259', proof[:259])
+    s1('len 261', proof + b'\x01')
+    return dict(risc0_ctx=dict(control_root=hx(cr), bn254_control_id=hx(cid), selector=hx(v.selector)),
+                cases=cases, ctx_cases=ctx_cases)
+
+
+def revert_fixture():
+    sel_r0 = bytes.fromhex('9f39696c'); sel_sp1 = bytes.fromhex('a4594c59'); got = bytes.fromhex('12345678')
+    out = []
+    for vm, exp in (('risc0', sel_r0), ('sp1', sel_sp1)):
+        for st in range(6):
+            out.append(dict(vm=vm, status=st, received=hx(got), expected=hx(exp),
+                            revert=hx(m.revert_bytes(vm, st, got, exp))))
+    return out
+
+
+def main():
+    rng = random.Random(0x5A4B5600)
+    real = real_proof_fixture()
+    with open(os.path.join(HERE, 'real_proofs.json'), 'w') as f:
+        json.dump(real, f, indent=1)
+    with open(os.path.join(HERE, 'precompile_kats.json'), 'w') as f:
+        json.dump(precompile_fixture(rng), f, indent=1)
+    with open(os.path.join(HERE, 'verify_corpus.json'), 'w') as f:
+        json.dump(corpus_fixture(rng, real), f, indent=1)
+    with open(os.path.join(HERE, 'revert_bytes.json'), 'w') as f:
+        json.dump(revert_fixture(), f, indent=1)
+    print('golden fixtures written to', HERE)
+
+
+if __name__ == '__main__':
+    main()

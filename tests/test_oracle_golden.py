@@ -1,0 +1,102 @@
+"""CPU oracle (oracle/zkv_oracle.c) pinned against the golden vectors.
+
+Pinned by the reference: the two real proofs of examples/*/examples/interact.rs (ACCEPT).
+Everything else is three-way agreement with oracle/spec_model.py => "parity unpinned" (SURVEY.md 8c).
+"""
+import pytest
+
+import oracle_lib as ol
+
+H = bytes.fromhex
+
+
+@pytest.fixture(scope='module')
+def r0ctx(real_proofs):
+    v = ol.Risc0Oracle()
+    assert v.initialize(H(real_proofs['risc0']['control_root']), H(real_proofs['risc0']['bn254_control_id'])) == 0
+    return v
+
+
+def test_real_risc0_proof_accepts(real_proofs, r0ctx):
+    r = real_proofs['risc0']
+    assert r0ctx.get_selector().hex() == r['selector'] == r['seal'][:8]
+    assert ol.risc0_vk_digest().hex() == r['vk_digest']
+    lo, hi = r0ctx.get_control_root()
+    assert (lo.hex(), hi.hex()) == (r['control_root_0'], r['control_root_1'])
+    assert ol.risc0_claim_digest(H(r['image_id']), H(r['journal_digest'])).hex() == r['claim_digest']
+    assert ol.groth16_vk_x(0, [H(s) for s in r['signals']]).hex() == ''.join(r['vk_x'])
+    assert r0ctx.verify(H(r['seal']), H(r['image_id']), H(r['journal_digest'])) == (0, None)
+    assert r0ctx.verify_integrity(H(r['seal']), H(r['claim_digest'])) == (0, None)
+
+
+def test_real_sp1_proof_accepts(real_proofs):
+    s = real_proofs['sp1']
+    assert ol.sp1_hash_public_values(H(s['public_values'])).hex() == s['signals'][1]
+    assert ol.groth16_vk_x(1, [H(x) for x in s['signals']]).hex() == ''.join(s['vk_x'])
+    assert ol.sp1_verify_proof(H(s['vkey']), H(s['public_values']), H(s['proof'])) == (0, None)
+
+
+def test_verify_corpus(verify_corpus, r0ctx):
+    for c in verify_corpus['cases']:
+        if c['vm'] == 'risc0':
+            st, recv = r0ctx.verify(H(c['seal']), H(c['image_id']), H(c['journal_digest']))
+        else:
+            st, recv = ol.sp1_verify_proof(H(c['vkey']), H(c['public_values']), H(c['proof']))
+        assert st == c['status'], c['name']
+        assert (recv.hex() if recv else None) == c['received'], c['name']
+
+
+def test_context_cases(verify_corpus):
+    for c in verify_corpus['ctx_cases']:
+        v = ol.Risc0Oracle()
+        if c['name'] == 'second initialize':
+            cr = H(verify_corpus['risc0_ctx']['control_root']); cid = H(verify_corpus['risc0_ctx']['bn254_control_id'])
+            assert v.initialize(cr, cid) == 0
+            assert v.initialize(cr, cid) == c['status']
+            continue
+        if c['control_root'] is not None:
+            assert v.initialize(H(c['control_root']), H(c['bn254_control_id'])) == 0
+            assert v.get_selector().hex() == c['selector']
+        st, _ = v.verify(H(c['seal']), H(c['image_id']), H(c['journal_digest']))
+        assert st == c['status'], c['name']
+
+
+def test_precompile_kats(precompile_kats):
+    for fn, key in ((ol.ecadd, 'ecadd'), (ol.ecmul, 'ecmul'), (ol.ecpairing, 'pairing')):
+        for c in precompile_kats[key]:
+            out = fn(H(c['input']))
+            assert (out.hex() if out is not None else None) == c['output'], (key, c.get('name'), c['input'][:32])
+
+
+def test_g2_subgroup_kats(precompile_kats):
+    for c in precompile_kats['g2_subgroup']:
+        cls = ol.g2_classify(H(''.join(c['point'])))
+        assert bool(cls & 2) == c['on_twist']
+        if c['on_twist']:
+            assert bool(cls & 4) == c['in_subgroup']
+
+
+def test_revert_bytes(revert_vectors):
+    for c in revert_vectors:
+        out = ol.status_abi_encode(0 if c['vm'] == 'risc0' else 1, c['status'], H(c['received']), H(c['expected']))
+        assert out.hex() == c['revert']
+
+
+def test_sha256_matches_hashlib():
+    import hashlib
+    for n in (0, 1, 55, 56, 63, 64, 65, 119, 120, 128, 1000):
+        m = bytes((i * 7 + 3) & 0xff for i in range(n))
+        assert ol.sha256(m) == hashlib.sha256(m).digest()
+
+
+def test_op_count_reported():
+    """Algorithmic work per verify of the reference-shaped CPU path (SURVEY 8d secondary figure)."""
+    import json, os
+    from conftest import load_golden
+    r = load_golden('real_proofs.json')['risc0']
+    v = ol.Risc0Oracle(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    ol.lib().zkvo_count_enable(1)
+    v.verify(H(r['seal']), H(r['image_id']), H(r['journal_digest']))
+    n = ol.lib().zkvo_count_read()
+    ol.lib().zkvo_count_enable(0)
+    assert 50_000 < n < 400_000, n
