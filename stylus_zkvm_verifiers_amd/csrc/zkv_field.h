@@ -1,0 +1,294 @@
+// BN254 base field and tower arithmetic for gfx950 kernels.
+//
+// Replaces what the reference delegates to the EVM precompiles 0x06/0x07/0x08
+// (/root/reference/contracts/src/common/groth16.rs:12-14, 60-73, 109-128): Fp Montgomery arithmetic on
+// 8 x 32-bit limbs (v_mad_u64_u32 chains), Fp2 = Fp[u]/(u^2+1), Fp6 = Fp2[v]/(v^3 - (9+u)),
+// Fp12 = Fp6[w]/(w^2 - v).  Integer arithmetic only -- no MFMA (not a dense contraction).
+//
+// The code is plain C++ so tests/ can also compile it for the host (tests/host_sim) and check the
+// kernel math without a GPU; the shipped library instantiates it only inside HIP kernels.
+#pragma once
+#include <stdint.h>
+#include "bn254_constants.h"
+
+#if defined(__HIPCC__)
+#define ZKV_HD __host__ __device__ __forceinline__
+#define ZKV_HD_NI __host__ __device__ __noinline__
+#else
+#define ZKV_HD inline
+#define ZKV_HD_NI
+#endif
+
+namespace zkv {
+
+struct Fp { uint32_t v[8]; };
+struct Fp2 { Fp c0, c1; };
+struct Fp6 { Fp2 c0, c1, c2; };
+struct Fp12 { Fp6 c0, c1; };     // c0 = g (w^0,w^2,w^4), c1 = h (w^1,w^3,w^5)
+
+// ---------------------------------------------------------------- carry helpers
+ZKV_HD uint32_t addc(uint32_t a, uint32_t b, uint32_t& carry) {
+    uint64_t t = (uint64_t)a + b + carry;
+    carry = (uint32_t)(t >> 32);
+    return (uint32_t)t;
+}
+ZKV_HD uint32_t subb(uint32_t a, uint32_t b, uint32_t& borrow) {
+    uint64_t t = (uint64_t)a - b - borrow;
+    borrow = (uint32_t)(t >> 32) & 1u;
+    return (uint32_t)t;
+}
+
+// ---------------------------------------------------------------- Fp
+ZKV_HD Fp fp_zero() { Fp r; for (int i = 0; i < 8; i++) r.v[i] = 0; return r; }
+ZKV_HD Fp fp_one() { Fp r = ZKV_FP_ONE; return r; }
+ZKV_HD bool fp_is_zero(const Fp& a) {
+    uint32_t o = 0;
+    for (int i = 0; i < 8; i++) o |= a.v[i];
+    return o == 0;
+}
+ZKV_HD bool fp_eq(const Fp& a, const Fp& b) {
+    uint32_t o = 0;
+    for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+}
+// raw 256-bit compare a >= m (m given as limbs)
+ZKV_HD bool u256_geq(const uint32_t* a, const uint32_t* m) {
+    uint32_t br = 0;
+    for (int i = 0; i < 8; i++) (void)subb(a[i], m[i], br);
+    return br == 0;
+}
+ZKV_HD Fp fp_add(const Fp& a, const Fp& b) {
+    const uint32_t P[8] = ZKV_FP_P_LIMBS;
+    Fp t, s; uint32_t c = 0, br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t.v[i] = addc(a.v[i], b.v[i], c);      // < 2p < 2^255, no carry out
+#pragma unroll
+    for (int i = 0; i < 8; i++) s.v[i] = subb(t.v[i], P[i], br);
+#pragma unroll
+    for (int i = 0; i < 8; i++) t.v[i] = br ? t.v[i] : s.v[i];
+    return t;
+}
+ZKV_HD Fp fp_sub(const Fp& a, const Fp& b) {
+    const uint32_t P[8] = ZKV_FP_P_LIMBS;
+    Fp t; uint32_t br = 0, c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t.v[i] = subb(a.v[i], b.v[i], br);
+    uint32_t mask = 0u - br;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t.v[i] = addc(t.v[i], P[i] & mask, c);
+    return t;
+}
+ZKV_HD Fp fp_neg(const Fp& a) { return fp_sub(fp_zero(), a); }
+ZKV_HD Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
+
+// Montgomery product a*b*2^-256 mod p, CIOS over 32-bit limbs.  p < 2^254 so the running value stays < 2p
+// and never needs a 10th word.
+#if defined(ZKV_FP_MUL_NOINLINE)
+ZKV_HD_NI
+#else
+ZKV_HD
+#endif
+Fp fp_mul(const Fp& a, const Fp& b) {
+    const uint32_t P[8] = ZKV_FP_P_LIMBS;
+    uint32_t t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint64_t x = (uint64_t)a.v[j] * b.v[i] + t[j] + c;
+            t[j] = (uint32_t)x; c = (uint32_t)(x >> 32);
+        }
+        t[8] += c;
+        uint32_t m = t[0] * ZKV_FP_INV32;
+        uint64_t x = (uint64_t)m * P[0] + t[0];
+        c = (uint32_t)(x >> 32);
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            x = (uint64_t)m * P[j] + t[j] + c;
+            t[j - 1] = (uint32_t)x; c = (uint32_t)(x >> 32);
+        }
+        x = (uint64_t)t[8] + c;
+        t[7] = (uint32_t)x; t[8] = (uint32_t)(x >> 32);
+    }
+    Fp r, s; uint32_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s.v[i] = subb(t[i], P[i], br);
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = br ? t[i] : s.v[i];
+    return r;
+}
+ZKV_HD Fp fp_sqr(const Fp& a) { return fp_mul(a, a); }
+
+ZKV_HD Fp fp_from_raw(const uint32_t* limbs) {        // canonical value < p -> Montgomery form
+    Fp t, r2 = ZKV_FP_R2;
+    for (int i = 0; i < 8; i++) t.v[i] = limbs[i];
+    return fp_mul(t, r2);
+}
+ZKV_HD void fp_to_raw(uint32_t* limbs, const Fp& a) {
+    Fp one = fp_zero(); one.v[0] = 1;
+    Fp t = fp_mul(a, one);
+    for (int i = 0; i < 8; i++) limbs[i] = t.v[i];
+}
+// a^(p-2); inv(0) = 0.  Deliberately a loop (not unrolled): 254 squarings + multiplies.
+ZKV_HD Fp fp_inv(const Fp& a) {
+    const uint32_t E[8] = ZKV_FP_PM2_LIMBS;
+    Fp acc = fp_one();
+#pragma unroll 1
+    for (int i = 253; i >= 0; i--) {
+        acc = fp_sqr(acc);
+        if ((E[i >> 5] >> (i & 31)) & 1u) acc = fp_mul(acc, a);
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------- Fp2
+ZKV_HD Fp2 f2_zero() { Fp2 r; r.c0 = fp_zero(); r.c1 = fp_zero(); return r; }
+ZKV_HD Fp2 f2_one() { Fp2 r; r.c0 = fp_one(); r.c1 = fp_zero(); return r; }
+ZKV_HD bool f2_is_zero(const Fp2& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
+ZKV_HD bool f2_eq(const Fp2& a, const Fp2& b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
+ZKV_HD Fp2 f2_add(const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = fp_add(a.c0, b.c0); r.c1 = fp_add(a.c1, b.c1); return r; }
+ZKV_HD Fp2 f2_sub(const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = fp_sub(a.c0, b.c0); r.c1 = fp_sub(a.c1, b.c1); return r; }
+ZKV_HD Fp2 f2_neg(const Fp2& a) { Fp2 r; r.c0 = fp_neg(a.c0); r.c1 = fp_neg(a.c1); return r; }
+ZKV_HD Fp2 f2_dbl(const Fp2& a) { return f2_add(a, a); }
+ZKV_HD Fp2 f2_conj(const Fp2& a) { Fp2 r; r.c0 = a.c0; r.c1 = fp_neg(a.c1); return r; }
+ZKV_HD Fp2 f2_mul(const Fp2& a, const Fp2& b) {
+    Fp t0 = fp_mul(a.c0, b.c0), t1 = fp_mul(a.c1, b.c1);
+    Fp m = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
+    Fp2 r; r.c0 = fp_sub(t0, t1); r.c1 = fp_sub(fp_sub(m, t0), t1);
+    return r;
+}
+ZKV_HD Fp2 f2_sqr(const Fp2& a) {
+    Fp m = fp_mul(a.c0, a.c1);
+    Fp2 r; r.c0 = fp_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1)); r.c1 = fp_dbl(m);
+    return r;
+}
+ZKV_HD Fp2 f2_mul_fp(const Fp2& a, const Fp& k) { Fp2 r; r.c0 = fp_mul(a.c0, k); r.c1 = fp_mul(a.c1, k); return r; }
+ZKV_HD Fp2 f2_mul_xi(const Fp2& a) {          // (9+u)(a0 + a1 u) = (9a0 - a1) + (9a1 + a0) u
+    Fp t0 = fp_dbl(fp_dbl(fp_dbl(a.c0))), t1 = fp_dbl(fp_dbl(fp_dbl(a.c1)));
+    Fp2 r; r.c0 = fp_sub(fp_add(t0, a.c0), a.c1); r.c1 = fp_add(fp_add(t1, a.c1), a.c0);
+    return r;
+}
+ZKV_HD Fp2 f2_inv(const Fp2& a) {
+    Fp n = fp_add(fp_sqr(a.c0), fp_sqr(a.c1));
+    Fp i = fp_inv(n);
+    Fp2 r; r.c0 = fp_mul(a.c0, i); r.c1 = fp_neg(fp_mul(a.c1, i));
+    return r;
+}
+
+// ---------------------------------------------------------------- Fp6
+ZKV_HD Fp6 f6_zero() { Fp6 r; r.c0 = f2_zero(); r.c1 = f2_zero(); r.c2 = f2_zero(); return r; }
+ZKV_HD Fp6 f6_add(const Fp6& a, const Fp6& b) { Fp6 r; r.c0 = f2_add(a.c0, b.c0); r.c1 = f2_add(a.c1, b.c1); r.c2 = f2_add(a.c2, b.c2); return r; }
+ZKV_HD Fp6 f6_sub(const Fp6& a, const Fp6& b) { Fp6 r; r.c0 = f2_sub(a.c0, b.c0); r.c1 = f2_sub(a.c1, b.c1); r.c2 = f2_sub(a.c2, b.c2); return r; }
+ZKV_HD Fp6 f6_neg(const Fp6& a) { Fp6 r; r.c0 = f2_neg(a.c0); r.c1 = f2_neg(a.c1); r.c2 = f2_neg(a.c2); return r; }
+ZKV_HD Fp6 f6_mul_v(const Fp6& a) { Fp6 r; r.c0 = f2_mul_xi(a.c2); r.c1 = a.c0; r.c2 = a.c1; return r; }
+ZKV_HD Fp6 f6_mul(const Fp6& a, const Fp6& b) {
+    Fp2 v0 = f2_mul(a.c0, b.c0), v1 = f2_mul(a.c1, b.c1), v2 = f2_mul(a.c2, b.c2);
+    Fp6 r;
+    r.c0 = f2_add(v0, f2_mul_xi(f2_sub(f2_sub(f2_mul(f2_add(a.c1, a.c2), f2_add(b.c1, b.c2)), v1), v2)));
+    r.c1 = f2_add(f2_sub(f2_sub(f2_mul(f2_add(a.c0, a.c1), f2_add(b.c0, b.c1)), v0), v1), f2_mul_xi(v2));
+    r.c2 = f2_add(f2_sub(f2_sub(f2_mul(f2_add(a.c0, a.c2), f2_add(b.c0, b.c2)), v0), v2), v1);
+    return r;
+}
+// a * (b0 + b1 v)   (5 Fp2 products)
+ZKV_HD Fp6 f6_mul_by_01(const Fp6& a, const Fp2& b0, const Fp2& b1) {
+    Fp2 v0 = f2_mul(a.c0, b0), v1 = f2_mul(a.c1, b1);
+    Fp6 r;
+    r.c1 = f2_sub(f2_sub(f2_mul(f2_add(a.c0, a.c1), f2_add(b0, b1)), v0), v1);
+    r.c0 = f2_add(v0, f2_mul_xi(f2_mul(a.c2, b1)));
+    r.c2 = f2_add(v1, f2_mul(a.c2, b0));
+    return r;
+}
+ZKV_HD Fp6 f6_mul_fp2(const Fp6& a, const Fp2& k) { Fp6 r; r.c0 = f2_mul(a.c0, k); r.c1 = f2_mul(a.c1, k); r.c2 = f2_mul(a.c2, k); return r; }
+ZKV_HD Fp6 f6_inv(const Fp6& a) {
+    Fp2 A = f2_sub(f2_sqr(a.c0), f2_mul_xi(f2_mul(a.c1, a.c2)));
+    Fp2 B = f2_sub(f2_mul_xi(f2_sqr(a.c2)), f2_mul(a.c0, a.c1));
+    Fp2 C = f2_sub(f2_sqr(a.c1), f2_mul(a.c0, a.c2));
+    Fp2 F = f2_add(f2_mul_xi(f2_add(f2_mul(a.c2, B), f2_mul(a.c1, C))), f2_mul(a.c0, A));
+    F = f2_inv(F);
+    Fp6 r; r.c0 = f2_mul(A, F); r.c1 = f2_mul(B, F); r.c2 = f2_mul(C, F);
+    return r;
+}
+
+// ---------------------------------------------------------------- Fp12
+ZKV_HD Fp12 f12_one() { Fp12 r; r.c0 = f6_zero(); r.c1 = f6_zero(); r.c0.c0.c0 = fp_one(); return r; }
+ZKV_HD bool f12_is_one(const Fp12& a) {
+    Fp one = fp_one();
+    bool ok = fp_eq(a.c0.c0.c0, one) && fp_is_zero(a.c0.c0.c1);
+    ok = ok && f2_is_zero(a.c0.c1) && f2_is_zero(a.c0.c2);
+    ok = ok && f2_is_zero(a.c1.c0) && f2_is_zero(a.c1.c1) && f2_is_zero(a.c1.c2);
+    return ok;
+}
+ZKV_HD Fp12 f12_mul(const Fp12& a, const Fp12& b) {
+    Fp6 t0 = f6_mul(a.c0, b.c0), t1 = f6_mul(a.c1, b.c1);
+    Fp6 m = f6_mul(f6_add(a.c0, a.c1), f6_add(b.c0, b.c1));
+    Fp12 r; r.c1 = f6_sub(f6_sub(m, t0), t1); r.c0 = f6_add(t0, f6_mul_v(t1));
+    return r;
+}
+// complex squaring: c0 = (a0+a1)(a0+v a1) - a0a1 - v a0a1, c1 = 2 a0a1
+ZKV_HD Fp12 f12_sqr(const Fp12& a) {
+    Fp6 t = f6_mul(a.c0, a.c1);
+    Fp6 s = f6_mul(f6_add(a.c0, a.c1), f6_add(a.c0, f6_mul_v(a.c1)));
+    Fp12 r; r.c0 = f6_sub(f6_sub(s, t), f6_mul_v(t)); r.c1 = f6_add(t, t);
+    return r;
+}
+ZKV_HD Fp12 f12_conj(const Fp12& a) { Fp12 r; r.c0 = a.c0; r.c1 = f6_neg(a.c1); return r; }
+ZKV_HD Fp12 f12_inv(const Fp12& a) {
+    Fp6 t = f6_sub(f6_mul(a.c0, a.c0), f6_mul_v(f6_mul(a.c1, a.c1)));
+    t = f6_inv(t);
+    Fp12 r; r.c0 = f6_mul(a.c0, t); r.c1 = f6_neg(f6_mul(a.c1, t));
+    return r;
+}
+// f * (c0 + (c3 + c4 v) w), 13 Fp2 products
+ZKV_HD Fp12 f12_mul_by_034(const Fp12& f, const Fp2& c0, const Fp2& c3, const Fp2& c4) {
+    Fp6 t0 = f6_mul_fp2(f.c0, c0);
+    Fp6 t1 = f6_mul_by_01(f.c1, c3, c4);
+    Fp6 t2 = f6_mul_by_01(f6_add(f.c0, f.c1), f2_add(c0, c3), c4);
+    Fp12 r; r.c1 = f6_sub(f6_sub(t2, t0), t1); r.c0 = f6_add(t0, f6_mul_v(t1));
+    return r;
+}
+// f * (1 + (c3 + c4 v) w), 10 Fp2 products  (lines scaled by 1/yP)
+ZKV_HD Fp12 f12_mul_by_134(const Fp12& f, const Fp2& c3, const Fp2& c4) {
+    Fp6 hs = f6_mul_by_01(f.c1, c3, c4);
+    Fp6 gs = f6_mul_by_01(f.c0, c3, c4);
+    Fp12 r; r.c0 = f6_add(f.c0, f6_mul_v(hs)); r.c1 = f6_add(f.c1, gs);
+    return r;
+}
+// Frobenius maps on f = sum_k c_k w^k: (c0,c2,c4) = g, (c1,c3,c5) = h.
+ZKV_HD Fp12 f12_frob1(const Fp12& a) {
+    const Fp2 G[6] = ZKV_FROB1;
+    Fp12 r;
+    r.c0.c0 = f2_conj(a.c0.c0);
+    r.c1.c0 = f2_mul(f2_conj(a.c1.c0), G[1]);
+    r.c0.c1 = f2_mul(f2_conj(a.c0.c1), G[2]);
+    r.c1.c1 = f2_mul(f2_conj(a.c1.c1), G[3]);
+    r.c0.c2 = f2_mul(f2_conj(a.c0.c2), G[4]);
+    r.c1.c2 = f2_mul(f2_conj(a.c1.c2), G[5]);
+    return r;
+}
+ZKV_HD Fp12 f12_frob2(const Fp12& a) {
+    const Fp G[6] = ZKV_FROB2;
+    Fp12 r;
+    r.c0.c0 = a.c0.c0;
+    r.c1.c0 = f2_mul_fp(a.c1.c0, G[1]);
+    r.c0.c1 = f2_mul_fp(a.c0.c1, G[2]);
+    r.c1.c1 = f2_mul_fp(a.c1.c1, G[3]);
+    r.c0.c2 = f2_mul_fp(a.c0.c2, G[4]);
+    r.c1.c2 = f2_mul_fp(a.c1.c2, G[5]);
+    return r;
+}
+ZKV_HD Fp12 f12_frob3(const Fp12& a) {
+    const Fp2 G[6] = ZKV_FROB3;
+    Fp12 r;
+    r.c0.c0 = f2_conj(a.c0.c0);
+    r.c1.c0 = f2_mul(f2_conj(a.c1.c0), G[1]);
+    r.c0.c1 = f2_mul(f2_conj(a.c0.c1), G[2]);
+    r.c1.c1 = f2_mul(f2_conj(a.c1.c1), G[3]);
+    r.c0.c2 = f2_mul(f2_conj(a.c0.c2), G[4]);
+    r.c1.c2 = f2_mul(f2_conj(a.c1.c2), G[5]);
+    return r;
+}
+
+}  // namespace zkv

@@ -1,0 +1,316 @@
+// Per-proof stages of the batched Groth16 verify path, one proof per lane.
+//
+// Mirrors, stage by stage, the reference control flow (paths under /root/reference/contracts/src):
+//   stage PREP    risc0/verifier.rs:146-179 / sp1/verifier.rs:58-94  selector + strict length + seal words,
+//                 risc0/types.rs:44-94 claim digest, risc0/crypto.rs:95-110 split_digest,
+//                 sp1/types.rs:22-38 public-input hashing; common/groth16.rs:32 signal range check;
+//                 groth16.rs:75-84 negate_g1; EIP-196/197 coordinate / on-curve validation
+//   stage MSM     common/groth16.rs:51-58 compute_vk_x (ecMul/ecAdd loop) -> fixed-base windowed sum
+//   stage G2CHK   EIP-197 subgroup validation of B inside the ecPairing call (groth16.rs:121-125)
+//   stage MILLER  + FINALEXP   the ecPairing precompile itself (groth16.rs:109-128)
+// The functions are __host__ __device__ so tests/host_sim can run the identical code on the CPU.
+#pragma once
+#include "zkv_curve.h"
+#include "zkv_sha256.h"
+
+namespace zkv {
+
+enum : uint8_t {
+    ST_OK = 0, ST_VERIFICATION_FAILED = 1, ST_INVALID_INITIALIZATION = 2, ST_ALREADY_INITIALIZED = 3,
+    ST_INVALID_PROOF_DATA = 4, ST_SELECTOR_MISMATCH = 5
+};
+enum : uint32_t { FL_ALIVE = 1u, FL_A_INF = 2u, FL_B_INF = 4u, FL_C_INF = 8u, FL_L_INF = 16u };
+
+constexpr int N_LINES = 88;          // 65 doublings + 21 NAF additions + 2 Frobenius additions
+constexpr int MSM_MAX_WINDOWS = 64;  // 4-bit windows over a 256-bit scalar
+constexpr int MAX_IC = 6;
+
+// Raw verification key handed to the set-up kernel: canonical values as 8 x 32-bit little-endian limbs.
+struct VkRaw {
+    uint32_t alpha[2][8];
+    uint32_t beta[4][8], gamma[4][8], delta[4][8];   // x_re, x_im, y_re, y_im
+    uint32_t ic[MAX_IC][2][8];
+    uint32_t n_ic;
+    uint32_t fixed_scalar[MAX_IC][8];   // for IC index i >= 1: per-context scalar (risc0 control root / id)
+    uint32_t is_fixed[MAX_IC];
+    uint32_t var_ic[2];                 // IC indices of the two per-proof scalars
+    uint32_t var_windows[2];            // 4-bit windows per per-proof scalar (32 for 128-bit, 64 for 256-bit)
+};
+
+// Device-resident tables derived from the VK at context set-up.
+struct VkTables {
+    G1A base; uint32_t base_inf; uint32_t var_windows[2];
+    G1A msm[2][MSM_MAX_WINDOWS][16];     // msm[b][w][d] = d * 16^w * IC_var[b]   (d = 0 unused)
+    LineAff lines[2][N_LINES];           // gamma, delta: slope-form lines of the fixed-Q Miller loop
+    Fp12 f_alpha_beta;                   // Miller value of (alpha, beta)
+};
+
+struct PrepOut {
+    Fp ax, ay, cx, cy; Fp2 bx, by;
+    uint32_t s[2][8];
+    uint32_t flags;
+};
+struct G1Norm { Fp axs, ays, lxs, lys, cxs, cys; };   // x/y and 1/y of A', L = vk_x, C
+
+ZKV_HD int8_t ate_naf(int i) {
+    const int8_t NAF[ZKV_ATE_NAF_LEN] = ZKV_ATE_NAF;
+    return NAF[i];
+}
+
+// ---------------------------------------------------------------- raw 256-bit helpers
+ZKV_HD void load_be256(uint32_t limbs[8], const uint8_t* p) {
+#pragma unroll 1
+    for (int i = 0; i < 8; i++) limbs[7 - i] = load_be32(p + 4 * i);
+}
+ZKV_HD bool raw_is_zero(const uint32_t* a) {
+    uint32_t o = 0;
+    for (int i = 0; i < 8; i++) o |= a[i];
+    return o == 0;
+}
+ZKV_HD bool raw_lt_p(const uint32_t* a) { const uint32_t P[8] = ZKV_FP_P_LIMBS; return !u256_geq(a, P); }
+ZKV_HD bool raw_lt_r(const uint32_t* a) { const uint32_t R[8] = ZKV_FR_R_LIMBS; return !u256_geq(a, R); }
+
+// ---------------------------------------------------------------- stage PREP (shared part)
+// words: the 8 proof words a.x a.y b.x_im b.x_re b.y_im b.y_re c.x c.y as raw limbs.
+// Returns false => VerificationFailed (a precompile would reject the point encoding).
+ZKV_HD bool prep_points(uint32_t w[8][8], bool negate_a, PrepOut& o) {
+    const uint32_t P[8] = ZKV_FP_P_LIMBS;
+    if (negate_a && !(raw_is_zero(w[0]) && raw_is_zero(w[1]))) {      // groth16.rs:75-84, Q.wrapping_sub(y)
+        uint32_t br = 0;
+        for (int i = 0; i < 8; i++) w[1][i] = subb(P[i], w[1][i], br);
+    }
+    bool ok = true;
+    for (int k = 0; k < 8; k++) ok = ok && raw_lt_p(w[k]);
+    if (!ok) return false;
+    uint32_t fl = 0;
+    if (raw_is_zero(w[0]) && raw_is_zero(w[1])) {
+        fl |= FL_A_INF; o.ax = fp_zero(); o.ay = fp_zero();
+    } else {
+        o.ax = fp_from_raw(w[0]); o.ay = fp_from_raw(w[1]);
+        if (!g1_on_curve(o.ax, o.ay)) return false;
+    }
+    if (raw_is_zero(w[6]) && raw_is_zero(w[7])) {
+        fl |= FL_C_INF; o.cx = fp_zero(); o.cy = fp_zero();
+    } else {
+        o.cx = fp_from_raw(w[6]); o.cy = fp_from_raw(w[7]);
+        if (!g1_on_curve(o.cx, o.cy)) return false;
+    }
+    if (raw_is_zero(w[2]) && raw_is_zero(w[3]) && raw_is_zero(w[4]) && raw_is_zero(w[5])) {
+        fl |= FL_B_INF; o.bx = f2_zero(); o.by = f2_zero();
+    } else {
+        o.bx.c1 = fp_from_raw(w[2]); o.bx.c0 = fp_from_raw(w[3]);    // wire order (im, re), SURVEY a8
+        o.by.c1 = fp_from_raw(w[4]); o.by.c0 = fp_from_raw(w[5]);
+        if (!g2_on_twist(o.bx, o.by)) return false;
+    }
+    o.flags = fl | FL_ALIVE;
+    return true;
+}
+
+// risc0/types.rs:44-94: claim digest from (image_id, journal_digest).  tag_output = sha256("risc0.Output"),
+// claim_mid = SHA-256 state after the constant first block of the claim message
+// (sha256("risc0.ReceiptClaim") || input = 0^32), post = SYSTEM_STATE_ZERO_DIGEST words.
+struct Risc0Consts { uint32_t tag_output[8]; uint32_t claim_mid[8]; uint32_t post[8]; };
+
+ZKV_HD void risc0_claim_digest(const Risc0Consts& k, const uint8_t* image_id, const uint8_t* journal, uint32_t h[8]) {
+    uint32_t w[16], out[8];
+    // Output::digest: tag || journal || 0^32 || 0x0200   (98 bytes)
+    sha256_init(out);
+    for (int i = 0; i < 8; i++) { w[i] = k.tag_output[i]; w[8 + i] = load_be32(journal + 4 * i); }
+    sha256_compress(out, w);
+    for (int i = 0; i < 8; i++) w[i] = 0;
+    w[8] = 0x02008000u;                                   // 02 00 | 0x80 pad
+    for (int i = 9; i < 15; i++) w[i] = 0;
+    w[15] = 98u * 8u;
+    sha256_compress(out, w);
+    // ReceiptClaim::digest: tag || input || pre || post || output || 0^8 || 0x0400   (170 bytes)
+    for (int i = 0; i < 8; i++) h[i] = k.claim_mid[i];
+    for (int i = 0; i < 8; i++) { w[i] = load_be32(image_id + 4 * i); w[8 + i] = k.post[i]; }
+    sha256_compress(h, w);
+    for (int i = 0; i < 8; i++) w[i] = out[i];
+    w[8] = 0; w[9] = 0;
+    w[10] = 0x04008000u;
+    for (int i = 11; i < 15; i++) w[i] = 0;
+    w[15] = 170u * 8u;
+    sha256_compress(h, w);
+}
+// risc0/crypto.rs:95-110: low/high 128-bit halves of the byte-reversed digest as scalars
+ZKV_HD void risc0_split_digest(const uint32_t h[8], uint32_t lo[8], uint32_t hi[8]) {
+    for (int i = 0; i < 4; i++) {
+        lo[i] = __builtin_bswap32(h[i]); hi[i] = __builtin_bswap32(h[4 + i]);
+        lo[4 + i] = 0; hi[4 + i] = 0;
+    }
+}
+
+// ---------------------------------------------------------------- stage MSM + G1 normalisation
+// vk_x = base + sum_b s_b * IC_var[b] (groth16.rs:51-58), then x/y and 1/y of A', L, C with one inversion.
+ZKV_HD void msm_normalize(const VkTables& vk, const PrepOut& in, uint32_t& flags, G1Norm& out) {
+    G1J acc;
+    if (vk.base_inf) acc = g1j_infinity();
+    else { acc.x = vk.base.x; acc.y = vk.base.y; acc.z = fp_one(); }
+#pragma unroll 1
+    for (int b = 0; b < 2; b++) {
+#pragma unroll 1
+        for (uint32_t w = 0; w < vk.var_windows[b]; w++) {
+            uint32_t d = (in.s[b][w >> 3] >> ((w & 7) * 4)) & 15u;
+            if (d) {
+                const G1A& e = vk.msm[b][w][d];
+                acc = g1j_add_affine(acc, e.x, e.y);
+            }
+        }
+    }
+    Fp one = fp_one();
+    bool linf = fp_is_zero(acc.z), ainf = (flags & FL_A_INF) != 0, cinf = (flags & FL_C_INF) != 0;
+    if (linf) flags |= FL_L_INF;
+    Fp ya = ainf ? one : in.ay, yl = linf ? one : acc.y, yc = cinf ? one : in.cy;
+    Fp t = fp_mul(ya, yl);
+    Fp inv = fp_inv(fp_mul(t, yc));
+    Fp iyc = fp_mul(inv, t);
+    Fp u = fp_mul(inv, yc);            // 1/(ya yl)
+    Fp iyl = fp_mul(u, ya), iya = fp_mul(u, yl);
+    out.axs = fp_mul(in.ax, iya); out.ays = iya;
+    out.cxs = fp_mul(in.cx, iyc); out.cys = iyc;
+    Fp z2 = fp_sqr(acc.z);
+    out.lxs = fp_mul(fp_mul(acc.x, acc.z), iyl);         // (X/Z^2) / (Y/Z^3) = X Z / Y
+    out.lys = fp_mul(fp_mul(z2, acc.z), iyl);            // Z^3 / Y
+}
+
+// ---------------------------------------------------------------- stage MILLER
+// Shared-accumulator Miller loop over (A',B) [variable Q, projective], (L,gamma), (C,delta) [fixed Q,
+// precomputed slope lines]; multiplied by the precomputed Miller value of (alpha, beta).
+ZKV_HD Fp12 miller_loop(const VkTables& vk, uint32_t flags, const G1Norm& n, const Fp2& bx, const Fp2& by,
+                        bool with_fixed) {
+    bool do_ab = !(flags & (FL_A_INF | FL_B_INF));
+    bool do_k[2] = {with_fixed && !(flags & FL_L_INF), with_fixed && !(flags & FL_C_INF)};
+    const Fp* kxs[2] = {&n.lxs, &n.cxs};
+    const Fp* kys[2] = {&n.lys, &n.cys};
+    Fp12 f = f12_one();
+    G2H T; T.x = bx; T.y = by; T.z = f2_one();
+    Fp2 nby = f2_neg(by);
+    Fp2 l0, l1, l3;
+    int li = 0;
+#pragma unroll 1
+    for (int i = ZKV_ATE_NAF_LEN - 2; i >= 0; i--) {
+        if (i != ZKV_ATE_NAF_LEN - 2) f = f12_sqr(f);
+        if (do_ab) {
+            line_dbl(T, l0, l1, l3);
+            f = f12_mul_by_034(f, l0, f2_mul_fp(l1, n.axs), f2_mul_fp(l3, n.ays));
+        }
+#pragma unroll 1
+        for (int k = 0; k < 2; k++)
+            if (do_k[k]) {
+                const LineAff& L = vk.lines[k][li];
+                f = f12_mul_by_134(f, f2_mul_fp(L.nl, *kxs[k]), f2_mul_fp(L.c, *kys[k]));
+            }
+        li++;
+        int d = ate_naf(i);
+        if (d != 0) {
+            if (do_ab) {
+                line_add(T, bx, d > 0 ? by : nby, l0, l1, l3);
+                f = f12_mul_by_034(f, l0, f2_mul_fp(l1, n.axs), f2_mul_fp(l3, n.ays));
+            }
+#pragma unroll 1
+            for (int k = 0; k < 2; k++)
+                if (do_k[k]) {
+                    const LineAff& L = vk.lines[k][li];
+                    f = f12_mul_by_134(f, f2_mul_fp(L.nl, *kxs[k]), f2_mul_fp(L.c, *kys[k]));
+                }
+            li++;
+        }
+    }
+    Fp2 q1x, q1y, q2x, q2y;
+    g2_frob_affine(q1x, q1y, bx, by);
+    g2_frob2_affine(q2x, q2y, bx, by);
+    q2y = f2_neg(q2y);
+#pragma unroll 1
+    for (int s = 0; s < 2; s++) {
+        if (do_ab) {
+            line_add(T, s ? q2x : q1x, s ? q2y : q1y, l0, l1, l3);
+            f = f12_mul_by_034(f, l0, f2_mul_fp(l1, n.axs), f2_mul_fp(l3, n.ays));
+        }
+#pragma unroll 1
+        for (int k = 0; k < 2; k++)
+            if (do_k[k]) {
+                const LineAff& L = vk.lines[k][li];
+                f = f12_mul_by_134(f, f2_mul_fp(L.nl, *kxs[k]), f2_mul_fp(L.c, *kys[k]));
+            }
+        li++;
+    }
+    if (with_fixed) f = f12_mul(f, vk.f_alpha_beta);
+    return f;
+}
+
+// ---------------------------------------------------------------- context set-up (run once per VK on the device)
+ZKV_HD void setup_lines(const uint32_t q[4][8], LineAff* out) {
+    G2A Q, T;
+    Q.x.c0 = fp_from_raw(q[0]); Q.x.c1 = fp_from_raw(q[1]); Q.y.c0 = fp_from_raw(q[2]); Q.y.c1 = fp_from_raw(q[3]);
+    T = Q;
+    Fp2 nqy = f2_neg(Q.y);
+    int li = 0;
+#pragma unroll 1
+    for (int i = ZKV_ATE_NAF_LEN - 2; i >= 0; i--) {
+        out[li++] = aff_dbl(T);
+        int d = ate_naf(i);
+        if (d != 0) out[li++] = aff_add(T, Q.x, d > 0 ? Q.y : nqy);
+    }
+    Fp2 q1x, q1y, q2x, q2y;
+    g2_frob_affine(q1x, q1y, Q.x, Q.y);
+    g2_frob2_affine(q2x, q2y, Q.x, Q.y);
+    out[li++] = aff_add(T, q1x, q1y);
+    out[li++] = aff_add(T, q2x, f2_neg(q2y));
+}
+ZKV_HD G1J g1_mul_raw(const Fp& x, const Fp& y, const uint32_t k[8]) {
+    G1J acc = g1j_infinity();
+#pragma unroll 1
+    for (int i = 255; i >= 0; i--) {
+        acc = g1j_dbl(acc);
+        if ((k[i >> 5] >> (i & 31)) & 1u) acc = g1j_add_affine(acc, x, y);
+    }
+    return acc;
+}
+ZKV_HD void g1j_to_affine(const G1J& p, G1A& out, uint32_t& inf) {
+    if (fp_is_zero(p.z)) { inf = 1; out.x = fp_zero(); out.y = fp_zero(); return; }
+    Fp zi = fp_inv(p.z), zi2 = fp_sqr(zi);
+    out.x = fp_mul(p.x, zi2); out.y = fp_mul(p.y, fp_mul(zi2, zi)); inf = 0;
+}
+// base = IC[0] + sum over fixed signals s_i * IC[i]
+ZKV_HD void setup_base(const VkRaw& vk, VkTables& t) {
+    G1J acc; acc.x = fp_from_raw(vk.ic[0][0]); acc.y = fp_from_raw(vk.ic[0][1]); acc.z = fp_one();
+#pragma unroll 1
+    for (uint32_t i = 1; i < vk.n_ic; i++) {
+        if (!vk.is_fixed[i]) continue;
+        G1J m = g1_mul_raw(fp_from_raw(vk.ic[i][0]), fp_from_raw(vk.ic[i][1]), vk.fixed_scalar[i]);
+        G1A ma; uint32_t inf;
+        g1j_to_affine(m, ma, inf);
+        if (!inf) acc = g1j_add_affine(acc, ma.x, ma.y);
+    }
+    g1j_to_affine(acc, t.base, t.base_inf);
+    t.var_windows[0] = vk.var_windows[0]; t.var_windows[1] = vk.var_windows[1];
+}
+// one (b, w) row of the fixed-base table: d * 16^w * IC_var[b], d = 1..15
+ZKV_HD void setup_msm_row(const VkRaw& vk, VkTables& t, int b, int w) {
+    uint32_t ici = vk.var_ic[b];
+    G1J p; p.x = fp_from_raw(vk.ic[ici][0]); p.y = fp_from_raw(vk.ic[ici][1]); p.z = fp_one();
+#pragma unroll 1
+    for (int i = 0; i < 4 * w; i++) p = g1j_dbl(p);
+    G1A pa; uint32_t inf;
+    g1j_to_affine(p, pa, inf);
+    G1J acc = g1j_infinity();
+    t.msm[b][w][0].x = fp_zero(); t.msm[b][w][0].y = fp_zero();
+#pragma unroll 1
+    for (int d = 1; d < 16; d++) {
+        acc = g1j_add_affine(acc, pa.x, pa.y);
+        g1j_to_affine(acc, t.msm[b][w][d], inf);
+    }
+}
+ZKV_HD void setup_alpha_beta(const VkRaw& vk, VkTables& t) {
+    Fp ax = fp_from_raw(vk.alpha[0]), ay = fp_from_raw(vk.alpha[1]);
+    Fp iy = fp_inv(ay);
+    G1Norm n; n.axs = fp_mul(ax, iy); n.ays = iy;
+    n.lxs = n.lys = n.cxs = n.cys = fp_zero();
+    Fp2 bx, by;
+    bx.c0 = fp_from_raw(vk.beta[0]); bx.c1 = fp_from_raw(vk.beta[1]);
+    by.c0 = fp_from_raw(vk.beta[2]); by.c1 = fp_from_raw(vk.beta[3]);
+    t.f_alpha_beta = miller_loop(t, 0, n, bx, by, false);
+}
+
+}  // namespace zkv

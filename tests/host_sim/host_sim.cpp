@@ -1,0 +1,74 @@
+// Host build of the kernel math (stylus_zkvm_verifiers_amd/csrc/zkv_*.h) for CPU-side tests.
+// TEST ONLY: the shipped library never runs these stages on the host; this file lets `-m "not gpu"` tests
+// check the exact stage functions the HIP kernels execute against the oracle and the golden vectors.
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+#include "../../stylus_zkvm_verifiers_amd/csrc/zkv_host_vk.h"
+
+using namespace zkv;
+
+static VkTables* g_tab[2] = {nullptr, nullptr};
+static uint8_t g_key[2][64];
+
+static VkTables* tables(int vm, const uint8_t* cr, const uint8_t* cid) {
+    uint8_t key[64]; memset(key, 0, 64);
+    if (vm == 0) { memcpy(key, cr, 32); memcpy(key + 32, cid, 32); }
+    if (g_tab[vm] && memcmp(key, g_key[vm], 64) == 0) return g_tab[vm];
+    VkRaw raw;
+    if (vm == 0) { uint8_t lo[16], hi[16]; host::split_digest(cr, lo, hi); host::fill_vk_risc0(raw, lo, hi, cid); }
+    else host::fill_vk_sp1(raw);
+    VkTables* t = g_tab[vm] ? g_tab[vm] : (VkTables*)malloc(sizeof(VkTables));
+    memset(t, 0, sizeof *t);
+    setup_base(raw, *t);
+    for (int b = 0; b < 2; b++) for (uint32_t w = 0; w < raw.var_windows[b]; w++) setup_msm_row(raw, *t, b, (int)w);
+    setup_lines(raw.gamma, t->lines[0]);
+    setup_lines(raw.delta, t->lines[1]);
+    setup_alpha_beta(raw, *t);
+    g_tab[vm] = t; memcpy(g_key[vm], key, 64);
+    return t;
+}
+
+extern "C" {
+
+// returns 1 accept / 0 reject for the Groth16 core given the 8 proof words and the two per-proof scalars
+int hs_groth16(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* words, const uint8_t* s0, const uint8_t* s1) {
+    VkTables* t = tables(vm, cr, cid);
+    if (vm == 0) { uint32_t id[8]; load_be256(id, cid); if (!raw_lt_r(id)) return 0; }
+    uint32_t w[8][8];
+    for (int k = 0; k < 8; k++) load_be256(w[k], words + 32 * k);
+    PrepOut p; memset(&p, 0, sizeof p);
+    load_be256(p.s[0], s0); load_be256(p.s[1], s1);
+    if (!raw_lt_r(p.s[0]) || !raw_lt_r(p.s[1])) return 0;
+    if (!prep_points(w, vm == 0, p)) return 0;
+    if (!(p.flags & FL_B_INF) && !g2_in_subgroup(p.bx, p.by)) return 0;
+    G1Norm n; uint32_t fl = p.flags;
+    msm_normalize(*t, p, fl, n);
+    Fp12 f = miller_loop(*t, fl, n, p.bx, p.by, true);
+    return f12_is_one(final_exp(f)) ? 1 : 0;
+}
+void hs_risc0_scalars(const uint8_t* image_id, const uint8_t* journal, uint8_t* digest32, uint8_t* lo32, uint8_t* hi32) {
+    Risc0Consts k; host::risc0_consts(k);
+    uint32_t h[8], lo[8], hi[8];
+    risc0_claim_digest(k, image_id, journal, h);
+    for (int i = 0; i < 8; i++) { digest32[4 * i] = h[i] >> 24; digest32[4 * i + 1] = h[i] >> 16; digest32[4 * i + 2] = h[i] >> 8; digest32[4 * i + 3] = h[i]; }
+    risc0_split_digest(h, lo, hi);
+    for (int i = 0; i < 8; i++) for (int b = 0; b < 4; b++) { lo32[31 - 4 * i - b] = lo[i] >> (8 * b); hi32[31 - 4 * i - b] = hi[i] >> (8 * b); }
+}
+void hs_sha256(const uint8_t* m, size_t n, uint8_t* out) { host::sha256_host(m, n, out); }
+void hs_risc0_selector(const uint8_t* cr, const uint8_t* cid, uint8_t* sel4, uint8_t* vkd32) { host::risc0_selector(cr, cid, sel4); host::risc0_vk_digest(vkd32); }
+// canonical big-endian a*b mod p through the Montgomery kernels' code
+void hs_fp_mulmod(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    uint32_t x[8], y[8], r[8];
+    load_be256(x, a); load_be256(y, b);
+    fp_to_raw(r, fp_mul(fp_from_raw(x), fp_from_raw(y)));
+    for (int i = 0; i < 8; i++) for (int k = 0; k < 4; k++) out[31 - 4 * i - k] = r[i] >> (8 * k);
+}
+int hs_g2_in_subgroup(const uint8_t* q128) {     // EIP-197 order: x_im x_re y_im y_re; must be on twist
+    uint32_t w[4][8];
+    for (int k = 0; k < 4; k++) load_be256(w[k], q128 + 32 * k);
+    Fp2 x, y; x.c1 = fp_from_raw(w[0]); x.c0 = fp_from_raw(w[1]); y.c1 = fp_from_raw(w[2]); y.c0 = fp_from_raw(w[3]);
+    if (!g2_on_twist(x, y)) return -1;
+    return g2_in_subgroup(x, y) ? 1 : 0;
+}
+}
