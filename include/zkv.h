@@ -1,0 +1,121 @@
+/*
+ * zkv.h -- C ABI of libzkv_mi355x.so: batched BN254 Groth16 verification for RISC Zero v2.1 and
+ * SP1 v5.0.0 proofs on AMD MI355X (gfx950).  Drop-in boundary for the verify path of
+ * gnosisguild/stylus-zkvm-verifiers; every entry point names the reference interface it replaces
+ * (paths relative to /root/reference/contracts/src).
+ *
+ * Conventions
+ *   - All buffers are caller-owned and borrowed for the duration of the call; the library writes only
+ *     into the caller-provided outputs.  A context is opaque and library-owned.
+ *   - The function return value is a LIBRARY/RUNTIME result (ZKV_OK or a negative ZKV_ERR_*); it is never
+ *     a verification outcome.  Verification outcomes are per-proof status bytes (ZKV_STATUS_*), which
+ *     reproduce the reference's `Result<_, Vec<u8>>` error classes in the reference's evaluation order.
+ *   - There is no CPU fallback: compute entry points return ZKV_ERR_NO_DEVICE when no gfx950 device is usable.
+ *   - A context is immutable after initialisation; batch calls on one context are serialised on the
+ *     context's HIP stream (use one context per host thread for concurrency).
+ */
+#ifndef ZKV_H
+#define ZKV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKV_OK 0
+#define ZKV_ERR_INVALID_ARG (-1)
+#define ZKV_ERR_NO_DEVICE (-2)
+#define ZKV_ERR_HIP (-3)
+#define ZKV_ERR_OOM (-4)
+#define ZKV_ERR_WRONG_CTX (-5)
+
+/* per-proof status: common/errors.rs:3-27, risc0/errors.rs:8-44, sp1/errors.rs:8-43 */
+#define ZKV_STATUS_OK 0                     /* Ok(true) / Ok(())                                        */
+#define ZKV_STATUS_VERIFICATION_FAILED 1    /* VerificationFailed()                                     */
+#define ZKV_STATUS_INVALID_INITIALIZATION 2 /* InvalidInitialization()                                  */
+#define ZKV_STATUS_ALREADY_INITIALIZED 3    /* AlreadyInitialized()                                     */
+#define ZKV_STATUS_INVALID_PROOF_DATA 4     /* InvalidProofData()                                       */
+#define ZKV_STATUS_SELECTOR_MISMATCH 5      /* SelectorMismatch(bytes4,bytes4) / WrongVerifierSelector  */
+
+#define ZKV_VM_RISC0 0
+#define ZKV_VM_SP1 1
+#define ZKV_SEAL_BYTES 260                  /* selector(4) + 8 x uint256: risc0/types.rs:7-13, sp1/types.rs:9-13 */
+
+typedef struct zkv_ctx zkv_ctx;
+
+/* ------------------------------------------------------------------ library */
+/* number of usable gfx950 devices (0 when none; never fails) */
+int zkv_device_count(void);
+const char* zkv_version(void);
+
+/* ------------------------------------------------------------------ RISC Zero verifier instance
+ * Replaces the `RiscZeroVerifier` storage struct + `IRiscZeroVerifier` (risc0/verifier.rs:18-52). */
+
+/* An un-initialised verifier bound to HIP device `device` (storage with initialized = false). */
+zkv_ctx* zkv_risc0_ctx_new(int device);
+/* IRiscZeroVerifier::initialize (risc0/verifier.rs:58-76): *status = OK or ALREADY_INITIALIZED. */
+int zkv_risc0_initialize(zkv_ctx* ctx, const uint8_t control_root[32], const uint8_t bn254_control_id[32], uint8_t* status);
+/* new + initialize */
+zkv_ctx* zkv_risc0_ctx_create(const uint8_t control_root[32], const uint8_t bn254_control_id[32], int device);
+void zkv_ctx_destroy(zkv_ctx* ctx);
+
+/* getters: get_selector / get_control_root / get_bn254_control_id / get_verifier_key_digest / is_initialized
+ * (risc0/verifier.rs:106-124) */
+int zkv_risc0_get_selector(const zkv_ctx* ctx, uint8_t out[4]);
+int zkv_risc0_get_control_root(const zkv_ctx* ctx, uint8_t out_0[16], uint8_t out_1[16]);
+int zkv_risc0_get_bn254_control_id(const zkv_ctx* ctx, uint8_t out[32]);
+int zkv_risc0_get_verifier_key_digest(const zkv_ctx* ctx, uint8_t out[32]);
+int zkv_risc0_is_initialized(const zkv_ctx* ctx);
+
+/* IRiscZeroVerifier::verify (risc0/verifier.rs:78-92) over a batch.
+ * seal i = seal_blob[seal_off[i] .. seal_off[i+1]); image_ids / journal_digests are n x 32 bytes.
+ * status[n] receives ZKV_STATUS_*; recv_selector (n x 4, may be NULL) receives the selector found in the seal
+ * for SELECTOR_MISMATCH entries (zero otherwise). */
+int zkv_risc0_verify_batch(zkv_ctx* ctx, size_t n, const uint8_t* seal_blob, const uint64_t* seal_off,
+                           const uint8_t* image_ids, const uint8_t* journal_digests, uint8_t* status, uint8_t* recv_selector);
+/* IRiscZeroVerifier::verify_integrity (risc0/verifier.rs:94-104) over a batch. */
+int zkv_risc0_verify_integrity_batch(zkv_ctx* ctx, size_t n, const uint8_t* seal_blob, const uint64_t* seal_off,
+                                     const uint8_t* claim_digests, uint8_t* status, uint8_t* recv_selector);
+/* Single-proof wrappers with the exact trait shapes. */
+int zkv_risc0_verify(zkv_ctx* ctx, const uint8_t* seal, size_t seal_len, const uint8_t image_id[32],
+                     const uint8_t journal_digest[32], uint8_t* status, uint8_t recv_selector[4]);
+int zkv_risc0_verify_integrity(zkv_ctx* ctx, const uint8_t* seal, size_t seal_len, const uint8_t claim_digest[32],
+                               uint8_t* status, uint8_t recv_selector[4]);
+/* Fast path: fixed-stride 260-byte seals, all inputs and outputs ALREADY RESIDENT IN HBM (device pointers);
+ * `stream` is a hipStream_t (NULL = the context's own stream).  Asynchronous: returns after enqueueing. */
+int zkv_risc0_verify_batch_dev(zkv_ctx* ctx, size_t n, const uint8_t* d_seals, const uint8_t* d_image_ids,
+                               const uint8_t* d_journal_digests, uint8_t* d_status, uint8_t* d_recv_selector, void* stream);
+
+/* ------------------------------------------------------------------ SP1 verifier
+ * Replaces `Sp1Verifier` + `ISp1Verifier` (sp1/verifier.rs:16-56). */
+zkv_ctx* zkv_sp1_ctx_create(int device);
+int zkv_sp1_verifier_hash(uint8_t out[32]);           /* ISp1Verifier::verifier_hash, sp1/config.rs:4-9 */
+const char* zkv_sp1_version(void);                    /* ISp1Verifier::version, sp1/config.rs:3          */
+/* ISp1Verifier::verify_proof (sp1/verifier.rs:39-46, 58-111) over a batch: program vkeys n x 32 bytes,
+ * ragged public values and proofs. */
+int zkv_sp1_verify_batch(zkv_ctx* ctx, size_t n, const uint8_t* program_vkeys, const uint8_t* pv_blob, const uint64_t* pv_off,
+                         const uint8_t* proof_blob, const uint64_t* proof_off, uint8_t* status, uint8_t* recv_selector);
+int zkv_sp1_verify_proof(zkv_ctx* ctx, const uint8_t program_vkey[32], const uint8_t* public_values, size_t pv_len,
+                         const uint8_t* proof, size_t proof_len, uint8_t* status, uint8_t recv_selector[4]);
+/* Fast path, device-resident: fixed-stride 260-byte proofs and fixed-length public values. */
+int zkv_sp1_verify_batch_dev(zkv_ctx* ctx, size_t n, const uint8_t* d_program_vkeys, const uint8_t* d_public_values, size_t pv_len,
+                             const uint8_t* d_proofs, uint8_t* d_status, uint8_t* d_recv_selector, void* stream);
+
+/* ------------------------------------------------------------------ shared */
+int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_RISC0 / ZKV_VM_SP1 */
+/* Blocks until everything enqueued on the context's stream has finished. */
+int zkv_ctx_synchronize(zkv_ctx* ctx);
+/* HIP-event durations (ms) of the stages of the most recent batch chunk on this context:
+ * [0] prep (parse + SHA-256 + point validation)  [1] vk_x MSM + normalisation  [2] G2 subgroup check
+ * [3] Miller loop  [4] final exponentiation.  Synchronises the context. */
+int zkv_ctx_last_stage_ms(zkv_ctx* ctx, float out_ms[5]);
+/* Revert bytes of a status exactly as the reference ABI-encodes its errors (common/errors.rs:18-27,
+ * risc0/errors.rs:21-32, sp1/errors.rs:21-32).  Returns the length written (0, 4 or 68) or a negative error. */
+int zkv_status_abi_encode(int vm, uint8_t status, const uint8_t received[4], const uint8_t expected[4], uint8_t out[68]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKV_H */

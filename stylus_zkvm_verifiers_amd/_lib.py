@@ -1,0 +1,73 @@
+"""ctypes binding of libzkv_mi355x.so (include/zkv.h).  Fails loudly when the HIP library is missing:
+there is no CPU fallback in this package."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libzkv_mi355x.so')
+
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_WRONG_CTX = 0, -1, -2, -3, -4, -5
+_ERR_NAMES = {ERR_INVALID_ARG: 'ZKV_ERR_INVALID_ARG', ERR_NO_DEVICE: 'ZKV_ERR_NO_DEVICE (no usable gfx950 device; there is no CPU fallback)',
+              ERR_HIP: 'ZKV_ERR_HIP', ERR_OOM: 'ZKV_ERR_OOM', ERR_WRONG_CTX: 'ZKV_ERR_WRONG_CTX'}
+
+# every symbol include/zkv.h declares: name -> (restype, argtypes)
+_vp, _cp, _sz, _i, _u8p = C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint8)
+SYMBOLS = {
+    'zkv_device_count': (_i, []),
+    'zkv_version': (_cp, []),
+    'zkv_risc0_ctx_new': (_vp, [_i]),
+    'zkv_risc0_initialize': (_i, [_vp, _cp, _cp, _u8p]),
+    'zkv_risc0_ctx_create': (_vp, [_cp, _cp, _i]),
+    'zkv_ctx_destroy': (None, [_vp]),
+    'zkv_risc0_get_selector': (_i, [_vp, _cp]),
+    'zkv_risc0_get_control_root': (_i, [_vp, _cp, _cp]),
+    'zkv_risc0_get_bn254_control_id': (_i, [_vp, _cp]),
+    'zkv_risc0_get_verifier_key_digest': (_i, [_vp, _cp]),
+    'zkv_risc0_is_initialized': (_i, [_vp]),
+    'zkv_risc0_verify_batch': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'zkv_risc0_verify_integrity_batch': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    'zkv_risc0_verify': (_i, [_vp, _cp, _sz, _cp, _cp, _u8p, _cp]),
+    'zkv_risc0_verify_integrity': (_i, [_vp, _cp, _sz, _cp, _u8p, _cp]),
+    'zkv_risc0_verify_batch_dev': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'zkv_sp1_ctx_create': (_vp, [_i]),
+    'zkv_sp1_verifier_hash': (_i, [_cp]),
+    'zkv_sp1_version': (_cp, []),
+    'zkv_sp1_verify_batch': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'zkv_sp1_verify_proof': (_i, [_vp, _cp, _cp, _sz, _cp, _sz, _u8p, _cp]),
+    'zkv_sp1_verify_batch_dev': (_i, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    'zkv_ctx_vm': (_i, [_vp]),
+    'zkv_ctx_synchronize': (_i, [_vp]),
+    'zkv_ctx_last_stage_ms': (_i, [_vp, C.POINTER(C.c_float)]),
+    'zkv_status_abi_encode': (_i, [_i, C.c_uint8, _cp, _cp, _cp]),
+}
+
+
+class ZkvRuntimeError(RuntimeError):
+    """A library/runtime failure (HIP, no device, bad arguments) -- never a verification outcome."""
+
+    def __init__(self, code, where):
+        super().__init__('%s failed: %s' % (where, _ERR_NAMES.get(code, 'error %d' % code)))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError('libzkv_mi355x.so is not built (%s); run `python -m stylus_zkvm_verifiers_amd.build` -- '
+                              'this package has no CPU fallback' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)          # AttributeError when a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, where):
+    if rc != OK:
+        raise ZkvRuntimeError(rc, where)

@@ -1,0 +1,36 @@
+// Context set-up kernels: derive the device tables of one verification key (run once per context).
+#include "zkv_internal.h"
+
+namespace zkv {
+
+// fixed part of vk_x: IC[0] + sum of per-context signals
+__global__ __launch_bounds__(64) void k_setup_base(const VkRaw* __restrict__ raw, VkTables* __restrict__ t) {
+    if (threadIdx.x == 0) setup_base(*raw, *t);
+}
+// gamma / delta slope-line tables for the fixed-Q Miller loops
+__global__ __launch_bounds__(64) void k_setup_lines(const VkRaw* __restrict__ raw, VkTables* __restrict__ t) {
+    if (threadIdx.x == 0) setup_lines(raw->gamma, t->lines[0]);
+    if (threadIdx.x == 1) setup_lines(raw->delta, t->lines[1]);
+}
+// one lane per (scalar, window) row of the fixed-base MSM table
+__global__ __launch_bounds__(64) void k_setup_msm(const VkRaw* __restrict__ raw, VkTables* __restrict__ t) {
+    int b = blockIdx.x, w = threadIdx.x;
+    if (w < (int)raw->var_windows[b]) setup_msm_row(*raw, *t, b, w);
+}
+// Miller value of (alpha, beta); f and T of the single lane live in LDS like in k_miller
+__global__ __launch_bounds__(64) void k_setup_alpha_beta(const VkRaw* __restrict__ raw, VkTables* __restrict__ t) {
+    __shared__ uint32_t lds[96 + 48];
+    if (threadIdx.x != 0) return;
+    MRef fm; fm.p = lds; fm.stride = 1;
+    MRef tm; tm.p = lds + 96; tm.stride = 1;
+    setup_alpha_beta(*raw, *t, fm, tm);
+}
+
+void launch_setup(const VkRaw* d_raw, VkTables* d_tab, hipStream_t s) {
+    hipLaunchKernelGGL(k_setup_base, dim3(1), dim3(64), 0, s, d_raw, d_tab);
+    hipLaunchKernelGGL(k_setup_lines, dim3(1), dim3(64), 0, s, d_raw, d_tab);
+    hipLaunchKernelGGL(k_setup_msm, dim3(2), dim3(64), 0, s, d_raw, d_tab);
+    hipLaunchKernelGGL(k_setup_alpha_beta, dim3(1), dim3(64), 0, s, d_raw, d_tab);
+}
+
+}  // namespace zkv

@@ -1,0 +1,367 @@
+// C ABI of libzkv_mi355x.so (include/zkv.h): verifier contexts, batch entry points, chunked stage pipeline.
+// Host code here only marshals bytes, runs the once-per-context SHA-256 chain (initialize) and enqueues
+// kernels; every field/curve/pairing operation runs in the HIP kernels.  No CPU fallback exists.
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <new>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/zkv.h"
+#include "zkv_host_vk.h"
+#include "zkv_internal.h"
+
+using namespace zkv;
+
+#define ZKV_EXPORT extern "C" __attribute__((visibility("default")))
+
+struct zkv_ctx {
+    int vm = 0, device = 0;
+    bool initialized = false, id_ge_r = false;
+    uint8_t control_root_0[16] = {0}, control_root_1[16] = {0}, control_id[32] = {0}, selector[4] = {0};
+    Risc0Consts consts;
+    // device side (created lazily on the first compute call)
+    bool dev_ready = false;
+    hipStream_t stream = nullptr;
+    VkTables* d_tab = nullptr;
+    Workspace ws = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    uint8_t *d_blob = nullptr, *d_a = nullptr, *d_b = nullptr, *d_pv = nullptr, *d_status = nullptr, *d_recv = nullptr;
+    uint64_t *d_off = nullptr, *d_pvoff = nullptr;
+    size_t blob_cap = 0, pv_cap = 0;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::mutex mu;
+};
+
+static size_t chunk_capacity() {
+    const char* e = getenv("ZKV_CHUNK");
+    size_t c = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 17;
+    if (c < 64) c = 64;
+    return (c + 63) & ~(size_t)63;
+}
+
+static bool device_is_gfx950(int dev) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
+    return strncmp(p.gcnArchName, "gfx950", 6) == 0;
+}
+
+ZKV_EXPORT int zkv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int ok = 0;
+    for (int i = 0; i < n; i++) ok += device_is_gfx950(i) ? 1 : 0;
+    return ok == n ? n : ok;
+}
+ZKV_EXPORT const char* zkv_version(void) { return "zkv-mi355x 0.1 (gfx950)"; }
+
+#define HIP_TRY(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return ZKV_ERR_HIP; } } while (0)
+
+static void ctx_free_device(zkv_ctx* c) {
+    if (!c->dev_ready && !c->stream) return;
+    (void)hipSetDevice(c->device);
+    void* ptrs[] = {c->d_tab, c->ws.prep, c->ws.norm, c->ws.f, c->ws.fe, c->ws.flags, c->d_blob, c->d_a, c->d_b, c->d_pv,
+                    c->d_status, c->d_recv, c->d_off, c->d_pvoff};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    c->dev_ready = false; c->stream = nullptr;
+}
+
+// Lazily creates the stream, the VK tables (set-up kernels) and the per-chunk workspace.
+static int ctx_device_init(zkv_ctx* c) {
+    if (c->dev_ready) return hipSetDevice(c->device) == hipSuccess ? ZKV_OK : ZKV_ERR_HIP;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return ZKV_ERR_NO_DEVICE; }
+    if (c->device < 0 || c->device >= n || !device_is_gfx950(c->device)) return ZKV_ERR_NO_DEVICE;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    VkRaw raw;
+    if (c->vm == ZKV_VM_RISC0) host::fill_vk_risc0(raw, c->control_root_0, c->control_root_1, c->control_id);
+    else host::fill_vk_sp1(raw);
+    if (c->id_ge_r) memset(raw.fixed_scalar[5], 0, 32);      // never used: every proof fails the range check first
+    VkRaw* d_raw = nullptr;
+    HIP_TRY(hipMalloc(&d_raw, sizeof(VkRaw)));
+    HIP_TRY(hipMalloc(&c->d_tab, sizeof(VkTables)));
+    HIP_TRY(hipMemsetAsync(c->d_tab, 0, sizeof(VkTables), c->stream));
+    HIP_TRY(hipMemcpyAsync(d_raw, &raw, sizeof raw, hipMemcpyHostToDevice, c->stream));
+    launch_setup(d_raw, c->d_tab, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_raw);
+    size_t cap = chunk_capacity();
+    c->ws.cap = cap;
+    if (hipMalloc(&c->ws.prep, sizeof(uint32_t) * WS_PREP_WORDS * cap) != hipSuccess ||
+        hipMalloc(&c->ws.norm, sizeof(uint32_t) * WS_NORM_WORDS * cap) != hipSuccess ||
+        hipMalloc(&c->ws.f, sizeof(uint32_t) * WS_F_WORDS * cap) != hipSuccess ||
+        hipMalloc(&c->ws.fe, sizeof(uint32_t) * WS_FE_WORDS * cap) != hipSuccess ||
+        hipMalloc(&c->ws.flags, sizeof(uint32_t) * cap) != hipSuccess ||
+        hipMalloc(&c->d_a, 32 * cap) != hipSuccess || hipMalloc(&c->d_b, 32 * cap) != hipSuccess ||
+        hipMalloc(&c->d_status, cap) != hipSuccess || hipMalloc(&c->d_recv, 4 * cap) != hipSuccess ||
+        hipMalloc(&c->d_off, sizeof(uint64_t) * (cap + 1)) != hipSuccess ||
+        hipMalloc(&c->d_pvoff, sizeof(uint64_t) * (cap + 1)) != hipSuccess) {
+        (void)hipGetLastError();
+        return ZKV_ERR_OOM;
+    }
+    c->dev_ready = true;
+    return ZKV_OK;
+}
+
+static int grow(uint8_t** p, size_t* cap, size_t need) {
+    if (need <= *cap) return ZKV_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    size_t want = need + need / 4 + 4096;
+    if (hipMalloc(p, want) != hipSuccess) { (void)hipGetLastError(); return ZKV_ERR_OOM; }
+    *cap = want;
+    return ZKV_OK;
+}
+
+// Enqueues the five stages for one chunk (all pointers device-resident).
+static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed) {
+    if (timed) (void)hipEventRecord(c->ev[0], s);
+    if (c->vm == ZKV_VM_RISC0) launch_prep_risc0(a, c->consts, c->ws, s); else launch_prep_sp1(a, c->ws, s);
+    if (timed) (void)hipEventRecord(c->ev[1], s);
+    launch_msm(a.n, c->d_tab, c->ws, s);
+    if (timed) (void)hipEventRecord(c->ev[2], s);
+    launch_g2chk(a.n, c->ws, a.status, s);
+    if (timed) (void)hipEventRecord(c->ev[3], s);
+    launch_miller(a.n, c->d_tab, c->ws, s);
+    if (timed) (void)hipEventRecord(c->ev[4], s);
+    launch_finalexp(a.n, c->ws, a.status, s);
+    if (timed) (void)hipEventRecord(c->ev[5], s);
+}
+
+static uint32_t be32_of(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+// Host-pointer batch driver shared by risc0 verify / verify_integrity / sp1 verify_proof.
+static int run_host_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const uint64_t* off, const uint8_t* in_a, const uint8_t* in_b,
+                          const uint8_t* pv_blob, const uint64_t* pv_off, uint8_t* status, uint8_t* recv) {
+    if (!c || (n && (!blob || !off || !status))) return ZKV_ERR_INVALID_ARG;
+    if (recv) memset(recv, 0, 4 * n);
+    if (c->vm == ZKV_VM_RISC0 && !c->initialized) {              // risc0/verifier.rs:84-86, 99-101
+        memset(status, ZKV_STATUS_INVALID_INITIALIZATION, n);
+        return ZKV_OK;
+    }
+    if (!n) return ZKV_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ctx_device_init(c);
+    if (rc != ZKV_OK) return rc;
+    size_t cap = c->ws.cap;
+    std::vector<uint64_t> rel(cap + 1);
+    for (size_t base = 0; base < n; base += cap) {
+        size_t m = n - base < cap ? n - base : cap;
+        uint64_t b0 = off[base], bytes = off[base + m] - b0;
+        if ((rc = grow(&c->d_blob, &c->blob_cap, (size_t)bytes + 8)) != ZKV_OK) return rc;
+        for (size_t i = 0; i <= m; i++) rel[i] = off[base + i] - b0;
+        HIP_TRY(hipMemcpyAsync(c->d_off, rel.data(), sizeof(uint64_t) * (m + 1), hipMemcpyHostToDevice, c->stream));
+        if (bytes) HIP_TRY(hipMemcpyAsync(c->d_blob, blob + b0, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));            // rel[] is reused below
+        HIP_TRY(hipMemcpyAsync(c->d_a, in_a + 32 * base, 32 * m, hipMemcpyHostToDevice, c->stream));
+        if (in_b) HIP_TRY(hipMemcpyAsync(c->d_b, in_b + 32 * base, 32 * m, hipMemcpyHostToDevice, c->stream));
+        PrepArgs a;
+        memset(&a, 0, sizeof a);
+        a.n = m; a.blob = c->d_blob; a.off = c->d_off; a.stride = 0;
+        a.in32_a = c->d_a; a.in32_b = in_b ? c->d_b : nullptr;
+        if (c->vm == ZKV_VM_SP1) {
+            uint64_t p0 = pv_off[base], pbytes = pv_off[base + m] - p0;
+            if ((rc = grow(&c->d_pv, &c->pv_cap, (size_t)pbytes + 8)) != ZKV_OK) return rc;
+            for (size_t i = 0; i <= m; i++) rel[i] = pv_off[base + i] - p0;
+            HIP_TRY(hipMemcpyAsync(c->d_pvoff, rel.data(), sizeof(uint64_t) * (m + 1), hipMemcpyHostToDevice, c->stream));
+            if (pbytes) HIP_TRY(hipMemcpyAsync(c->d_pv, pv_blob + p0, (size_t)pbytes, hipMemcpyHostToDevice, c->stream));
+            a.pv_blob = c->d_pv; a.pv_off = c->d_pvoff;
+            a.selector_be = be32_of(host::SP1_VERIFIER_HASH);
+        } else {
+            a.selector_be = be32_of(c->selector);
+            a.force_fail = c->id_ge_r ? 1u : 0u;
+        }
+        a.status = c->d_status; a.recv = c->d_recv;
+        enqueue_chunk(c, a, c->stream, true);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(status + base, c->d_status, m, hipMemcpyDeviceToHost, c->stream));
+        if (recv) HIP_TRY(hipMemcpyAsync(recv + 4 * base, c->d_recv, 4 * m, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return ZKV_OK;
+}
+
+// Device-pointer fast path (fixed stride), asynchronous on `stream`.
+static int run_dev_batch(zkv_ctx* c, size_t n, const uint8_t* d_blob, const uint8_t* d_a, const uint8_t* d_b, const uint8_t* d_pv,
+                         size_t pv_len, uint8_t* d_status, uint8_t* d_recv, void* stream) {
+    if (!c || (n && (!d_blob || !d_a || !d_status))) return ZKV_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ctx_device_init(c);
+    if (rc != ZKV_OK) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (c->vm == ZKV_VM_RISC0 && !c->initialized) {
+        HIP_TRY(hipMemsetAsync(d_status, ZKV_STATUS_INVALID_INITIALIZATION, n, s));
+        if (d_recv) HIP_TRY(hipMemsetAsync(d_recv, 0, 4 * n, s));
+        return ZKV_OK;
+    }
+    size_t cap = c->ws.cap;
+    for (size_t base = 0; base < n; base += cap) {
+        size_t m = n - base < cap ? n - base : cap;
+        PrepArgs a;
+        memset(&a, 0, sizeof a);
+        a.n = m; a.blob = d_blob + base * ZKV_SEAL_BYTES; a.off = nullptr; a.stride = ZKV_SEAL_BYTES;
+        a.in32_a = d_a + 32 * base; a.in32_b = d_b ? d_b + 32 * base : nullptr;
+        if (c->vm == ZKV_VM_SP1) {
+            a.pv_blob = d_pv + base * pv_len; a.pv_off = nullptr; a.pv_stride = (uint32_t)pv_len;
+            a.selector_be = be32_of(host::SP1_VERIFIER_HASH);
+        } else {
+            a.selector_be = be32_of(c->selector);
+            a.force_fail = c->id_ge_r ? 1u : 0u;
+        }
+        a.status = d_status + base; a.recv = d_recv ? d_recv + 4 * base : nullptr;
+        enqueue_chunk(c, a, s, base + cap >= n);
+    }
+    HIP_TRY(hipGetLastError());
+    return ZKV_OK;
+}
+
+// ------------------------------------------------------------------ RISC Zero
+ZKV_EXPORT zkv_ctx* zkv_risc0_ctx_new(int device) {
+    zkv_ctx* c = new (std::nothrow) zkv_ctx();
+    if (!c) return nullptr;
+    c->vm = ZKV_VM_RISC0; c->device = device;
+    host::risc0_consts(c->consts);
+    return c;
+}
+ZKV_EXPORT int zkv_risc0_initialize(zkv_ctx* c, const uint8_t control_root[32], const uint8_t bn254_control_id[32], uint8_t* status) {
+    if (!c || c->vm != ZKV_VM_RISC0 || !control_root || !bn254_control_id) return ZKV_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->initialized) { if (status) *status = ZKV_STATUS_ALREADY_INITIALIZED; return ZKV_OK; }   // verifier.rs:63-65
+    host::split_digest(control_root, c->control_root_0, c->control_root_1);                        // :67-69
+    memcpy(c->control_id, bn254_control_id, 32);                                                   // :70
+    host::risc0_selector(control_root, bn254_control_id, c->selector);                             // :71-72
+    uint32_t id[8];
+    host::be_to_limbs(id, bn254_control_id);
+    c->id_ge_r = !raw_lt_r(id);            // such a verifier fails every proof at groth16.rs:32
+    c->initialized = true;
+    if (status) *status = ZKV_STATUS_OK;
+    return ZKV_OK;
+}
+ZKV_EXPORT zkv_ctx* zkv_risc0_ctx_create(const uint8_t control_root[32], const uint8_t bn254_control_id[32], int device) {
+    zkv_ctx* c = zkv_risc0_ctx_new(device);
+    if (!c) return nullptr;
+    uint8_t st;
+    if (zkv_risc0_initialize(c, control_root, bn254_control_id, &st) != ZKV_OK) { delete c; return nullptr; }
+    return c;
+}
+ZKV_EXPORT void zkv_ctx_destroy(zkv_ctx* c) {
+    if (!c) return;
+    ctx_free_device(c);
+    delete c;
+}
+ZKV_EXPORT int zkv_risc0_get_selector(const zkv_ctx* c, uint8_t out[4]) {
+    if (!c || c->vm != ZKV_VM_RISC0) return ZKV_ERR_WRONG_CTX;
+    memcpy(out, c->selector, 4); return ZKV_OK;
+}
+ZKV_EXPORT int zkv_risc0_get_control_root(const zkv_ctx* c, uint8_t out_0[16], uint8_t out_1[16]) {
+    if (!c || c->vm != ZKV_VM_RISC0) return ZKV_ERR_WRONG_CTX;
+    memcpy(out_0, c->control_root_0, 16); memcpy(out_1, c->control_root_1, 16); return ZKV_OK;
+}
+ZKV_EXPORT int zkv_risc0_get_bn254_control_id(const zkv_ctx* c, uint8_t out[32]) {
+    if (!c || c->vm != ZKV_VM_RISC0) return ZKV_ERR_WRONG_CTX;
+    memcpy(out, c->control_id, 32); return ZKV_OK;
+}
+ZKV_EXPORT int zkv_risc0_get_verifier_key_digest(const zkv_ctx* c, uint8_t out[32]) {
+    if (!c || c->vm != ZKV_VM_RISC0) return ZKV_ERR_WRONG_CTX;
+    host::risc0_vk_digest(out); return ZKV_OK;
+}
+ZKV_EXPORT int zkv_risc0_is_initialized(const zkv_ctx* c) { return c && c->vm == ZKV_VM_RISC0 && c->initialized ? 1 : 0; }
+
+ZKV_EXPORT int zkv_risc0_verify_batch(zkv_ctx* c, size_t n, const uint8_t* seal_blob, const uint64_t* seal_off, const uint8_t* image_ids,
+                                      const uint8_t* journal_digests, uint8_t* status, uint8_t* recv) {
+    if (!c || c->vm != ZKV_VM_RISC0) return ZKV_ERR_WRONG_CTX;
+    if (n && (!image_ids || !journal_digests)) return ZKV_ERR_INVALID_ARG;
+    return run_host_batch(c, n, seal_blob, seal_off, image_ids, journal_digests, nullptr, nullptr, status, recv);
+}
+ZKV_EXPORT int zkv_risc0_verify_integrity_batch(zkv_ctx* c, size_t n, const uint8_t* seal_blob, const uint64_t* seal_off,
+                                                const uint8_t* claim_digests, uint8_t* status, uint8_t* recv) {
+    if (!c || c->vm != ZKV_VM_RISC0) return ZKV_ERR_WRONG_CTX;
+    if (n && !claim_digests) return ZKV_ERR_INVALID_ARG;
+    return run_host_batch(c, n, seal_blob, seal_off, claim_digests, nullptr, nullptr, nullptr, status, recv);
+}
+ZKV_EXPORT int zkv_risc0_verify(zkv_ctx* c, const uint8_t* seal, size_t seal_len, const uint8_t image_id[32], const uint8_t journal_digest[32],
+                                uint8_t* status, uint8_t recv[4]) {
+    uint64_t off[2] = {0, seal_len};
+    uint8_t dummy = 0;
+    return zkv_risc0_verify_batch(c, 1, seal ? seal : &dummy, off, image_id, journal_digest, status, recv);
+}
+ZKV_EXPORT int zkv_risc0_verify_integrity(zkv_ctx* c, const uint8_t* seal, size_t seal_len, const uint8_t claim_digest[32], uint8_t* status,
+                                          uint8_t recv[4]) {
+    uint64_t off[2] = {0, seal_len};
+    uint8_t dummy = 0;
+    return zkv_risc0_verify_integrity_batch(c, 1, seal ? seal : &dummy, off, claim_digest, status, recv);
+}
+ZKV_EXPORT int zkv_risc0_verify_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d_seals, const uint8_t* d_image_ids,
+                                          const uint8_t* d_journal_digests, uint8_t* d_status, uint8_t* d_recv, void* stream) {
+    if (!c || c->vm != ZKV_VM_RISC0) return ZKV_ERR_WRONG_CTX;
+    if (n && !d_journal_digests) return ZKV_ERR_INVALID_ARG;
+    return run_dev_batch(c, n, d_seals, d_image_ids, d_journal_digests, nullptr, 0, d_status, d_recv, stream);
+}
+
+// ------------------------------------------------------------------ SP1
+ZKV_EXPORT zkv_ctx* zkv_sp1_ctx_create(int device) {
+    zkv_ctx* c = new (std::nothrow) zkv_ctx();
+    if (!c) return nullptr;
+    c->vm = ZKV_VM_SP1; c->device = device; c->initialized = true;
+    memset(&c->consts, 0, sizeof c->consts);
+    return c;
+}
+ZKV_EXPORT int zkv_sp1_verifier_hash(uint8_t out[32]) { memcpy(out, host::SP1_VERIFIER_HASH, 32); return ZKV_OK; }
+ZKV_EXPORT const char* zkv_sp1_version(void) { return host::SP1_VERSION; }
+ZKV_EXPORT int zkv_sp1_verify_batch(zkv_ctx* c, size_t n, const uint8_t* vkeys, const uint8_t* pv_blob, const uint64_t* pv_off,
+                                    const uint8_t* proof_blob, const uint64_t* proof_off, uint8_t* status, uint8_t* recv) {
+    if (!c || c->vm != ZKV_VM_SP1) return ZKV_ERR_WRONG_CTX;
+    if (n && (!vkeys || !pv_blob || !pv_off)) return ZKV_ERR_INVALID_ARG;
+    return run_host_batch(c, n, proof_blob, proof_off, vkeys, nullptr, pv_blob, pv_off, status, recv);
+}
+ZKV_EXPORT int zkv_sp1_verify_proof(zkv_ctx* c, const uint8_t vkey[32], const uint8_t* pv, size_t pv_len, const uint8_t* proof, size_t proof_len,
+                                    uint8_t* status, uint8_t recv[4]) {
+    uint64_t poff[2] = {0, proof_len}, voff[2] = {0, pv_len};
+    uint8_t dummy = 0;
+    return zkv_sp1_verify_batch(c, 1, vkey, pv ? pv : &dummy, voff, proof ? proof : &dummy, poff, status, recv);
+}
+ZKV_EXPORT int zkv_sp1_verify_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d_vkeys, const uint8_t* d_pv, size_t pv_len, const uint8_t* d_proofs,
+                                        uint8_t* d_status, uint8_t* d_recv, void* stream) {
+    if (!c || c->vm != ZKV_VM_SP1) return ZKV_ERR_WRONG_CTX;
+    if (n && !d_pv) return ZKV_ERR_INVALID_ARG;
+    return run_dev_batch(c, n, d_proofs, d_vkeys, nullptr, d_pv, pv_len, d_status, d_recv, stream);
+}
+
+// ------------------------------------------------------------------ shared
+ZKV_EXPORT int zkv_ctx_vm(const zkv_ctx* c) { return c ? c->vm : ZKV_ERR_INVALID_ARG; }
+ZKV_EXPORT int zkv_ctx_synchronize(zkv_ctx* c) {
+    if (!c) return ZKV_ERR_INVALID_ARG;
+    if (!c->dev_ready) return ZKV_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return ZKV_OK;
+}
+ZKV_EXPORT int zkv_ctx_last_stage_ms(zkv_ctx* c, float out_ms[5]) {
+    if (!c || !out_ms) return ZKV_ERR_INVALID_ARG;
+    if (!c->dev_ready) return ZKV_ERR_NO_DEVICE;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev[5]));
+    for (int i = 0; i < 5; i++) HIP_TRY(hipEventElapsedTime(&out_ms[i], c->ev[i], c->ev[i + 1]));
+    return ZKV_OK;
+}
+ZKV_EXPORT int zkv_status_abi_encode(int vm, uint8_t status, const uint8_t received[4], const uint8_t expected[4], uint8_t out[68]) {
+    // keccak-256 selectors of the reference's Solidity custom errors
+    static const uint8_t sel[5][4] = {{0, 0, 0, 0}, {0x43, 0x9c, 0xc0, 0xcd}, {0xf9, 0x2e, 0xe8, 0xa9}, {0x0d, 0xc1, 0x49, 0xf0}, {0xe3, 0xe9, 0x43, 0x26}};
+    static const uint8_t mism[2][4] = {{0xb8, 0xb3, 0x8d, 0x4c}, {0x98, 0x80, 0x66, 0xa1}};
+    if (!out || (vm != ZKV_VM_RISC0 && vm != ZKV_VM_SP1)) return ZKV_ERR_INVALID_ARG;
+    if (status == ZKV_STATUS_OK) return 0;
+    if (status == ZKV_STATUS_SELECTOR_MISMATCH) {
+        if (!received || !expected) return ZKV_ERR_INVALID_ARG;
+        memset(out, 0, 68);
+        memcpy(out, mism[vm], 4); memcpy(out + 4, received, 4); memcpy(out + 36, expected, 4);
+        return 68;
+    }
+    if (status > ZKV_STATUS_SELECTOR_MISMATCH) return ZKV_ERR_INVALID_ARG;
+    memcpy(out, sel[status], 4);
+    return 4;
+}

@@ -13,10 +13,10 @@
 
 #if defined(__HIPCC__)
 #define ZKV_HD __host__ __device__ __forceinline__
-#define ZKV_HD_NI __host__ __device__ __noinline__
+#define ZKV_HD_NI __host__ __device__ __noinline__ inline
 #else
 #define ZKV_HD inline
-#define ZKV_HD_NI
+#define ZKV_HD_NI inline
 #endif
 
 namespace zkv {

@@ -1,0 +1,55 @@
+// Internal interface between the C-ABI translation unit and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "zkv_verify.h"
+
+namespace zkv {
+
+// Per-chunk workspace in HBM, struct-of-arrays: word k of proof i lives at base[k * cap + i], so the 64 lanes
+// of a wavefront read/write 256 contiguous bytes per word (coalesced).
+constexpr int WS_PREP_WORDS = 80;   // ax ay cx cy (4x8) | bx.c0 bx.c1 by.c0 by.c1 (4x8) | s0 s1 (2x8)
+constexpr int WS_NORM_WORDS = 48;   // axs ays lxs lys cxs cys
+constexpr int WS_F_WORDS = 96;      // Fp12 Miller value (slot F of the final exponentiation)
+constexpr int WS_FE_WORDS = 4 * 96; // cold Fp12 slots E, Y1, Y3, Y4 of the final exponentiation
+struct Workspace {
+    uint32_t* prep; uint32_t* norm; uint32_t* f; uint32_t* fe; uint32_t* flags;
+    size_t cap;
+};
+
+constexpr int ZKV_BLOCK = 64;       // one wavefront per workgroup: one proof per lane, no cross-lane traffic
+
+__device__ __forceinline__ Fp ws_ld(const uint32_t* base, size_t cap, int word0, size_t i) {
+    Fp r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.v[k] = base[(size_t)(word0 + k) * cap + i];
+    return r;
+}
+__device__ __forceinline__ void ws_st(uint32_t* base, size_t cap, int word0, size_t i, const Fp& a) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) base[(size_t)(word0 + k) * cap + i] = a.v[k];
+}
+
+struct PrepArgs {
+    size_t n;
+    const uint8_t* blob;        // seals / proofs
+    const uint64_t* off;        // n+1 offsets, or nullptr for fixed stride
+    uint32_t stride;            // bytes per record when off == nullptr
+    const uint8_t* in32_a;      // risc0: image_ids (or claim digests when in32_b == nullptr); sp1: program vkeys
+    const uint8_t* in32_b;      // risc0: journal digests; sp1: unused
+    const uint8_t* pv_blob;     // sp1 public values
+    const uint64_t* pv_off;     // sp1: n+1 offsets or nullptr
+    uint32_t pv_stride;
+    uint32_t selector_be;       // expected selector as big-endian word
+    uint32_t force_fail;        // context-level VerificationFailed (risc0 bn254_control_id >= R)
+    uint8_t* status; uint8_t* recv;
+};
+
+void launch_setup(const VkRaw* d_raw, VkTables* d_tab, hipStream_t s);
+void launch_prep_risc0(const PrepArgs& a, const Risc0Consts& k, const Workspace& ws, hipStream_t s);
+void launch_prep_sp1(const PrepArgs& a, const Workspace& ws, hipStream_t s);
+void launch_msm(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
+void launch_g2chk(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
+void launch_miller(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
+void launch_finalexp(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
+
+}  // namespace zkv

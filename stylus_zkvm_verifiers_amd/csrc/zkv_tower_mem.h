@@ -1,0 +1,123 @@
+// Fp12-level operations on memory-resident operands.
+//
+// Why this layer exists: one proof per lane keeps ~1.5 KB of live tower state per lane.  Letting the
+// compiler hold all of it in VGPRs across a fully inlined Miller loop / final exponentiation produces
+// multi-hour compiles and thousands of scratch spills on gfx950.  Instead every Fp12 value lives in a
+// word-strided memory slot -- LDS for the hot accumulator f and the running point T (lane-interleaved,
+// conflict-free: word k of lane l at base[k*64 + l]), HBM struct-of-arrays slots for the few cold values of
+// the final exponentiation -- and each Fp12-level operation is one non-inlined function whose temporaries
+// (a few Fp6) are register resident.  fp_mul is the non-inlined leaf.
+#pragma once
+#include "zkv_curve.h"
+
+namespace zkv {
+
+struct MRef { uint32_t* p; uint32_t stride; };     // word k of this lane's value: p[k * stride]
+
+ZKV_HD MRef m_off(MRef m, int words) { MRef r; r.p = m.p + (size_t)words * m.stride; r.stride = m.stride; return r; }
+ZKV_HD Fp m_ld_fp(MRef m, int word0) {
+    Fp r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.v[k] = m.p[(size_t)(word0 + k) * m.stride];
+    return r;
+}
+ZKV_HD void m_st_fp(MRef m, int word0, const Fp& a) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) m.p[(size_t)(word0 + k) * m.stride] = a.v[k];
+}
+ZKV_HD Fp2 m_ld_f2(MRef m, int idx) { Fp2 r; r.c0 = m_ld_fp(m, 16 * idx); r.c1 = m_ld_fp(m, 16 * idx + 8); return r; }
+ZKV_HD void m_st_f2(MRef m, int idx, const Fp2& a) { m_st_fp(m, 16 * idx, a.c0); m_st_fp(m, 16 * idx + 8, a.c1); }
+ZKV_HD Fp6 m_ld_f6(MRef m, int idx) { Fp6 r; r.c0 = m_ld_f2(m, idx); r.c1 = m_ld_f2(m, idx + 1); r.c2 = m_ld_f2(m, idx + 2); return r; }
+ZKV_HD void m_st_f6(MRef m, int idx, const Fp6& a) { m_st_f2(m, idx, a.c0); m_st_f2(m, idx + 1, a.c1); m_st_f2(m, idx + 2, a.c2); }
+ZKV_HD void m_st_f12(MRef m, const Fp12& a) { m_st_f6(m, 0, a.c0); m_st_f6(m, 3, a.c1); }
+ZKV_HD Fp12 m_ld_f12(MRef m) { Fp12 r; r.c0 = m_ld_f6(m, 0); r.c1 = m_ld_f6(m, 3); return r; }
+ZKV_HD void f12m_copy(MRef d, MRef a) {
+#pragma unroll 1
+    for (int k = 0; k < 96; k++) d.p[(size_t)k * d.stride] = a.p[(size_t)k * a.stride];
+}
+ZKV_HD void f12m_set_one(MRef d) {
+    Fp one = fp_one();
+#pragma unroll 1
+    for (int k = 0; k < 96; k++) d.p[(size_t)k * d.stride] = k < 8 ? one.v[k] : 0u;
+}
+ZKV_HD void f12m_conj(MRef d) {            // in place: negate h
+#pragma unroll 1
+    for (int k = 6; k < 12; k++) m_st_fp(d, 8 * k, fp_neg(m_ld_fp(d, 8 * k)));
+}
+
+// f <- f^2 (complex squaring, 12 Fp2 products)
+ZKV_HD_NI void f12m_sqr(MRef f) {
+    Fp6 g = m_ld_f6(f, 0), h = m_ld_f6(f, 3);
+    Fp6 t = f6_mul(g, h);
+    Fp6 s = f6_mul(f6_add(g, h), f6_add(g, f6_mul_v(h)));
+    m_st_f6(f, 0, f6_sub(f6_sub(s, t), f6_mul_v(t)));
+    m_st_f6(f, 3, f6_add(t, t));
+}
+// d <- a * b (d may alias a or b)
+ZKV_HD_NI void f12m_mul(MRef d, MRef a, MRef b) {
+    Fp6 ag = m_ld_f6(a, 0), bg = m_ld_f6(b, 0);
+    Fp6 t0 = f6_mul(ag, bg);
+    Fp6 ah = m_ld_f6(a, 3), bh = m_ld_f6(b, 3);
+    Fp6 t1 = f6_mul(ah, bh);
+    Fp6 m = f6_mul(f6_add(ag, ah), f6_add(bg, bh));
+    m_st_f6(d, 3, f6_sub(f6_sub(m, t0), t1));
+    m_st_f6(d, 0, f6_add(t0, f6_mul_v(t1)));
+}
+// f <- f * (c0 + (c3 + c4 v) w)
+ZKV_HD_NI void f12m_mul_by_034(MRef f, const Fp2* c0, const Fp2* c3, const Fp2* c4) {
+    Fp6 g = m_ld_f6(f, 0), h = m_ld_f6(f, 3);
+    Fp6 t0 = f6_mul_fp2(g, *c0);
+    Fp6 t1 = f6_mul_by_01(h, *c3, *c4);
+    Fp6 t2 = f6_mul_by_01(f6_add(g, h), f2_add(*c0, *c3), *c4);
+    m_st_f6(f, 3, f6_sub(f6_sub(t2, t0), t1));
+    m_st_f6(f, 0, f6_add(t0, f6_mul_v(t1)));
+}
+// f <- f * (1 + (c3 + c4 v) w)
+ZKV_HD_NI void f12m_mul_by_134(MRef f, const Fp2* c3, const Fp2* c4) {
+    Fp6 g = m_ld_f6(f, 0), h = m_ld_f6(f, 3);
+    Fp6 hs = f6_mul_by_01(h, *c3, *c4);
+    Fp6 gs = f6_mul_by_01(g, *c3, *c4);
+    m_st_f6(f, 0, f6_add(g, f6_mul_v(hs)));
+    m_st_f6(f, 3, f6_add(h, gs));
+}
+// d <- a^-1
+ZKV_HD_NI void f12m_inv(MRef d, MRef a) {
+    Fp6 g = m_ld_f6(a, 0), h = m_ld_f6(a, 3);
+    Fp6 t = f6_sub(f6_mul(g, g), f6_mul_v(f6_mul(h, h)));
+    t = f6_inv(t);
+    m_st_f6(d, 0, f6_mul(g, t));
+    m_st_f6(d, 3, f6_neg(f6_mul(h, t)));
+}
+// d <- pi^k(a), k = 1, 2, 3 (d may alias a)
+ZKV_HD_NI void f12m_frob(MRef d, MRef a, int k) {
+    const Fp2 G1[6] = ZKV_FROB1;
+    const Fp G2[6] = ZKV_FROB2;
+    const Fp2 G3[6] = ZKV_FROB3;
+    // memory order g0 g1 g2 h0 h1 h2 <-> w-powers 0 2 4 1 3 5
+    const int wp[6] = {0, 2, 4, 1, 3, 5};
+#pragma unroll 1
+    for (int i = 0; i < 6; i++) {
+        Fp2 c = m_ld_f2(a, i);
+        int e = wp[i];
+        if (k == 2) c = f2_mul_fp(c, G2[e]);
+        else {
+            c = f2_conj(c);
+            if (e) c = f2_mul(c, k == 1 ? G1[e] : G3[e]);
+        }
+        m_st_f2(d, i, c);
+    }
+}
+
+// T <- 2T with tangent-line coefficients (T is 3 Fp2 in memory)
+ZKV_HD_NI void g2m_line_dbl(MRef Tm, Fp2* l0, Fp2* l1, Fp2* l3) {
+    G2H T; T.x = m_ld_f2(Tm, 0); T.y = m_ld_f2(Tm, 1); T.z = m_ld_f2(Tm, 2);
+    line_dbl(T, *l0, *l1, *l3);
+    m_st_f2(Tm, 0, T.x); m_st_f2(Tm, 1, T.y); m_st_f2(Tm, 2, T.z);
+}
+ZKV_HD_NI void g2m_line_add(MRef Tm, const Fp2* qx, const Fp2* qy, Fp2* l0, Fp2* l1, Fp2* l3) {
+    G2H T; T.x = m_ld_f2(Tm, 0); T.y = m_ld_f2(Tm, 1); T.z = m_ld_f2(Tm, 2);
+    line_add(T, *qx, *qy, *l0, *l1, *l3);
+    m_st_f2(Tm, 0, T.x); m_st_f2(Tm, 1, T.y); m_st_f2(Tm, 2, T.z);
+}
+
+}  // namespace zkv

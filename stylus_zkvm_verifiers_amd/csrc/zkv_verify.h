@@ -10,7 +10,7 @@
 //   stage MILLER  + FINALEXP   the ecPairing precompile itself (groth16.rs:109-128)
 // The functions are __host__ __device__ so tests/host_sim can run the identical code on the CPU.
 #pragma once
-#include "zkv_curve.h"
+#include "zkv_tower_mem.h"
 #include "zkv_sha256.h"
 
 namespace zkv {
@@ -177,66 +177,110 @@ ZKV_HD void msm_normalize(const VkTables& vk, const PrepOut& in, uint32_t& flags
 // ---------------------------------------------------------------- stage MILLER
 // Shared-accumulator Miller loop over (A',B) [variable Q, projective], (L,gamma), (C,delta) [fixed Q,
 // precomputed slope lines]; multiplied by the precomputed Miller value of (alpha, beta).
-ZKV_HD Fp12 miller_loop(const VkTables& vk, uint32_t flags, const G1Norm& n, const Fp2& bx, const Fp2& by,
-                        bool with_fixed) {
+// fm: the Fp12 accumulator slot, tm: the 3 x Fp2 running point T (both LDS on the device).
+ZKV_HD void fixed_line_mul(MRef fm, const LineAff& L, const Fp& xs, const Fp& ys) {
+    Fp2 c3 = f2_mul_fp(L.nl, xs), c4 = f2_mul_fp(L.c, ys);
+    f12m_mul_by_134(fm, &c3, &c4);
+}
+ZKV_HD void var_line_mul(MRef fm, const Fp2& l0, const Fp2& l1, const Fp2& l3, const Fp& xs, const Fp& ys) {
+    Fp2 c3 = f2_mul_fp(l1, xs), c4 = f2_mul_fp(l3, ys);
+    f12m_mul_by_034(fm, &l0, &c3, &c4);
+}
+ZKV_HD void miller_loop_m(const VkTables& vk, uint32_t flags, const G1Norm& n, const Fp2& bx, const Fp2& by,
+                          bool with_fixed, MRef fm, MRef tm) {
     bool do_ab = !(flags & (FL_A_INF | FL_B_INF));
-    bool do_k[2] = {with_fixed && !(flags & FL_L_INF), with_fixed && !(flags & FL_C_INF)};
-    const Fp* kxs[2] = {&n.lxs, &n.cxs};
-    const Fp* kys[2] = {&n.lys, &n.cys};
-    Fp12 f = f12_one();
-    G2H T; T.x = bx; T.y = by; T.z = f2_one();
+    bool do_l = with_fixed && !(flags & FL_L_INF), do_c = with_fixed && !(flags & FL_C_INF);
+    f12m_set_one(fm);
+    m_st_f2(tm, 0, bx); m_st_f2(tm, 1, by); m_st_f2(tm, 2, f2_one());
     Fp2 nby = f2_neg(by);
     Fp2 l0, l1, l3;
     int li = 0;
 #pragma unroll 1
     for (int i = ZKV_ATE_NAF_LEN - 2; i >= 0; i--) {
-        if (i != ZKV_ATE_NAF_LEN - 2) f = f12_sqr(f);
+        if (i != ZKV_ATE_NAF_LEN - 2) f12m_sqr(fm);
         if (do_ab) {
-            line_dbl(T, l0, l1, l3);
-            f = f12_mul_by_034(f, l0, f2_mul_fp(l1, n.axs), f2_mul_fp(l3, n.ays));
+            g2m_line_dbl(tm, &l0, &l1, &l3);
+            var_line_mul(fm, l0, l1, l3, n.axs, n.ays);
         }
-#pragma unroll 1
-        for (int k = 0; k < 2; k++)
-            if (do_k[k]) {
-                const LineAff& L = vk.lines[k][li];
-                f = f12_mul_by_134(f, f2_mul_fp(L.nl, *kxs[k]), f2_mul_fp(L.c, *kys[k]));
-            }
+        if (do_l) fixed_line_mul(fm, vk.lines[0][li], n.lxs, n.lys);
+        if (do_c) fixed_line_mul(fm, vk.lines[1][li], n.cxs, n.cys);
         li++;
         int d = ate_naf(i);
         if (d != 0) {
             if (do_ab) {
-                line_add(T, bx, d > 0 ? by : nby, l0, l1, l3);
-                f = f12_mul_by_034(f, l0, f2_mul_fp(l1, n.axs), f2_mul_fp(l3, n.ays));
+                Fp2 qy = d > 0 ? by : nby;
+                g2m_line_add(tm, &bx, &qy, &l0, &l1, &l3);
+                var_line_mul(fm, l0, l1, l3, n.axs, n.ays);
             }
-#pragma unroll 1
-            for (int k = 0; k < 2; k++)
-                if (do_k[k]) {
-                    const LineAff& L = vk.lines[k][li];
-                    f = f12_mul_by_134(f, f2_mul_fp(L.nl, *kxs[k]), f2_mul_fp(L.c, *kys[k]));
-                }
+            if (do_l) fixed_line_mul(fm, vk.lines[0][li], n.lxs, n.lys);
+            if (do_c) fixed_line_mul(fm, vk.lines[1][li], n.cxs, n.cys);
             li++;
         }
     }
-    Fp2 q1x, q1y, q2x, q2y;
-    g2_frob_affine(q1x, q1y, bx, by);
-    g2_frob2_affine(q2x, q2y, bx, by);
-    q2y = f2_neg(q2y);
+    Fp2 qx[2], qy[2];
+    g2_frob_affine(qx[0], qy[0], bx, by);
+    g2_frob2_affine(qx[1], qy[1], bx, by);
+    qy[1] = f2_neg(qy[1]);
 #pragma unroll 1
     for (int s = 0; s < 2; s++) {
         if (do_ab) {
-            line_add(T, s ? q2x : q1x, s ? q2y : q1y, l0, l1, l3);
-            f = f12_mul_by_034(f, l0, f2_mul_fp(l1, n.axs), f2_mul_fp(l3, n.ays));
+            g2m_line_add(tm, &qx[s], &qy[s], &l0, &l1, &l3);
+            var_line_mul(fm, l0, l1, l3, n.axs, n.ays);
         }
-#pragma unroll 1
-        for (int k = 0; k < 2; k++)
-            if (do_k[k]) {
-                const LineAff& L = vk.lines[k][li];
-                f = f12_mul_by_134(f, f2_mul_fp(L.nl, *kxs[k]), f2_mul_fp(L.c, *kys[k]));
-            }
+        if (do_l) fixed_line_mul(fm, vk.lines[0][li], n.lxs, n.lys);
+        if (do_c) fixed_line_mul(fm, vk.lines[1][li], n.cxs, n.cys);
         li++;
     }
-    if (with_fixed) f = f12_mul(f, vk.f_alpha_beta);
-    return f;
+}
+
+// ---------------------------------------------------------------- stage FINALEXP
+// acc <- x^u  (acc and x are different slots)
+ZKV_HD void exp_u_m(MRef acc, MRef x) {
+    f12m_copy(acc, x);
+#pragma unroll 1
+    for (int i = 61; i >= 0; i--) {
+        f12m_sqr(acc);
+        if ((ZKV_BN_U >> i) & 1ULL) f12m_mul(acc, acc, x);
+    }
+}
+ZKV_HD bool f12m_is_one(MRef a) {
+    Fp one = fp_one();
+    uint32_t o = 0;
+#pragma unroll 1
+    for (int k = 0; k < 96; k++) o |= a.p[(size_t)k * a.stride] ^ (k < 8 ? one.v[k] : 0u);
+    return o == 0;
+}
+// f^(k (p^12-1)/r) == 1 with k = 2u(6u^2+3u+1), gcd(k, r) = 1  (Fuentes-Castaneda hard part; the chain is
+// checked symbolically in tests).  F holds the Miller value on entry (clobbered); E, Y1, Y3, Y4 are scratch
+// slots; acc is the hot accumulator (LDS on the device).
+ZKV_HD bool final_exp_is_one_m(MRef F, MRef E, MRef Y1, MRef Y3, MRef Y4, MRef acc) {
+    f12m_copy(acc, F); f12m_conj(acc);
+    f12m_inv(F, F);
+    f12m_mul(acc, acc, F);                  // f^(p^6-1)
+    f12m_frob(F, acc, 2);
+    f12m_mul(E, F, acc);                    // e = ^(p^2+1)
+    exp_u_m(acc, E); f12m_conj(acc);        // y0
+    f12m_sqr(acc); f12m_copy(Y1, acc);      // y1
+    f12m_sqr(acc);                          // y2
+    f12m_mul(acc, acc, Y1); f12m_copy(Y3, acc);     // y3
+    exp_u_m(acc, Y3); f12m_conj(acc); f12m_copy(Y4, acc);   // y4
+    f12m_sqr(acc); f12m_copy(F, acc);       // y5
+    exp_u_m(acc, F);                        // y6 (two conjugations cancel)
+    f12m_conj(Y3);
+    f12m_mul(acc, acc, Y4);                 // y7
+    f12m_mul(acc, acc, Y3); f12m_copy(Y3, acc);     // y8
+    f12m_mul(F, acc, Y1);                   // y9
+    f12m_mul(acc, acc, Y4);                 // y10
+    f12m_mul(acc, acc, E);                  // y11
+    f12m_frob(Y1, F, 1);
+    f12m_mul(acc, Y1, acc);                 // y13
+    f12m_frob(Y3, Y3, 2);
+    f12m_mul(acc, Y3, acc);                 // y14
+    f12m_conj(E);
+    f12m_mul(E, E, F);
+    f12m_frob(E, E, 3);                     // y15
+    f12m_mul(acc, E, acc);
+    return f12m_is_one(acc);
 }
 
 // ---------------------------------------------------------------- context set-up (run once per VK on the device)
@@ -292,17 +336,20 @@ ZKV_HD void setup_msm_row(const VkRaw& vk, VkTables& t, int b, int w) {
     G1J p; p.x = fp_from_raw(vk.ic[ici][0]); p.y = fp_from_raw(vk.ic[ici][1]); p.z = fp_one();
 #pragma unroll 1
     for (int i = 0; i < 4 * w; i++) p = g1j_dbl(p);
-    G1A pa; uint32_t inf;
-    g1j_to_affine(p, pa, inf);
-    G1J acc = g1j_infinity();
-    t.msm[b][w][0].x = fp_zero(); t.msm[b][w][0].y = fp_zero();
+    Fp zi = fp_inv(p.z), zi2 = fp_sqr(zi);
+    Fp px = fp_mul(p.x, zi2), py = fp_mul(p.y, fp_mul(zi2, zi));
+    G1J acc; acc.x = px; acc.y = py; acc.z = fp_one();
+    G1A* row = t.msm[b][w];
+    row[0].x = fp_zero(); row[0].y = fp_zero();
+    row[1].x = px; row[1].y = py;
 #pragma unroll 1
-    for (int d = 1; d < 16; d++) {
-        acc = g1j_add_affine(acc, pa.x, pa.y);
-        g1j_to_affine(acc, t.msm[b][w][d], inf);
+    for (int d = 2; d < 16; d++) {
+        acc = g1j_add_affine(acc, px, py);
+        Fp ai = fp_inv(acc.z), ai2 = fp_sqr(ai);
+        row[d].x = fp_mul(acc.x, ai2); row[d].y = fp_mul(acc.y, fp_mul(ai2, ai));
     }
 }
-ZKV_HD void setup_alpha_beta(const VkRaw& vk, VkTables& t) {
+ZKV_HD void setup_alpha_beta(const VkRaw& vk, VkTables& t, MRef fm, MRef tm) {
     Fp ax = fp_from_raw(vk.alpha[0]), ay = fp_from_raw(vk.alpha[1]);
     Fp iy = fp_inv(ay);
     G1Norm n; n.axs = fp_mul(ax, iy); n.ays = iy;
@@ -310,7 +357,8 @@ ZKV_HD void setup_alpha_beta(const VkRaw& vk, VkTables& t) {
     Fp2 bx, by;
     bx.c0 = fp_from_raw(vk.beta[0]); bx.c1 = fp_from_raw(vk.beta[1]);
     by.c0 = fp_from_raw(vk.beta[2]); by.c1 = fp_from_raw(vk.beta[3]);
-    t.f_alpha_beta = miller_loop(t, 0, n, bx, by, false);
+    miller_loop_m(t, 0, n, bx, by, false, fm, tm);
+    t.f_alpha_beta = m_ld_f12(fm);
 }
 
 }  // namespace zkv

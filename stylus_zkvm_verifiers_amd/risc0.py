@@ -1,0 +1,119 @@
+"""Host-side mirror of `IRiscZeroVerifier` / `RiscZeroVerifier`
+(/root/reference/contracts/src/risc0/verifier.rs:18-196) over the C ABI of libzkv_mi355x.so.
+
+Same method names, argument meaning and error behaviour as the reference trait; the batch methods are the
+MI355X-native addition (one call, many proofs, one status byte per proof)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .errors import (STATUS_OK, STATUS_SELECTOR_MISMATCH, VM_RISC0, VerifierError)
+
+
+def _blob(items):
+    off = np.zeros(len(items) + 1, dtype=np.uint64)
+    if len(items):
+        off[1:] = np.cumsum([len(s) for s in items], dtype=np.uint64)
+    return b''.join(bytes(s) for s in items) + b'\0', off
+
+
+def _cat32(items, what):
+    for x in items:
+        if len(x) != 32:
+            raise ValueError('%s must be 32 bytes' % what)
+    return b''.join(bytes(x) for x in items) + b'\0'
+
+
+class RiscZeroVerifier:
+    def __init__(self, device=0):
+        self._L = _lib.lib()
+        self._h = self._L.zkv_risc0_ctx_new(device)
+        if not self._h:
+            raise MemoryError('zkv_risc0_ctx_new')
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._L.zkv_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- IRiscZeroVerifier
+    def initialize(self, control_root, bn254_control_id):
+        """verifier.rs:58-76.  Raises VerifierError(AlreadyInitialized) on a second call."""
+        st = C.c_uint8(0)
+        _lib.check(self._L.zkv_risc0_initialize(self._h, bytes(control_root), bytes(bn254_control_id), C.byref(st)),
+                   'zkv_risc0_initialize')
+        if st.value != STATUS_OK:
+            raise VerifierError(VM_RISC0, st.value)
+
+    def verify(self, seal, image_id, journal_digest):
+        """verifier.rs:78-92: returns True or raises VerifierError (the reference never returns Ok(false))."""
+        st = C.c_uint8(0); rv = C.create_string_buffer(4)
+        _lib.check(self._L.zkv_risc0_verify(self._h, bytes(seal), len(seal), bytes(image_id), bytes(journal_digest),
+                                            C.byref(st), rv), 'zkv_risc0_verify')
+        return self._result(st.value, rv.raw)
+
+    def verify_integrity(self, receipt_seal, receipt_claim_digest):
+        """verifier.rs:94-104."""
+        st = C.c_uint8(0); rv = C.create_string_buffer(4)
+        _lib.check(self._L.zkv_risc0_verify_integrity(self._h, bytes(receipt_seal), len(receipt_seal),
+                                                      bytes(receipt_claim_digest), C.byref(st), rv), 'zkv_risc0_verify_integrity')
+        return self._result(st.value, rv.raw)
+
+    def get_selector(self):
+        o = C.create_string_buffer(4); _lib.check(self._L.zkv_risc0_get_selector(self._h, o), 'get_selector'); return o.raw
+
+    def get_control_root(self):
+        a, b = C.create_string_buffer(16), C.create_string_buffer(16)
+        _lib.check(self._L.zkv_risc0_get_control_root(self._h, a, b), 'get_control_root')
+        return a.raw, b.raw
+
+    def get_bn254_control_id(self):
+        o = C.create_string_buffer(32); _lib.check(self._L.zkv_risc0_get_bn254_control_id(self._h, o), 'get_bn254_control_id'); return o.raw
+
+    def get_verifier_key_digest(self):
+        o = C.create_string_buffer(32); _lib.check(self._L.zkv_risc0_get_verifier_key_digest(self._h, o), 'get_verifier_key_digest'); return o.raw
+
+    def is_initialized(self):
+        return bool(self._L.zkv_risc0_is_initialized(self._h))
+
+    def _result(self, status, recv):
+        if status == STATUS_OK:
+            return True
+        if status == STATUS_SELECTOR_MISMATCH:
+            raise VerifierError(VM_RISC0, status, recv, self.get_selector())
+        raise VerifierError(VM_RISC0, status)
+
+    # ---- batch (host buffers, ragged seals)
+    def verify_batch(self, seals, image_ids, journal_digests):
+        """One status byte per proof (errors.STATUS_*), plus the received selector of mismatching seals."""
+        n = len(seals)
+        blob, off = _blob(seals)
+        st = np.zeros(n, dtype=np.uint8); rv = np.zeros((n, 4), dtype=np.uint8)
+        _lib.check(self._L.zkv_risc0_verify_batch(self._h, n, blob, off.ctypes.data, _cat32(image_ids, 'image_id'),
+                                                  _cat32(journal_digests, 'journal_digest'), st.ctypes.data, rv.ctypes.data),
+                   'zkv_risc0_verify_batch')
+        return st, rv
+
+    def verify_integrity_batch(self, seals, claim_digests):
+        n = len(seals)
+        blob, off = _blob(seals)
+        st = np.zeros(n, dtype=np.uint8); rv = np.zeros((n, 4), dtype=np.uint8)
+        _lib.check(self._L.zkv_risc0_verify_integrity_batch(self._h, n, blob, off.ctypes.data, _cat32(claim_digests, 'claim_digest'),
+                                                            st.ctypes.data, rv.ctypes.data), 'zkv_risc0_verify_integrity_batch')
+        return st, rv
+
+    # ---- batch, inputs already resident in HBM (device pointers as ints; 260-byte stride)
+    def verify_batch_dev(self, n, d_seals, d_image_ids, d_journal_digests, d_status, d_recv=0, stream=0):
+        _lib.check(self._L.zkv_risc0_verify_batch_dev(self._h, n, d_seals, d_image_ids, d_journal_digests, d_status,
+                                                      d_recv or None, stream or None), 'zkv_risc0_verify_batch_dev')
+
+    def synchronize(self):
+        _lib.check(self._L.zkv_ctx_synchronize(self._h), 'zkv_ctx_synchronize')
+
+    def last_stage_ms(self):
+        out = (C.c_float * 5)()
+        _lib.check(self._L.zkv_ctx_last_stage_ms(self._h, out), 'zkv_ctx_last_stage_ms')
+        return list(out)

@@ -1,0 +1,64 @@
+"""Host-side mirror of `ISp1Verifier` / `Sp1Verifier`
+(/root/reference/contracts/src/sp1/verifier.rs:16-111) over the C ABI of libzkv_mi355x.so."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .errors import STATUS_OK, STATUS_SELECTOR_MISMATCH, VM_SP1, VerifierError
+from .risc0 import _blob, _cat32
+
+
+class Sp1Verifier:
+    def __init__(self, device=0):
+        self._L = _lib.lib()
+        self._h = self._L.zkv_sp1_ctx_create(device)
+        if not self._h:
+            raise MemoryError('zkv_sp1_ctx_create')
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._L.zkv_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- ISp1Verifier
+    def verify_proof(self, program_vkey, public_values, proof_bytes):
+        """sp1/verifier.rs:39-46, 58-111: returns None or raises VerifierError."""
+        st = C.c_uint8(0); rv = C.create_string_buffer(4)
+        _lib.check(self._L.zkv_sp1_verify_proof(self._h, bytes(program_vkey), bytes(public_values), len(public_values),
+                                                bytes(proof_bytes), len(proof_bytes), C.byref(st), rv), 'zkv_sp1_verify_proof')
+        if st.value == STATUS_OK:
+            return None
+        if st.value == STATUS_SELECTOR_MISMATCH:
+            raise VerifierError(VM_SP1, st.value, rv.raw, self.verifier_hash()[:4])
+        raise VerifierError(VM_SP1, st.value)
+
+    def verifier_hash(self):
+        o = C.create_string_buffer(32); self._L.zkv_sp1_verifier_hash(o); return o.raw
+
+    def version(self):
+        return self._L.zkv_sp1_version().decode()
+
+    # ---- batch
+    def verify_batch(self, program_vkeys, public_values, proofs):
+        n = len(proofs)
+        pblob, poff = _blob(proofs)
+        vblob, voff = _blob(public_values)
+        st = np.zeros(n, dtype=np.uint8); rv = np.zeros((n, 4), dtype=np.uint8)
+        _lib.check(self._L.zkv_sp1_verify_batch(self._h, n, _cat32(program_vkeys, 'program_vkey'), vblob, voff.ctypes.data,
+                                                pblob, poff.ctypes.data, st.ctypes.data, rv.ctypes.data), 'zkv_sp1_verify_batch')
+        return st, rv
+
+    def verify_batch_dev(self, n, d_vkeys, d_public_values, pv_len, d_proofs, d_status, d_recv=0, stream=0):
+        _lib.check(self._L.zkv_sp1_verify_batch_dev(self._h, n, d_vkeys, d_public_values, pv_len, d_proofs, d_status,
+                                                    d_recv or None, stream or None), 'zkv_sp1_verify_batch_dev')
+
+    def synchronize(self):
+        _lib.check(self._L.zkv_ctx_synchronize(self._h), 'zkv_ctx_synchronize')
+
+    def last_stage_ms(self):
+        out = (C.c_float * 5)()
+        _lib.check(self._L.zkv_ctx_last_stage_ms(self._h, out), 'zkv_ctx_last_stage_ms')
+        return list(out)

@@ -24,7 +24,7 @@ static VkTables* tables(int vm, const uint8_t* cr, const uint8_t* cid) {
     for (int b = 0; b < 2; b++) for (uint32_t w = 0; w < raw.var_windows[b]; w++) setup_msm_row(raw, *t, b, (int)w);
     setup_lines(raw.gamma, t->lines[0]);
     setup_lines(raw.delta, t->lines[1]);
-    setup_alpha_beta(raw, *t);
+    { uint32_t ab[96 + 48]; MRef fm{ab, 1}, tm{ab + 96, 1}; setup_alpha_beta(raw, *t, fm, tm); }
     g_tab[vm] = t; memcpy(g_key[vm], key, 64);
     return t;
 }
@@ -44,8 +44,14 @@ int hs_groth16(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* wor
     if (!(p.flags & FL_B_INF) && !g2_in_subgroup(p.bx, p.by)) return 0;
     G1Norm n; uint32_t fl = p.flags;
     msm_normalize(*t, p, fl, n);
-    Fp12 f = miller_loop(*t, fl, n, p.bx, p.by, true);
-    return f12_is_one(final_exp(f)) ? 1 : 0;
+    // same slot structure as the kernels: f and T in one buffer (LDS on the device), 5 Fp12 slots for the final exp
+    static thread_local uint32_t buf[96 + 48], slots[5 * 96];
+    MRef fm{buf, 1}, tm{buf + 96, 1};
+    miller_loop_m(*t, fl, n, p.bx, p.by, true, fm, tm);
+    MRef F{slots, 1}, E{slots + 96, 1}, Y1{slots + 192, 1}, Y3{slots + 288, 1}, Y4{slots + 384, 1};
+    m_st_f12(F, t->f_alpha_beta);
+    f12m_mul(F, F, fm);
+    return final_exp_is_one_m(F, E, Y1, Y3, Y4, fm) ? 1 : 0;
 }
 void hs_risc0_scalars(const uint8_t* image_id, const uint8_t* journal, uint8_t* digest32, uint8_t* lo32, uint8_t* hi32) {
     Risc0Consts k; host::risc0_consts(k);
