@@ -1,0 +1,202 @@
+"""Synthetic proof batches for benchmarks and size-independent parity tests.
+
+Valid proofs cannot be forged for the real verification keys, so batches are Groth16 re-randomisations of a
+real proof:  A' = r1^-1 A,  B' = r1 B + r1 r2 delta,  C' = C + r2 A  (public inputs unchanged), which yields
+unlimited distinct valid 260-byte seals for the fixed VK.  A small pool is fully re-randomised (seeded
+SplitMix64); the batch is then filled by walking r2 (B += delta, C += A per step), which costs two affine
+additions per proof.  A configurable fraction is mutated into proofs that must NOT verify.
+
+Pure Python big-int arithmetic, independent of both the HIP kernels and oracle/ (the generator is part of the
+product tooling: the reference leaves proof generation as a TODO, examples/risc0-verifier/examples/interact.rs:110).
+"""
+import numpy as np
+
+U = 4965661367192848881
+P = 36 * U**4 + 36 * U**3 + 24 * U**2 + 6 * U + 1
+R = 36 * U**4 + 36 * U**3 + 18 * U**2 + 6 * U + 1
+
+# delta2 of the two verification keys in the reference's word order (x_im, x_re, y_im, y_re):
+# risc0/crypto.rs:43-52 and sp1/crypto.rs:48-59 (the SP1 key stores -delta).
+RISC0_DELTA = (0x03B03CD5EFFA95AC9BEE94F1F5EF907157BDA4812CCF0B4C91F42BB629F83A1C, 0x1AA085FF28179A12D922DBA0547057CCAAE94B9D69CFAA4E60401FEA7F3E0333,
+               0x110C10134F200B19F6490846D518C9AEA868366EFB7228CA5C91D2940D030762, 0x1E60F31FCBF757E837E867178318832D0B2D74D59E2FEA1C7142DF187D3FC6D3)
+SP1_DELTA_NEG = (0x1CC7CB8DE715675F21F01ECC9B46D236E0865E0CC020024521998269845F74E6, 0x03FF41F4BA0C37FE2CAF27354D28E4B8F83D3B76777A63B327D736BFFB0122ED,
+                 0x01909CD7827E0278E6B60843A4ABC7B111D7F8B2725CD5902A6B20DA7A2938FB, 0x192BD3274441670227B4F69A44005B8711266E474227C6439CA25CA8E1EC1FC2)
+
+MUTATION_CLASSES = ('flip_c_x', 'flip_input', 'b_out_of_subgroup', 'coord_plus_q', 'wrong_selector')
+
+
+class SplitMix64:
+    def __init__(self, seed):
+        self.s = seed & 0xFFFFFFFFFFFFFFFF
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return z ^ (z >> 31)
+
+    def below(self, n):
+        v = 0
+        for _ in range(5):
+            v = (v << 64) | self.next()
+        return v % n
+
+    def scalar(self):
+        return 1 + self.below(R - 1)
+
+
+# ---------------------------------------------------------------- tiny affine BN254 arithmetic (None = infinity)
+def _f2mul(a, b): return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+def _f2sub(a, b): return ((a[0] - b[0]) % P, (a[1] - b[1]) % P)
+def _f2add(a, b): return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
+def _f2inv(a):
+    d = pow(a[0] * a[0] + a[1] * a[1], -1, P)
+    return (a[0] * d % P, -a[1] * d % P)
+
+
+def g1_add(p, q):
+    if p is None: return q
+    if q is None: return p
+    if p[0] == q[0]:
+        if (p[1] + q[1]) % P == 0:
+            return None
+        lam = 3 * p[0] * p[0] * pow(2 * p[1], -1, P) % P
+    else:
+        lam = (q[1] - p[1]) * pow(q[0] - p[0], -1, P) % P
+    x = (lam * lam - p[0] - q[0]) % P
+    return (x, (lam * (p[0] - x) - p[1]) % P)
+
+
+def g1_mul(p, k):
+    acc = None
+    while k:
+        if k & 1:
+            acc = g1_add(acc, p)
+        p = g1_add(p, p)
+        k >>= 1
+    return acc
+
+
+def g2_add(p, q):
+    if p is None: return q
+    if q is None: return p
+    if p[0] == q[0]:
+        if _f2add(p[1], q[1]) == (0, 0):
+            return None
+        x2 = _f2mul(p[0], p[0])
+        lam = _f2mul(((3 * x2[0]) % P, (3 * x2[1]) % P), _f2inv(((2 * p[1][0]) % P, (2 * p[1][1]) % P)))
+    else:
+        lam = _f2mul(_f2sub(q[1], p[1]), _f2inv(_f2sub(q[0], p[0])))
+    x = _f2sub(_f2sub(_f2mul(lam, lam), p[0]), q[0])
+    return (x, _f2sub(_f2mul(lam, _f2sub(p[0], x)), p[1]))
+
+
+def g2_mul(p, k):
+    acc = None
+    while k:
+        if k & 1:
+            acc = g2_add(acc, p)
+        p = g2_add(p, p)
+        k >>= 1
+    return acc
+
+
+def _f2sqrt(a):
+    a0, a1 = a
+    n = (a0 * a0 + a1 * a1) % P
+    s = pow(n, (P + 1) // 4, P)
+    if s * s % P != n:
+        return None
+    inv2 = pow(2, -1, P)
+    for sg in (s, -s % P):
+        t = (a0 + sg) * inv2 % P
+        x0 = pow(t, (P + 1) // 4, P)
+        if x0 and x0 * x0 % P == t:
+            x1 = a1 * pow(2 * x0, -1, P) % P
+            if _f2mul((x0, x1), (x0, x1)) == (a0 % P, a1 % P):
+                return (x0, x1)
+    return None
+
+
+def random_twist_point(rng):
+    """A point on the twist that is (with overwhelming probability) outside the order-r subgroup."""
+    b2 = _f2mul((3, 0), _f2inv((9, 1)))
+    while True:
+        x = (rng.below(P), rng.below(P))
+        y = _f2sqrt(_f2add(_f2mul(_f2mul(x, x), x), b2))
+        if y is not None:
+            return (x, y)
+
+
+# ---------------------------------------------------------------- seal <-> points
+def parse_seal(seal):
+    w = [int.from_bytes(seal[4 + 32 * i:36 + 32 * i], 'big') for i in range(8)]
+    return (w[0], w[1]), ((w[3], w[2]), (w[5], w[4])), (w[6], w[7])         # A, B ((re,im),(re,im)), C
+
+
+def seal_words(a, b, c):
+    (bxr, bxi), (byr, byi) = b
+    return (a[0], a[1], bxi, bxr, byi, byr, c[0], c[1])
+
+
+def _delta_point(words, negate):
+    xi, xr, yi, yr = words
+    pt = ((xr, xi), (yr, yi))
+    return (pt[0], (-pt[1][0] % P, -pt[1][1] % P)) if negate else pt
+
+
+def _write(out, row, selector, words):
+    out[row, :4] = np.frombuffer(selector, dtype=np.uint8)
+    out[row, 4:] = np.frombuffer(b''.join(int(v).to_bytes(32, 'big') for v in words), dtype=np.uint8)
+
+
+def make_batch(vm, base_seal, n, seed, pool=16, mutate_every=64, classes=MUTATION_CLASSES):
+    """Returns (seals uint8[n,260], mutated bool[n], mutation class index int8[n] (-1 = valid), flip_input bool[n]).
+
+    vm: 'risc0' or 'sp1'.  base_seal: a real 260-byte proof for that VM.  `flip_input` marks proofs whose
+    *public input* (journal digest / public values) must have one bit flipped by the caller.
+    """
+    rng = SplitMix64(seed)
+    selector = bytes(base_seal[:4])
+    a0, b0, c0 = parse_seal(base_seal)
+    delta = _delta_point(RISC0_DELTA if vm == 'risc0' else SP1_DELTA_NEG, negate=(vm != 'risc0'))
+    pool = max(1, min(pool, n))
+    state = []
+    for _ in range(pool):
+        r1, r2 = rng.scalar(), rng.scalar()
+        a = g1_mul(a0, pow(r1, -1, R))
+        b = g2_add(g2_mul(b0, r1), g2_mul(delta, r1 * r2 % R))
+        c = g1_add(c0, g1_mul(a0, r2))
+        # walking r2 by one step for THIS pool entry: B += r1 * delta, C += r1 * A'  (A' = r1^-1 A  =>  r1 A' = A)
+        state.append([a, b, c, g2_mul(delta, r1), a0])
+    seals = np.zeros((n, 260), dtype=np.uint8)
+    mutated = np.zeros(n, dtype=bool)
+    mclass = np.full(n, -1, dtype=np.int8)
+    flip_input = np.zeros(n, dtype=bool)
+    oos = random_twist_point(rng) if 'b_out_of_subgroup' in classes else None
+    for i in range(n):
+        st = state[i % pool]
+        a, b, c = st[0], st[1], st[2]
+        words = list(seal_words(a, b, c))
+        sel = selector
+        if mutate_every and i % mutate_every == mutate_every - 1 and classes:
+            k = rng.below(len(classes))
+            name = classes[k]
+            mutated[i] = True
+            mclass[i] = MUTATION_CLASSES.index(name)
+            if name == 'flip_c_x':
+                words[6] ^= 1 << rng.below(250)
+            elif name == 'flip_input':
+                flip_input[i] = True
+            elif name == 'b_out_of_subgroup':
+                words[2:6] = [oos[0][1], oos[0][0], oos[1][1], oos[1][0]]
+            elif name == 'coord_plus_q':
+                j = rng.below(8)
+                words[j] = words[j] + P
+            elif name == 'wrong_selector':
+                sel = bytes([selector[0] ^ 0x01]) + selector[1:]
+        _write(seals, i, sel, words)
+        st[1] = g2_add(b, st[3])
+        st[2] = g1_add(c, st[4])
+    return seals, mutated, mclass, flip_input
