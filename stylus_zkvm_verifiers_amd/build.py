@@ -19,6 +19,7 @@ UNITS = ['k_setup', 'k_prep', 'k_msm', 'k_g2chk', 'k_miller', 'k_finalexp', 'zkv
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-DZKV_FP_MUL_NOINLINE',
          '-Rpass-analysis=kernel-resource-usage']
 COMPILE_TIMEOUT_S = 1500
+EXTRA = os.environ.get('ZKV_EXTRA_FLAGS', '').split()
 
 
 def _hipcc():
@@ -39,7 +40,7 @@ def _compile(unit, force, dep_m):
     log = os.path.join(BUILD, unit + '.log')
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), dep_m):
         return unit, 'cached'
-    cmd = [_hipcc()] + FLAGS + ['-c', src, '-o', obj]
+    cmd = [_hipcc()] + FLAGS + EXTRA + ['-c', src, '-o', obj]
     with open(log, 'w') as lf:
         try:
             rc = subprocess.run(cmd, stdout=lf, stderr=subprocess.STDOUT, timeout=COMPILE_TIMEOUT_S, cwd=CSRC).returncode

@@ -27,18 +27,34 @@ struct Fp6 { Fp2 c0, c1, c2; };
 struct Fp12 { Fp6 c0, c1; };     // c0 = g (w^0,w^2,w^4), c1 = h (w^1,w^3,w^5)
 
 // ---------------------------------------------------------------- carry helpers
+// clang lowers __builtin_addc/__builtin_subc chains to v_add_co/v_addc_co (one instruction per limb);
+// the arithmetic fallback is for host compilers without the builtins (tests/host_sim with g++).
+#if defined(__has_builtin)
+#if __has_builtin(__builtin_addc) && __has_builtin(__builtin_subc)
+#define ZKV_HAVE_CARRY_BUILTINS 1
+#endif
+#endif
 ZKV_HD uint32_t addc(uint32_t a, uint32_t b, uint32_t& carry) {
+#if defined(ZKV_HAVE_CARRY_BUILTINS)
+    unsigned co; uint32_t r = __builtin_addc(a, b, carry, &co); carry = co; return r;
+#else
     uint64_t t = (uint64_t)a + b + carry;
     carry = (uint32_t)(t >> 32);
     return (uint32_t)t;
+#endif
 }
 ZKV_HD uint32_t subb(uint32_t a, uint32_t b, uint32_t& borrow) {
+#if defined(ZKV_HAVE_CARRY_BUILTINS)
+    unsigned bo; uint32_t r = __builtin_subc(a, b, borrow, &bo); borrow = bo; return r;
+#else
     uint64_t t = (uint64_t)a - b - borrow;
     borrow = (uint32_t)(t >> 32) & 1u;
     return (uint32_t)t;
+#endif
 }
 
 // ---------------------------------------------------------------- Fp
+// Canonical residues (< p) in Montgomery form with R = 2^261, stored as 8 x 32-bit limbs.
 ZKV_HD Fp fp_zero() { Fp r; for (int i = 0; i < 8; i++) r.v[i] = 0; return r; }
 ZKV_HD Fp fp_one() { Fp r = ZKV_FP_ONE; return r; }
 ZKV_HD bool fp_is_zero(const Fp& a) {
@@ -81,44 +97,70 @@ ZKV_HD Fp fp_sub(const Fp& a, const Fp& b) {
 ZKV_HD Fp fp_neg(const Fp& a) { return fp_sub(fp_zero(), a); }
 ZKV_HD Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
 
-// Montgomery product a*b*2^-256 mod p, CIOS over 32-bit limbs.  p < 2^254 so the running value stays < 2p
-// and never needs a 10th word.
+// Montgomery product a*b*2^-261 mod p.
+//
+// gfx950 has no carry-in on v_mad_u64_u32 and needs wait states between VCC-chained adds, so a 32-bit-limb CIOS
+// spends more issue slots on carries, zero-extension moves and s_nops than on multiplies (measured: 590
+// instructions, 128 of them multiplies).  The product is therefore formed on 9 x 29-bit limbs: every partial
+// product is < 2^58, so a 64-bit column accumulator takes all 18 terms of a column (9 of a*b, 9 of m*p) without
+// any carry handling -- one v_mad_u64_u32 per term and nothing else -- and carries are extracted once per column
+// with a 64-bit shift.  Operands are unpacked from / packed to the canonical 8 x 32-bit form around the core.
+//   col[k] <= 9*(2^29-1)^2 + 9*(2^29-1)^2 + 2^36 < 2^63.
+// Result = (a*b + m*p) / 2^261 < p*p/2^261 + p < 1.006 p, made canonical by one conditional subtraction.
 #if defined(ZKV_FP_MUL_NOINLINE)
 ZKV_HD_NI
 #else
 ZKV_HD
 #endif
-Fp fp_mul(const Fp& a, const Fp& b) {
+Fp fp_mul(Fp a, Fp b) {   // by value: 16 VGPRs in, 8 out, no scratch traffic at the call
+    const uint32_t P29[9] = ZKV_FP_P29_LIMBS;
     const uint32_t P[8] = ZKV_FP_P_LIMBS;
-    uint32_t t[9];
+    const uint32_t M29 = 0x1fffffffu;
+    uint32_t x[9], y[9];
 #pragma unroll
-    for (int i = 0; i < 9; i++) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint32_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            uint64_t x = (uint64_t)a.v[j] * b.v[i] + t[j] + c;
-            t[j] = (uint32_t)x; c = (uint32_t)(x >> 32);
-        }
-        t[8] += c;
-        uint32_t m = t[0] * ZKV_FP_INV32;
-        uint64_t x = (uint64_t)m * P[0] + t[0];
-        c = (uint32_t)(x >> 32);
-#pragma unroll
-        for (int j = 1; j < 8; j++) {
-            x = (uint64_t)m * P[j] + t[j] + c;
-            t[j - 1] = (uint32_t)x; c = (uint32_t)(x >> 32);
-        }
-        x = (uint64_t)t[8] + c;
-        t[7] = (uint32_t)x; t[8] = (uint32_t)(x >> 32);
+    for (int k = 0; k < 9; k++) {                 // unpack 8 x 32 -> 9 x 29
+        const int bit = 29 * k, w = bit >> 5, s = bit & 31;
+        uint32_t xa = a.v[w] >> s, yb = b.v[w] >> s;
+        if (s > 3 && w < 7) { xa |= a.v[w + 1] << (32 - s); yb |= b.v[w + 1] << (32 - s); }
+        x[k] = xa & M29; y[k] = yb & M29;
     }
-    Fp r, s; uint32_t br = 0;
+    uint64_t col[18];
 #pragma unroll
-    for (int i = 0; i < 8; i++) s.v[i] = subb(t[i], P[i], br);
+    for (int k = 0; k < 18; k++) col[k] = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = br ? t[i] : s.v[i];
-    return r;
+    for (int i = 0; i < 9; i++) {                 // 81 independent-column multiply-accumulates
+#pragma unroll
+        for (int j = 0; j < 9; j++) col[i + j] += (uint64_t)x[i] * y[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) {                 // Montgomery reduction, one 29-bit digit per step
+        uint32_t m = ((uint32_t)col[i] * ZKV_FP_INV29) & M29;
+#pragma unroll
+        for (int j = 0; j < 9; j++) col[i + j] += (uint64_t)m * P29[j];
+        col[i + 1] += col[i] >> 29;               // low 29 bits of col[i] are now zero
+    }
+    uint32_t r[9];
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+        r[k - 9] = (uint32_t)col[k] & M29;
+        col[k + 1] += col[k] >> 29;
+    }
+    r[8] = (uint32_t)col[17];
+    uint32_t t[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) {                 // pack 9 x 29 -> 8 x 32
+        const int bit = 32 * w, k = bit / 29, s = bit - 29 * k, got = 29 - s;
+        uint32_t v = r[k] >> s;
+        if (k + 1 < 9) v |= r[k + 1] << got;
+        if (got + 29 < 32 && k + 2 < 9) v |= r[k + 2] << (got + 29);
+        t[w] = v;
+    }
+    Fp o, sb; uint32_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) sb.v[i] = subb(t[i], P[i], br);
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.v[i] = br ? t[i] : sb.v[i];
+    return o;
 }
 ZKV_HD Fp fp_sqr(const Fp& a) { return fp_mul(a, a); }
 
