@@ -53,6 +53,31 @@ ZKV_HD_NI void f12m_sqr(MRef f) {
     m_st_f6(f, 0, f6_sub(f6_sub(s, t), f6_mul_v(t)));
     m_st_f6(f, 3, f6_add(t, t));
 }
+// f <- f^2 for f in the cyclotomic subgroup (after the easy part of the final exponentiation):
+// Granger-Scott, three Fp4 squarings = 6 Fp2 products instead of 12.
+ZKV_HD void fp4_sqr(const Fp2& a, const Fp2& b, Fp2& t0, Fp2& t1) {     // (a + b y)^2, y^2 = xi
+    Fp2 tmp = f2_mul(a, b);
+    t0 = f2_sub(f2_sub(f2_mul(f2_add(a, b), f2_add(f2_mul_xi(b), a)), tmp), f2_mul_xi(tmp));
+    t1 = f2_dbl(tmp);
+}
+ZKV_HD_NI void f12m_cyclo_sqr(MRef f) {
+    // memory order g0 g1 g2 h0 h1 h2; pairs (g0,h1), (h0,g2), (g1,h2)
+    Fp2 z0 = m_ld_f2(f, 0), z1 = m_ld_f2(f, 4), t0, t1;
+    fp4_sqr(z0, z1, t0, t1);
+    z0 = f2_sub(t0, z0); z0 = f2_add(f2_dbl(z0), t0);           // 3 t0 - 2 z0
+    z1 = f2_add(t1, z1); z1 = f2_add(f2_dbl(z1), t1);           // 3 t1 + 2 z1
+    m_st_f2(f, 0, z0); m_st_f2(f, 4, z1);
+    Fp2 z2 = m_ld_f2(f, 3), z3 = m_ld_f2(f, 2), t2, t3;
+    fp4_sqr(z2, z3, t2, t3);
+    Fp2 z4 = m_ld_f2(f, 1), z5 = m_ld_f2(f, 5), t4, t5;
+    fp4_sqr(z4, z5, t4, t5);
+    Fp2 x = f2_mul_xi(t5);
+    z2 = f2_add(x, z2); z2 = f2_add(f2_dbl(z2), x);             // 3 xi t5 + 2 z2
+    z3 = f2_sub(t4, z3); z3 = f2_add(f2_dbl(z3), t4);           // 3 t4 - 2 z3
+    z4 = f2_sub(t2, z4); z4 = f2_add(f2_dbl(z4), t2);           // 3 t2 - 2 z4
+    z5 = f2_add(t3, z5); z5 = f2_add(f2_dbl(z5), t3);           // 3 t3 + 2 z5
+    m_st_f2(f, 3, z2); m_st_f2(f, 2, z3); m_st_f2(f, 1, z4); m_st_f2(f, 5, z5);
+}
 // d <- a * b (d may alias a or b)
 ZKV_HD_NI void f12m_mul(MRef d, MRef a, MRef b) {
     Fp6 ag = m_ld_f6(a, 0), bg = m_ld_f6(b, 0);

@@ -234,12 +234,12 @@ ZKV_HD void miller_loop_m(const VkTables& vk, uint32_t flags, const G1Norm& n, c
 }
 
 // ---------------------------------------------------------------- stage FINALEXP
-// acc <- x^u  (acc and x are different slots)
+// acc <- x^u  (acc and x are different slots; x in the cyclotomic subgroup)
 ZKV_HD void exp_u_m(MRef acc, MRef x) {
     f12m_copy(acc, x);
 #pragma unroll 1
     for (int i = 61; i >= 0; i--) {
-        f12m_sqr(acc);
+        f12m_cyclo_sqr(acc);
         if ((ZKV_BN_U >> i) & 1ULL) f12m_mul(acc, acc, x);
     }
 }
@@ -260,11 +260,11 @@ ZKV_HD bool final_exp_is_one_m(MRef F, MRef E, MRef Y1, MRef Y3, MRef Y4, MRef a
     f12m_frob(F, acc, 2);
     f12m_mul(E, F, acc);                    // e = ^(p^2+1)
     exp_u_m(acc, E); f12m_conj(acc);        // y0
-    f12m_sqr(acc); f12m_copy(Y1, acc);      // y1
-    f12m_sqr(acc);                          // y2
+    f12m_cyclo_sqr(acc); f12m_copy(Y1, acc);    // y1
+    f12m_cyclo_sqr(acc);                    // y2
     f12m_mul(acc, acc, Y1); f12m_copy(Y3, acc);     // y3
     exp_u_m(acc, Y3); f12m_conj(acc); f12m_copy(Y4, acc);   // y4
-    f12m_sqr(acc); f12m_copy(F, acc);       // y5
+    f12m_cyclo_sqr(acc); f12m_copy(F, acc); // y5
     exp_u_m(acc, F);                        // y6 (two conjugations cancel)
     f12m_conj(Y3);
     f12m_mul(acc, acc, Y4);                 // y7

@@ -70,6 +70,19 @@ void hs_fp_mulmod(const uint8_t* a, const uint8_t* b, uint8_t* out) {
     fp_to_raw(r, fp_mul(fp_from_raw(x), fp_from_raw(y)));
     for (int i = 0; i < 8; i++) for (int k = 0; k < 4; k++) out[31 - 4 * i - k] = r[i] >> (8 * k);
 }
+// returns 1 when the Granger-Scott cyclotomic squaring equals the generic squaring on a random element of the
+// cyclotomic subgroup (x^((p^6-1)(p^2+1)) for x built from the seed bytes)
+int hs_cyclo_sqr_check(const uint8_t* seed384) {
+    uint32_t buf[4 * 96];
+    MRef X{buf, 1}, A{buf + 96, 1}, B{buf + 192, 1}, C{buf + 288, 1};
+    for (int k = 0; k < 12; k++) { uint32_t w[8]; load_be256(w, seed384 + 32 * k); w[7] &= 0x0fffffffu; m_st_fp(X, 8 * k, fp_from_raw(w)); }
+    f12m_copy(A, X); f12m_conj(A); f12m_inv(B, X); f12m_mul(A, A, B);      // ^(p^6-1)
+    f12m_frob(B, A, 2); f12m_mul(A, B, A);                                  // ^(p^2+1)
+    f12m_copy(B, A); f12m_copy(C, A);
+    f12m_sqr(B); f12m_cyclo_sqr(C);
+    for (int k = 0; k < 96; k++) if (buf[192 + k] != buf[288 + k]) return 0;
+    return f12m_is_one(A) ? -1 : 1;
+}
 int hs_g2_in_subgroup(const uint8_t* q128) {     // EIP-197 order: x_im x_re y_im y_re; must be on twist
     uint32_t w[4][8];
     for (int k = 0; k < 4; k++) load_be256(w[k], q128 + 32 * k);

@@ -1,0 +1,95 @@
+"""C ABI on a machine without a GPU: the library loads, exports every symbol include/zkv.h declares, the host-side
+context logic (initialize / selector / VK digest / revert bytes) matches the golden vectors, and compute entry points
+fail loudly (ZKV_ERR_NO_DEVICE) instead of falling back to a CPU path."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H = bytes.fromhex
+
+
+@pytest.fixture(scope='module')
+def z():
+    from stylus_zkvm_verifiers_amd import build
+    build.build(verbose=False)
+    import stylus_zkvm_verifiers_amd as pkg
+    return pkg
+
+
+def test_every_declared_symbol_is_exported(z):
+    from stylus_zkvm_verifiers_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'zkv.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(zkv_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 25
+    L = C.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), 'missing export: ' + name
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+
+
+def test_risc0_context_host_logic(z, real_proofs):
+    r = real_proofs['risc0']
+    v = z.RiscZeroVerifier()
+    assert not v.is_initialized()
+    assert v.get_selector() == b'\0' * 4
+    v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    assert v.is_initialized()
+    assert v.get_selector().hex() == r['selector']
+    assert tuple(x.hex() for x in v.get_control_root()) == (r['control_root_0'], r['control_root_1'])
+    assert v.get_bn254_control_id().hex() == r['bn254_control_id']
+    assert v.get_verifier_key_digest().hex() == r['vk_digest']
+    with pytest.raises(z.VerifierError) as ei:
+        v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    assert ei.value.status == z.errors.STATUS_ALREADY_INITIALIZED
+    assert ei.value.revert.hex() == '0dc149f0'
+
+
+def test_sp1_constants(z, real_proofs):
+    s = z.Sp1Verifier()
+    assert s.version() == real_proofs['sp1']['version'] == 'v5.0.0'
+    assert s.verifier_hash().hex() == real_proofs['sp1']['verifier_hash']
+    assert s.verifier_hash()[:4].hex() == real_proofs['sp1']['selector']
+
+
+def test_revert_bytes(z, revert_vectors):
+    for c in revert_vectors:
+        vm = 0 if c['vm'] == 'risc0' else 1
+        assert z.errors.revert_bytes(vm, c['status'], H(c['received']), H(c['expected'])).hex() == c['revert']
+
+
+def test_uninitialised_verifier_needs_no_device(z, real_proofs):
+    """risc0/verifier.rs:84-86: the initialisation gate comes before everything else."""
+    r = real_proofs['risc0']
+    v = z.RiscZeroVerifier()
+    st, rv = v.verify_batch([H(r['seal'])] * 3, [H(r['image_id'])] * 3, [H(r['journal_digest'])] * 3)
+    assert list(st) == [2, 2, 2]
+    with pytest.raises(z.VerifierError) as ei:
+        v.verify(H(r['seal']), H(r['image_id']), H(r['journal_digest']))
+    assert ei.value.status == 2 and ei.value.revert.hex() == 'f92ee8a9'
+
+
+def test_no_cpu_fallback(z, real_proofs):
+    if z.device_count() > 0:
+        pytest.skip('a gfx950 device is present')
+    from stylus_zkvm_verifiers_amd import _lib
+    r = real_proofs['risc0']
+    v = z.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    with pytest.raises(_lib.ZkvRuntimeError) as ei:
+        v.verify(H(r['seal']), H(r['image_id']), H(r['journal_digest']))
+    assert ei.value.code == _lib.ERR_NO_DEVICE
+    s = real_proofs['sp1']
+    with pytest.raises(_lib.ZkvRuntimeError):
+        z.Sp1Verifier().verify_proof(H(s['vkey']), H(s['public_values']), H(s['proof']))
+
+
+def test_argument_validation(z):
+    from stylus_zkvm_verifiers_amd import _lib
+    L = _lib.lib()
+    assert L.zkv_risc0_get_selector(None, C.create_string_buffer(4)) == _lib.ERR_WRONG_CTX
+    sp = z.Sp1Verifier()
+    assert L.zkv_risc0_get_selector(sp._h, C.create_string_buffer(4)) == _lib.ERR_WRONG_CTX
+    assert L.zkv_status_abi_encode(7, 1, b'\0' * 4, b'\0' * 4, C.create_string_buffer(68)) == _lib.ERR_INVALID_ARG

@@ -1,0 +1,80 @@
+"""The exact stage functions the HIP kernels run (stylus_zkvm_verifiers_amd/csrc/zkv_*.h), compiled for the host
+(tests/host_sim) and checked against the spec model and the golden corpus.  CPU only; complements the -m gpu tests.
+Everything beyond the two real proofs is "parity unpinned" (SURVEY.md 8c)."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import pytest
+
+import spec_model as m
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+H = bytes.fromhex
+
+
+@pytest.fixture(scope='module')
+def hs():
+    src = os.path.join(HERE, 'host_sim', 'host_sim.cpp')
+    lib = os.path.join(HERE, 'host_sim', 'libhost_sim.so')
+    deps = [src] + [os.path.join(HERE, '..', 'stylus_zkvm_verifiers_amd', 'csrc', f)
+                    for f in os.listdir(os.path.join(HERE, '..', 'stylus_zkvm_verifiers_amd', 'csrc')) if f.endswith('.h')]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-Wno-unknown-pragmas', '-o', lib, src])
+    return C.CDLL(lib)
+
+
+def test_fp_mul_matches_bigint(hs):
+    rng = random.Random(7)
+    vals = [0, 1, 2, m.P - 1, m.P - 2, (1 << 253), (1 << 253) - 1] + [rng.randrange(m.P) for _ in range(300)]
+    for i in range(len(vals) - 1):
+        a, b = vals[i], vals[(i * 7 + 3) % len(vals)]
+        o = C.create_string_buffer(32)
+        hs.hs_fp_mulmod(a.to_bytes(32, 'big'), b.to_bytes(32, 'big'), o)
+        assert int.from_bytes(o.raw, 'big') == a * b % m.P
+
+
+def test_digest_chain(hs, real_proofs):
+    r = real_proofs['risc0']
+    d, lo, hi = (C.create_string_buffer(32) for _ in range(3))
+    hs.hs_risc0_scalars(H(r['image_id']), H(r['journal_digest']), d, lo, hi)
+    assert d.raw.hex() == r['claim_digest']
+    assert (lo.raw.hex(), hi.raw.hex()) == (r['signals'][2], r['signals'][3])
+    sel, vkd = C.create_string_buffer(4), C.create_string_buffer(32)
+    hs.hs_risc0_selector(H(r['control_root']), H(r['bn254_control_id']), sel, vkd)
+    assert sel.raw.hex() == r['selector'] and vkd.raw.hex() == r['vk_digest']
+
+
+def test_cyclotomic_square_equals_generic(hs):
+    for _ in range(4):
+        assert hs.hs_cyclo_sqr_check(os.urandom(384)) == 1
+
+
+def test_g2_subgroup_check_matches_r_torsion(hs, precompile_kats):
+    for c in precompile_kats['g2_subgroup']:
+        if not c['on_twist'] or all(int(w, 16) == 0 for w in c['point']):
+            continue
+        assert hs.hs_g2_in_subgroup(H(''.join(c['point']))) == (1 if c['in_subgroup'] else 0)
+
+
+def test_groth16_core_on_corpus(hs, verify_corpus, real_proofs):
+    """Cases that reach the Groth16 core (valid selector, 260 bytes): accept <=> status OK."""
+    r0 = real_proofs['risc0']
+    cr, cid = H(r0['control_root']), H(r0['bn254_control_id'])
+    v = m.Risc0Verifier(); v.initialize(cr, cid)
+    n = 0
+    for c in verify_corpus['cases']:
+        if c['status'] not in (0, 1):
+            continue
+        if c['vm'] == 'risc0':
+            seal = H(c['seal'])
+            sig = v.signals(m.receipt_claim_ok_digest(H(c['image_id']), H(c['journal_digest'])))
+            acc = hs.hs_groth16(0, cr, cid, seal[4:], m.be32(sig[2]), m.be32(sig[3]))
+        else:
+            proof = H(c['proof'])
+            s0 = H(c['vkey']); s1 = m.be32(m.sp1_hash_public_values(H(c['public_values'])))
+            acc = hs.hs_groth16(1, None, None, proof[4:], s0, s1)
+        assert acc == (1 if c['status'] == 0 else 0), c['name']
+        n += 1
+    assert n > 40
