@@ -96,6 +96,35 @@ ZKV_HD Fp fp_sub(const Fp& a, const Fp& b) {
 }
 ZKV_HD Fp fp_neg(const Fp& a) { return fp_sub(fp_zero(), a); }
 ZKV_HD Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
+// a + b without the modular reduction: for sums that only feed fp_mul (which accepts any 256-bit operand and
+// returns a canonical result).  Caller guarantees a + b < 2^256 (at most four canonical values summed: 4p < 2^256).
+ZKV_HD Fp fp_add_nr(const Fp& a, const Fp& b) {
+    Fp t; uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t.v[i] = addc(a.v[i], b.v[i], c);
+    return t;
+}
+// Two independent modular additions / subtractions with their carry chains interleaved limb by limb: gfx950 needs
+// wait states between a carry-writing VALU op and the dependent v_addc/v_subb, and the second chain fills them.
+ZKV_HD void fp_add_x2(const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1, Fp& r0, Fp& r1) {
+    const uint32_t P[8] = ZKV_FP_P_LIMBS;
+    Fp t0, t1, s0, s1; uint32_t c0 = 0, c1 = 0, w0 = 0, w1 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { t0.v[i] = addc(a0.v[i], b0.v[i], c0); t1.v[i] = addc(a1.v[i], b1.v[i], c1); }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { s0.v[i] = subb(t0.v[i], P[i], w0); s1.v[i] = subb(t1.v[i], P[i], w1); }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { r0.v[i] = w0 ? t0.v[i] : s0.v[i]; r1.v[i] = w1 ? t1.v[i] : s1.v[i]; }
+}
+ZKV_HD void fp_sub_x2(const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1, Fp& r0, Fp& r1) {
+    const uint32_t P[8] = ZKV_FP_P_LIMBS;
+    Fp t0, t1; uint32_t w0 = 0, w1 = 0, c0 = 0, c1 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { t0.v[i] = subb(a0.v[i], b0.v[i], w0); t1.v[i] = subb(a1.v[i], b1.v[i], w1); }
+    uint32_t m0 = 0u - w0, m1 = 0u - w1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { r0.v[i] = addc(t0.v[i], P[i] & m0, c0); r1.v[i] = addc(t1.v[i], P[i] & m1, c1); }
+}
 
 // Montgomery product a*b*2^-261 mod p.
 //
@@ -191,20 +220,25 @@ ZKV_HD Fp2 f2_zero() { Fp2 r; r.c0 = fp_zero(); r.c1 = fp_zero(); return r; }
 ZKV_HD Fp2 f2_one() { Fp2 r; r.c0 = fp_one(); r.c1 = fp_zero(); return r; }
 ZKV_HD bool f2_is_zero(const Fp2& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
 ZKV_HD bool f2_eq(const Fp2& a, const Fp2& b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
-ZKV_HD Fp2 f2_add(const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = fp_add(a.c0, b.c0); r.c1 = fp_add(a.c1, b.c1); return r; }
-ZKV_HD Fp2 f2_sub(const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = fp_sub(a.c0, b.c0); r.c1 = fp_sub(a.c1, b.c1); return r; }
-ZKV_HD Fp2 f2_neg(const Fp2& a) { Fp2 r; r.c0 = fp_neg(a.c0); r.c1 = fp_neg(a.c1); return r; }
+ZKV_HD Fp2 f2_add(const Fp2& a, const Fp2& b) { Fp2 r; fp_add_x2(a.c0, b.c0, a.c1, b.c1, r.c0, r.c1); return r; }
+ZKV_HD Fp2 f2_sub(const Fp2& a, const Fp2& b) { Fp2 r; fp_sub_x2(a.c0, b.c0, a.c1, b.c1, r.c0, r.c1); return r; }
+ZKV_HD Fp2 f2_neg(const Fp2& a) { Fp2 r; Fp z = fp_zero(); fp_sub_x2(z, a.c0, z, a.c1, r.c0, r.c1); return r; }
+// lazy sum (components < 2p) that may only be passed to f2_mul
+ZKV_HD Fp2 f2_add_nr(const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = fp_add_nr(a.c0, b.c0); r.c1 = fp_add_nr(a.c1, b.c1); return r; }
 ZKV_HD Fp2 f2_dbl(const Fp2& a) { return f2_add(a, a); }
 ZKV_HD Fp2 f2_conj(const Fp2& a) { Fp2 r; r.c0 = a.c0; r.c1 = fp_neg(a.c1); return r; }
+// Karatsuba; operand components may be lazy sums < 2p (their sums stay < 4p < 2^256), the result is canonical.
 ZKV_HD Fp2 f2_mul(const Fp2& a, const Fp2& b) {
     Fp t0 = fp_mul(a.c0, b.c0), t1 = fp_mul(a.c1, b.c1);
-    Fp m = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
-    Fp2 r; r.c0 = fp_sub(t0, t1); r.c1 = fp_sub(fp_sub(m, t0), t1);
+    Fp m = fp_mul(fp_add_nr(a.c0, a.c1), fp_add_nr(b.c0, b.c1));
+    Fp2 r; Fp u;
+    fp_sub_x2(t0, t1, m, t0, r.c0, u);
+    r.c1 = fp_sub(u, t1);
     return r;
 }
-ZKV_HD Fp2 f2_sqr(const Fp2& a) {
+ZKV_HD Fp2 f2_sqr(const Fp2& a) {           // canonical input
     Fp m = fp_mul(a.c0, a.c1);
-    Fp2 r; r.c0 = fp_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1)); r.c1 = fp_dbl(m);
+    Fp2 r; r.c0 = fp_mul(fp_add_nr(a.c0, a.c1), fp_sub(a.c0, a.c1)); r.c1 = fp_dbl(m);
     return r;
 }
 ZKV_HD Fp2 f2_mul_fp(const Fp2& a, const Fp& k) { Fp2 r; r.c0 = fp_mul(a.c0, k); r.c1 = fp_mul(a.c1, k); return r; }
@@ -229,16 +263,16 @@ ZKV_HD Fp6 f6_mul_v(const Fp6& a) { Fp6 r; r.c0 = f2_mul_xi(a.c2); r.c1 = a.c0; 
 ZKV_HD Fp6 f6_mul(const Fp6& a, const Fp6& b) {
     Fp2 v0 = f2_mul(a.c0, b.c0), v1 = f2_mul(a.c1, b.c1), v2 = f2_mul(a.c2, b.c2);
     Fp6 r;
-    r.c0 = f2_add(v0, f2_mul_xi(f2_sub(f2_sub(f2_mul(f2_add(a.c1, a.c2), f2_add(b.c1, b.c2)), v1), v2)));
-    r.c1 = f2_add(f2_sub(f2_sub(f2_mul(f2_add(a.c0, a.c1), f2_add(b.c0, b.c1)), v0), v1), f2_mul_xi(v2));
-    r.c2 = f2_add(f2_sub(f2_sub(f2_mul(f2_add(a.c0, a.c2), f2_add(b.c0, b.c2)), v0), v2), v1);
+    r.c0 = f2_add(v0, f2_mul_xi(f2_sub(f2_sub(f2_mul(f2_add_nr(a.c1, a.c2), f2_add_nr(b.c1, b.c2)), v1), v2)));
+    r.c1 = f2_add(f2_sub(f2_sub(f2_mul(f2_add_nr(a.c0, a.c1), f2_add_nr(b.c0, b.c1)), v0), v1), f2_mul_xi(v2));
+    r.c2 = f2_add(f2_sub(f2_sub(f2_mul(f2_add_nr(a.c0, a.c2), f2_add_nr(b.c0, b.c2)), v0), v2), v1);
     return r;
 }
 // a * (b0 + b1 v)   (5 Fp2 products)
 ZKV_HD Fp6 f6_mul_by_01(const Fp6& a, const Fp2& b0, const Fp2& b1) {
     Fp2 v0 = f2_mul(a.c0, b0), v1 = f2_mul(a.c1, b1);
     Fp6 r;
-    r.c1 = f2_sub(f2_sub(f2_mul(f2_add(a.c0, a.c1), f2_add(b0, b1)), v0), v1);
+    r.c1 = f2_sub(f2_sub(f2_mul(f2_add_nr(a.c0, a.c1), f2_add_nr(b0, b1)), v0), v1);
     r.c0 = f2_add(v0, f2_mul_xi(f2_mul(a.c2, b1)));
     r.c2 = f2_add(v1, f2_mul(a.c2, b0));
     return r;
