@@ -79,13 +79,35 @@ class Shard:
         self.stage_samples += 1
 
 
+def host_cores():
+    """CPU threads this process may actually use: affinity mask, capped by the cgroup CPU quota when one is set."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(shard, budget_s=15.0):
     """The CPU oracle (oracle/zkv_oracle.c, a port of the reference-shaped path) on the host cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import oracle_lib as ol
     H = bytes.fromhex
     g = golden()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     def run(k):
         seals = [shard.h_seals[i].tobytes() for i in range(k)]
         a = [shard.h_a[i].tobytes() for i in range(k)]

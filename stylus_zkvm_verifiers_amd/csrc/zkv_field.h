@@ -19,6 +19,10 @@
 #define ZKV_HD_NI inline
 #endif
 
+#if defined(ZKV_COUNT_FP_MUL)
+static unsigned long long zkv_fp_mul_counter = 0;
+#endif
+
 namespace zkv {
 
 struct Fp { uint32_t v[8]; };
@@ -142,6 +146,9 @@ ZKV_HD_NI
 ZKV_HD
 #endif
 Fp fp_mul(Fp a, Fp b) {   // by value: 16 VGPRs in, 8 out, no scratch traffic at the call
+#if defined(ZKV_COUNT_FP_MUL)
+    zkv_fp_mul_counter++;     // host-only op counter of tests/host_sim (algorithmic work per stage)
+#endif
     const uint32_t P29[9] = ZKV_FP_P29_LIMBS;
     const uint32_t P[8] = ZKV_FP_P_LIMBS;
     const uint32_t M29 = 0x1fffffffu;

@@ -1,0 +1,130 @@
+// C++ host-side mirror of the reference traits over the C ABI (include/zkv.h).
+//
+//   zkv::RiscZeroVerifier  <->  trait IRiscZeroVerifier + struct RiscZeroVerifier
+//                               (/root/reference/contracts/src/risc0/verifier.rs:18-52)
+//   zkv::Sp1Verifier       <->  trait ISp1Verifier + struct Sp1Verifier (contracts/src/sp1/verifier.rs:16-33)
+//
+// Same method names, argument meaning and error behaviour: the reference returns Result<_, Vec<u8>> whose error
+// is the ABI-encoded Solidity custom error; here `Result::err` holds exactly those bytes.  Library/runtime failures
+// (no device, HIP errors) are thrown as zkv::RuntimeError -- they are never verification outcomes.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/zkv.h"
+
+namespace zkv {
+
+using Bytes = std::vector<uint8_t>;
+using B256 = std::array<uint8_t, 32>;
+using B128 = std::array<uint8_t, 16>;
+using Bytes4 = std::array<uint8_t, 4>;
+
+struct RuntimeError : std::runtime_error {
+    int code;
+    RuntimeError(int c, const char* where) : std::runtime_error(std::string(where) + " failed with ZKV error " + std::to_string(c)), code(c) {}
+};
+inline void check(int rc, const char* where) { if (rc != ZKV_OK) throw RuntimeError(rc, where); }
+
+template <class T>
+struct Result {            // Result<T, Vec<u8>>
+    bool ok;
+    T value;
+    Bytes err;             // ABI-encoded revert bytes when !ok
+    uint8_t status;        // ZKV_STATUS_*
+};
+
+inline Bytes revert_bytes(int vm, uint8_t status, const uint8_t received[4], const uint8_t expected[4]) {
+    uint8_t buf[68];
+    int n = zkv_status_abi_encode(vm, status, received, expected, buf);
+    if (n < 0) throw RuntimeError(n, "zkv_status_abi_encode");
+    return Bytes(buf, buf + n);
+}
+
+class RiscZeroVerifier {
+public:
+    explicit RiscZeroVerifier(int device = 0) : ctx_(zkv_risc0_ctx_new(device)) { if (!ctx_) throw std::bad_alloc(); }
+    ~RiscZeroVerifier() { zkv_ctx_destroy(ctx_); }
+    RiscZeroVerifier(const RiscZeroVerifier&) = delete;
+    RiscZeroVerifier& operator=(const RiscZeroVerifier&) = delete;
+
+    // fn initialize(&mut self, control_root: B256, bn254_control_id: B256) -> Result<(), Self::Error>
+    Result<bool> initialize(const B256& control_root, const B256& bn254_control_id) {
+        uint8_t st = 0;
+        check(zkv_risc0_initialize(ctx_, control_root.data(), bn254_control_id.data(), &st), "zkv_risc0_initialize");
+        return make(st, nullptr);
+    }
+    // fn verify(&self, seal: Vec<u8>, image_id: B256, journal_digest: B256) -> Result<bool, Self::Error>
+    Result<bool> verify(const Bytes& seal, const B256& image_id, const B256& journal_digest) const {
+        uint8_t st = 0, rv[4] = {0, 0, 0, 0};
+        check(zkv_risc0_verify(ctx_, seal.data(), seal.size(), image_id.data(), journal_digest.data(), &st, rv), "zkv_risc0_verify");
+        return make(st, rv);
+    }
+    // fn verify_integrity(&self, receipt_seal: Vec<u8>, receipt_claim_digest: B256) -> Result<bool, Self::Error>
+    Result<bool> verify_integrity(const Bytes& receipt_seal, const B256& receipt_claim_digest) const {
+        uint8_t st = 0, rv[4] = {0, 0, 0, 0};
+        check(zkv_risc0_verify_integrity(ctx_, receipt_seal.data(), receipt_seal.size(), receipt_claim_digest.data(), &st, rv),
+              "zkv_risc0_verify_integrity");
+        return make(st, rv);
+    }
+    Bytes4 get_selector() const { Bytes4 o; check(zkv_risc0_get_selector(ctx_, o.data()), "get_selector"); return o; }
+    std::pair<B128, B128> get_control_root() const {
+        std::pair<B128, B128> o; check(zkv_risc0_get_control_root(ctx_, o.first.data(), o.second.data()), "get_control_root"); return o;
+    }
+    B256 get_bn254_control_id() const { B256 o; check(zkv_risc0_get_bn254_control_id(ctx_, o.data()), "get_bn254_control_id"); return o; }
+    B256 get_verifier_key_digest() const { B256 o; check(zkv_risc0_get_verifier_key_digest(ctx_, o.data()), "get_verifier_key_digest"); return o; }
+    bool is_initialized() const { return zkv_risc0_is_initialized(ctx_) != 0; }
+
+    // Batch form: n ragged seals, n image ids, n journal digests -> n status bytes (+ received selectors).
+    void verify_batch(size_t n, const uint8_t* seal_blob, const uint64_t* seal_off, const uint8_t* image_ids, const uint8_t* journal_digests,
+                      uint8_t* status, uint8_t* recv_selector = nullptr) const {
+        check(zkv_risc0_verify_batch(ctx_, n, seal_blob, seal_off, image_ids, journal_digests, status, recv_selector), "zkv_risc0_verify_batch");
+    }
+    zkv_ctx* raw() const { return ctx_; }
+
+private:
+    Result<bool> make(uint8_t st, const uint8_t* rv) const {
+        Result<bool> r{st == ZKV_STATUS_OK, st == ZKV_STATUS_OK, {}, st};
+        if (!r.ok) {
+            Bytes4 exp = get_selector();
+            static const uint8_t zero[4] = {0, 0, 0, 0};
+            r.err = revert_bytes(ZKV_VM_RISC0, st, rv ? rv : zero, exp.data());
+        }
+        return r;
+    }
+    zkv_ctx* ctx_;
+};
+
+class Sp1Verifier {
+public:
+    explicit Sp1Verifier(int device = 0) : ctx_(zkv_sp1_ctx_create(device)) { if (!ctx_) throw std::bad_alloc(); }
+    ~Sp1Verifier() { zkv_ctx_destroy(ctx_); }
+    Sp1Verifier(const Sp1Verifier&) = delete;
+    Sp1Verifier& operator=(const Sp1Verifier&) = delete;
+
+    // fn verify_proof(&self, program_vkey: B256, public_values: Vec<u8>, proof_bytes: Vec<u8>) -> Result<(), Self::Error>
+    Result<bool> verify_proof(const B256& program_vkey, const Bytes& public_values, const Bytes& proof_bytes) const {
+        uint8_t st = 0, rv[4] = {0, 0, 0, 0};
+        check(zkv_sp1_verify_proof(ctx_, program_vkey.data(), public_values.data(), public_values.size(), proof_bytes.data(), proof_bytes.size(),
+                                   &st, rv), "zkv_sp1_verify_proof");
+        Result<bool> r{st == ZKV_STATUS_OK, st == ZKV_STATUS_OK, {}, st};
+        if (!r.ok) { B256 h = verifier_hash(); r.err = revert_bytes(ZKV_VM_SP1, st, rv, h.data()); }
+        return r;
+    }
+    B256 verifier_hash() const { B256 o; zkv_sp1_verifier_hash(o.data()); return o; }
+    std::string version() const { return zkv_sp1_version(); }
+    void verify_batch(size_t n, const uint8_t* vkeys, const uint8_t* pv_blob, const uint64_t* pv_off, const uint8_t* proof_blob,
+                      const uint64_t* proof_off, uint8_t* status, uint8_t* recv_selector = nullptr) const {
+        check(zkv_sp1_verify_batch(ctx_, n, vkeys, pv_blob, pv_off, proof_blob, proof_off, status, recv_selector), "zkv_sp1_verify_batch");
+    }
+    zkv_ctx* raw() const { return ctx_; }
+
+private:
+    zkv_ctx* ctx_;
+};
+
+}  // namespace zkv

@@ -1,0 +1,38 @@
+// Exercises the C++ host mirror (stylus_zkvm_verifiers_amd/host/zkv_verifiers.hpp) against the real RISC Zero proof.
+// argv: control_root bn254_control_id seal image_id journal_digest (hex).  Prints one line of key=value pairs.
+#include <cstdio>
+#include <cstring>
+#include "../../stylus_zkvm_verifiers_amd/host/zkv_verifiers.hpp"
+
+static zkv::Bytes unhex(const char* h) {
+    zkv::Bytes o; size_t n = strlen(h) / 2; o.resize(n);
+    for (size_t i = 0; i < n; i++) { unsigned v; sscanf(h + 2 * i, "%2x", &v); o[i] = (uint8_t)v; }
+    return o;
+}
+template <size_t N> static std::array<uint8_t, N> arr(const char* h) { std::array<uint8_t, N> a; auto b = unhex(h); memcpy(a.data(), b.data(), N); return a; }
+static void hex(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) printf("%02x", p[i]); }
+
+int main(int argc, char** argv) {
+    if (argc < 6) return 2;
+    zkv::RiscZeroVerifier v(0);
+    printf("initialized0=%d ", (int)v.is_initialized());
+    auto r1 = v.initialize(arr<32>(argv[1]), arr<32>(argv[2]));
+    auto r2 = v.initialize(arr<32>(argv[1]), arr<32>(argv[2]));
+    printf("init=%d reinit_status=%d reinit_err=", (int)r1.ok, (int)r2.status); hex(r2.err.data(), r2.err.size());
+    auto sel = v.get_selector(); printf(" selector="); hex(sel.data(), 4);
+    auto vkd = v.get_verifier_key_digest(); printf(" vk_digest="); hex(vkd.data(), 32);
+    zkv::Sp1Verifier s(0);
+    printf(" sp1_version=%s", s.version().c_str());
+    if (zkv_device_count() > 0) {
+        auto ok = v.verify(unhex(argv[3]), arr<32>(argv[4]), arr<32>(argv[5]));
+        printf(" verify_ok=%d", (int)ok.ok);
+        zkv::Bytes bad = unhex(argv[3]); bad[0] ^= 1;
+        auto mm = v.verify(bad, arr<32>(argv[4]), arr<32>(argv[5]));
+        printf(" mismatch_status=%d mismatch_err=", (int)mm.status); hex(mm.err.data(), mm.err.size());
+    } else {
+        try { v.verify(unhex(argv[3]), arr<32>(argv[4]), arr<32>(argv[5])); printf(" verify=unexpected"); }
+        catch (const zkv::RuntimeError& e) { printf(" verify_runtime_error=%d", e.code); }
+    }
+    printf("\n");
+    return 0;
+}

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdlib.h>
+#define ZKV_COUNT_FP_MUL 1
 #include "../../stylus_zkvm_verifiers_amd/csrc/zkv_host_vk.h"
 
 using namespace zkv;
@@ -29,7 +30,10 @@ static VkTables* tables(int vm, const uint8_t* cr, const uint8_t* cid) {
     return t;
 }
 
+static unsigned long long g_stage_muls[5];
 extern "C" {
+// Montgomery multiplications spent in each stage (prep, msm, g2chk, miller, finalexp) by the last hs_groth16 call
+void hs_stage_muls(unsigned long long* out) { for (int i = 0; i < 5; i++) out[i] = g_stage_muls[i]; }
 
 // returns 1 accept / 0 reject for the Groth16 core given the 8 proof words and the two per-proof scalars
 int hs_groth16(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* words, const uint8_t* s0, const uint8_t* s1) {
@@ -40,18 +44,25 @@ int hs_groth16(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* wor
     PrepOut p; memset(&p, 0, sizeof p);
     load_be256(p.s[0], s0); load_be256(p.s[1], s1);
     if (!raw_lt_r(p.s[0]) || !raw_lt_r(p.s[1])) return 0;
+    unsigned long long c0 = zkv_fp_mul_counter;
     if (!prep_points(w, vm == 0, p)) return 0;
+    g_stage_muls[0] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
     if (!(p.flags & FL_B_INF) && !g2_in_subgroup(p.bx, p.by)) return 0;
+    g_stage_muls[2] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
     G1Norm n; uint32_t fl = p.flags;
     msm_normalize(*t, p, fl, n);
+    g_stage_muls[1] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
     // same slot structure as the kernels: f and T in one buffer (LDS on the device), 5 Fp12 slots for the final exp
     static thread_local uint32_t buf[96 + 48], slots[5 * 96];
     MRef fm{buf, 1}, tm{buf + 96, 1};
     miller_loop_m(*t, fl, n, p.bx, p.by, true, fm, tm);
+    g_stage_muls[3] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
     MRef F{slots, 1}, E{slots + 96, 1}, Y1{slots + 192, 1}, Y3{slots + 288, 1}, Y4{slots + 384, 1};
     m_st_f12(F, t->f_alpha_beta);
     f12m_mul(F, F, fm);
-    return final_exp_is_one_m(F, E, Y1, Y3, Y4, fm) ? 1 : 0;
+    int acc = final_exp_is_one_m(F, E, Y1, Y3, Y4, fm) ? 1 : 0;
+    g_stage_muls[4] = zkv_fp_mul_counter - c0;
+    return acc;
 }
 void hs_risc0_scalars(const uint8_t* image_id, const uint8_t* journal, uint8_t* digest32, uint8_t* lo32, uint8_t* hi32) {
     Risc0Consts k; host::risc0_consts(k);
