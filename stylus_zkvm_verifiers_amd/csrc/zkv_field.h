@@ -138,42 +138,36 @@ ZKV_HD void fp_sub_x2(const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1, Fp
 // product is < 2^58, so a 64-bit column accumulator takes all 18 terms of a column (9 of a*b, 9 of m*p) without
 // any carry handling -- one v_mad_u64_u32 per term and nothing else -- and carries are extracted once per column
 // with a 64-bit shift.  Operands are unpacked from / packed to the canonical 8 x 32-bit form around the core.
-//   col[k] <= 9*(2^29-1)^2 + 9*(2^29-1)^2 + 2^36 < 2^63.
-// Result = (a*b + m*p) / 2^261 < p*p/2^261 + p < 1.006 p, made canonical by one conditional subtraction.
-#if defined(ZKV_FP_MUL_NOINLINE)
-ZKV_HD_NI
-#else
-ZKV_HD
-#endif
-Fp fp_mul(Fp a, Fp b) {   // by value: 16 VGPRs in, 8 out, no scratch traffic at the call
-#if defined(ZKV_COUNT_FP_MUL)
-    zkv_fp_mul_counter++;     // host-only op counter of tests/host_sim (algorithmic work per stage, DESIGN.md)
-#endif
+// Columns are signed 64-bit so that differences of products (Fp2 Karatsuba below) reduce with the same routine;
+//   |col[k]| <= 9*(2^30)^2 (lazy-sum operands) resp. 18*(2^29)^2 + 9*(2^29)^2 + carry  <  2^63.
+ZKV_HD void fp_unpack29(const Fp& a, uint32_t x[9]) {            // 8 x 32 -> 9 x 29 (any 256-bit value)
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int bit = 29 * k, w = bit >> 5, s = bit & 31;
+        uint32_t v = a.v[w] >> s;
+        if (s > 3 && w < 7) v |= a.v[w + 1] << (32 - s);
+        x[k] = v & 0x1fffffffu;
+    }
+}
+ZKV_HD void fp_mac81(int64_t col[18], const uint32_t x[9], const uint32_t y[9]) {   // col += x * y, 81 independent-column MACs
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) col[i + j] = (int64_t)((uint64_t)col[i + j] + (uint64_t)x[i] * y[j]);
+    }
+}
+// Montgomery reduction of an 18-column value V >= 0 (V = sum col[k] 2^(29k)): returns V * 2^-261 mod p, canonical.
+// Requires V / 2^261 + p < 2p, i.e. V < p * 2^261 (about 169 p^2).
+ZKV_HD Fp fp_reduce_cols(int64_t col[18]) {
     const uint32_t P29[9] = ZKV_FP_P29_LIMBS;
     const uint32_t P[8] = ZKV_FP_P_LIMBS;
     const uint32_t M29 = 0x1fffffffu;
-    uint32_t x[9], y[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) {                 // unpack 8 x 32 -> 9 x 29
-        const int bit = 29 * k, w = bit >> 5, s = bit & 31;
-        uint32_t xa = a.v[w] >> s, yb = b.v[w] >> s;
-        if (s > 3 && w < 7) { xa |= a.v[w + 1] << (32 - s); yb |= b.v[w + 1] << (32 - s); }
-        x[k] = xa & M29; y[k] = yb & M29;
-    }
-    uint64_t col[18];
-#pragma unroll
-    for (int k = 0; k < 18; k++) col[k] = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {                 // 81 independent-column multiply-accumulates
-#pragma unroll
-        for (int j = 0; j < 9; j++) col[i + j] += (uint64_t)x[i] * y[j];
-    }
-#pragma unroll
-    for (int i = 0; i < 9; i++) {                 // Montgomery reduction, one 29-bit digit per step
+    for (int i = 0; i < 9; i++) {                 // one 29-bit digit per step
         uint32_t m = ((uint32_t)col[i] * ZKV_FP_INV29) & M29;
 #pragma unroll
-        for (int j = 0; j < 9; j++) col[i + j] += (uint64_t)m * P29[j];
-        col[i + 1] += col[i] >> 29;               // low 29 bits of col[i] are now zero
+        for (int j = 0; j < 9; j++) col[i + j] = (int64_t)((uint64_t)col[i + j] + (uint64_t)m * P29[j]);
+        col[i + 1] += col[i] >> 29;               // low 29 bits of col[i] are now zero; arithmetic shift
     }
     uint32_t r[9];
 #pragma unroll
@@ -197,6 +191,23 @@ Fp fp_mul(Fp a, Fp b) {   // by value: 16 VGPRs in, 8 out, no scratch traffic at
 #pragma unroll
     for (int i = 0; i < 8; i++) o.v[i] = br ? t[i] : sb.v[i];
     return o;
+}
+#if defined(ZKV_FP_MUL_NOINLINE)
+ZKV_HD_NI
+#else
+ZKV_HD
+#endif
+Fp fp_mul(Fp a, Fp b) {   // by value: 16 VGPRs in, 8 out, no scratch traffic at the call
+#if defined(ZKV_COUNT_FP_MUL)
+    zkv_fp_mul_counter++;     // host-only op counter of tests/host_sim (algorithmic work per stage, DESIGN.md)
+#endif
+    uint32_t x[9], y[9];
+    fp_unpack29(a, x); fp_unpack29(b, y);
+    int64_t col[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) col[k] = 0;
+    fp_mac81(col, x, y);
+    return fp_reduce_cols(col);
 }
 ZKV_HD Fp fp_sqr(const Fp& a) { return fp_mul(a, a); }
 
@@ -234,18 +245,50 @@ ZKV_HD Fp2 f2_neg(const Fp2& a) { Fp2 r; Fp z = fp_zero(); fp_sub_x2(z, a.c0, z,
 ZKV_HD Fp2 f2_add_nr(const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = fp_add_nr(a.c0, b.c0); r.c1 = fp_add_nr(a.c1, b.c1); return r; }
 ZKV_HD Fp2 f2_dbl(const Fp2& a) { return f2_add(a, a); }
 ZKV_HD Fp2 f2_conj(const Fp2& a) { Fp2 r; r.c0 = a.c0; r.c1 = fp_neg(a.c1); return r; }
-// Karatsuba; operand components may be lazy sums < 2p (their sums stay < 4p < 2^256), the result is canonical.
-ZKV_HD Fp2 f2_mul(const Fp2& a, const Fp2& b) {
-    Fp t0 = fp_mul(a.c0, b.c0), t1 = fp_mul(a.c1, b.c1);
-    Fp m = fp_mul(fp_add_nr(a.c0, a.c1), fp_add_nr(b.c0, b.c1));
-    Fp2 r; Fp u;
-    fp_sub_x2(t0, t1, m, t0, r.c0, u);
-    r.c1 = fp_sub(u, t1);
+// Fp2 product with the Montgomery reductions shared: three 81-term column products (a0 b0, a1 b1,
+// (a0+a1)(b0+b1)) and only TWO reductions -- c1 = M - T0 - T1 is non-negative column by column, c0 = T0 - T1 + 16 p^2
+// is non-negative as a whole and reduces on signed columns.  405 multiplies instead of 486.
+// Operand components may be lazy sums < 2p (so T1 < 4 p^2 <= 16 p^2 and every total stays < 169 p^2).
+ZKV_HD void f2_mul_core(const Fp& a0, const Fp& a1, const Fp& b0, const Fp& b1, Fp& c0, Fp& c1) {
+#if defined(ZKV_COUNT_FP_MUL)
+    zkv_fp_mul_counter += 3;
+#endif
+    const uint64_t C16P2[18] = ZKV_FP_16P2_COLS;
+    uint32_t x0[9], x1[9], y0[9], y1[9], sx[9], sy[9];
+    fp_unpack29(a0, x0); fp_unpack29(a1, x1); fp_unpack29(b0, y0); fp_unpack29(b1, y1);
+#pragma unroll
+    for (int i = 0; i < 9; i++) { sx[i] = x0[i] + x1[i]; sy[i] = y0[i] + y1[i]; }
+    int64_t t0[18], t1[18], m[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) { t0[k] = 0; t1[k] = 0; m[k] = 0; }
+    fp_mac81(t0, x0, y0); fp_mac81(t1, x1, y1); fp_mac81(m, sx, sy);
+#pragma unroll
+    for (int k = 0; k < 18; k++) {
+        m[k] = (int64_t)((uint64_t)m[k] - (uint64_t)t0[k] - (uint64_t)t1[k]);
+        t0[k] = (int64_t)((uint64_t)t0[k] - (uint64_t)t1[k] + C16P2[k]);
+    }
+    c0 = fp_reduce_cols(t0);
+    c1 = fp_reduce_cols(m);
+}
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ZKV_FP_MUL_NOINLINE)
+// Non-inlined on the device with all 32 operand limbs as scalar parameters: the AMDGPU calling convention passes
+// them in v0..v31 and returns the 16 result limbs in v0..v15 -- no stack traffic at the call.
+#define ZKV_L8(p) uint32_t p##0, uint32_t p##1, uint32_t p##2, uint32_t p##3, uint32_t p##4, uint32_t p##5, uint32_t p##6, uint32_t p##7
+#define ZKV_A8(f) f.v[0], f.v[1], f.v[2], f.v[3], f.v[4], f.v[5], f.v[6], f.v[7]
+#define ZKV_MK(f, p) Fp f; f.v[0] = p##0; f.v[1] = p##1; f.v[2] = p##2; f.v[3] = p##3; f.v[4] = p##4; f.v[5] = p##5; f.v[6] = p##6; f.v[7] = p##7
+__device__ __noinline__ inline Fp2 f2_mul_ni(ZKV_L8(pa), ZKV_L8(pb), ZKV_L8(pc), ZKV_L8(pd)) {
+    ZKV_MK(a0, pa); ZKV_MK(a1, pb); ZKV_MK(b0, pc); ZKV_MK(b1, pd);
+    Fp2 r; f2_mul_core(a0, a1, b0, b1, r.c0, r.c1);
     return r;
 }
+ZKV_HD Fp2 f2_mul(const Fp2& a, const Fp2& b) { return f2_mul_ni(ZKV_A8(a.c0), ZKV_A8(a.c1), ZKV_A8(b.c0), ZKV_A8(b.c1)); }
+#else
+ZKV_HD Fp2 f2_mul(const Fp2& a, const Fp2& b) { Fp2 r; f2_mul_core(a.c0, a.c1, b.c0, b.c1, r.c0, r.c1); return r; }
+#endif
 ZKV_HD Fp2 f2_sqr(const Fp2& a) {           // canonical input
-    Fp m = fp_mul(a.c0, a.c1);
-    Fp2 r; r.c0 = fp_mul(fp_add_nr(a.c0, a.c1), fp_sub(a.c0, a.c1)); r.c1 = fp_dbl(m);
+    Fp2 r;
+    r.c0 = fp_mul(fp_add_nr(a.c0, a.c1), fp_sub(a.c0, a.c1));
+    r.c1 = fp_mul(fp_add_nr(a.c0, a.c0), a.c1);
     return r;
 }
 ZKV_HD Fp2 f2_mul_fp(const Fp2& a, const Fp& k) { Fp2 r; r.c0 = fp_mul(a.c0, k); r.c1 = fp_mul(a.c1, k); return r; }
