@@ -4,27 +4,16 @@
 
 namespace zkv {
 
-#if defined(ZKV_OCC2)
-__global__ __launch_bounds__(ZKV_BLOCK, 2)
-#else
-__global__ __launch_bounds__(ZKV_BLOCK)
-#endif
-void k_finalexp(size_t n, Workspace ws, uint8_t* __restrict__ status) {
-#if !defined(ZKV_OCC2)
+__global__ __launch_bounds__(ZKV_BLOCK) void k_finalexp(size_t n, Workspace ws, uint8_t* __restrict__ status) {
     __shared__ uint32_t lds[96 * ZKV_BLOCK];
-#endif
     size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t flags = ws.flags[i];
     if (!(flags & FL_ALIVE)) return;
     uint32_t st = (uint32_t)ws.cap;
-#if defined(ZKV_OCC2)
-    MRef acc; acc.p = ws.fe + (size_t)384 * ws.cap + i; acc.stride = st;
-#else
-    MRef acc; acc.p = lds + threadIdx.x; acc.stride = ZKV_BLOCK;
-#endif
-    MRef F; F.p = ws.f + i; F.stride = st;
-    MRef E; E.p = ws.fe + i; E.stride = st;
+    MRef acc = m_ref(lds + threadIdx.x, ZKV_BLOCK);
+    MRef F = m_ref(ws.f + i, st);
+    MRef E = m_ref(ws.fe + i, st);
     MRef Y1 = m_off(E, 96), Y3 = m_off(E, 192), Y4 = m_off(E, 288);
     status[i] = final_exp_is_one_m(F, E, Y1, Y3, Y4, acc) ? ST_OK : ST_VERIFICATION_FAILED;
 }

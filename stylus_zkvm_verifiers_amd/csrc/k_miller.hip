@@ -6,15 +6,8 @@
 
 namespace zkv {
 
-#if defined(ZKV_OCC2)
-__global__ __launch_bounds__(ZKV_BLOCK, 2)
-#else
-__global__ __launch_bounds__(ZKV_BLOCK)
-#endif
-void k_miller(size_t n, const VkTables* __restrict__ vk, Workspace ws) {
-#if !defined(ZKV_OCC2)
+__global__ __launch_bounds__(ZKV_BLOCK) void k_miller(size_t n, const VkTables* __restrict__ vk, Workspace ws) {
     __shared__ uint32_t lds[(96 + 48) * ZKV_BLOCK];
-#endif
     size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t flags = ws.flags[i];
@@ -26,17 +19,11 @@ void k_miller(size_t n, const VkTables* __restrict__ vk, Workspace ws) {
     Fp2 bx, by;
     bx.c0 = ws_ld(ws.prep, ws.cap, 32, i); bx.c1 = ws_ld(ws.prep, ws.cap, 40, i);
     by.c0 = ws_ld(ws.prep, ws.cap, 48, i); by.c1 = ws_ld(ws.prep, ws.cap, 56, i);
-#if defined(ZKV_OCC2)
-    // two waves per SIMD: f and T live in HBM struct-of-arrays slots (L2/MALL resident) instead of LDS
-    MRef fm; fm.p = ws.fe + i; fm.stride = (uint32_t)ws.cap;
-    MRef tm = m_off(fm, 96);
-#else
-    MRef fm; fm.p = lds + threadIdx.x; fm.stride = ZKV_BLOCK;
-    MRef tm; tm.p = lds + 96 * ZKV_BLOCK + threadIdx.x; tm.stride = ZKV_BLOCK;
-#endif
+    MRef fm = m_ref(lds + threadIdx.x, ZKV_BLOCK);
+    MRef tm = m_ref(lds + 96 * ZKV_BLOCK + threadIdx.x, ZKV_BLOCK);
     miller_loop_m(*vk, flags, nm, bx, by, true, fm, tm);
-    MRef ab; ab.p = (uint32_t*)(&vk->f_alpha_beta); ab.stride = 1;
-    MRef out; out.p = ws.f + i; out.stride = (uint32_t)ws.cap;
+    MRef ab = m_ref((uint32_t*)(vk->f_alpha_beta), 1);
+    MRef out = m_ref(ws.f + i, (uint32_t)ws.cap);
     f12m_mul(out, fm, ab);
 }
 

@@ -21,8 +21,8 @@ __global__ __launch_bounds__(64) void k_setup_msm(const VkRaw* __restrict__ raw,
 __global__ __launch_bounds__(64) void k_setup_alpha_beta(const VkRaw* __restrict__ raw, VkTables* __restrict__ t) {
     __shared__ uint32_t lds[96 + 48];
     if (threadIdx.x != 0) return;
-    MRef fm; fm.p = lds; fm.stride = 1;
-    MRef tm; tm.p = lds + 96; tm.stride = 1;
+    MRef fm = m_ref(lds, 1);
+    MRef tm = m_ref(lds + 96, 1);
     setup_alpha_beta(*raw, *t, fm, tm);
 }
 

@@ -40,6 +40,13 @@ static size_t chunk_capacity() {
     return (c + 63) & ~(size_t)63;
 }
 
+// Kernel mapping of the Fp2-heavy stages: 2 = one proof per lane pair (default), 1 = one proof per lane.
+static int lanes_per_proof() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ZKV_LANES_PER_PROOF"); v = (e && e[0] == '1') ? 1 : 2; }
+    return v;
+}
+
 static bool device_is_gfx950(int dev) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
@@ -125,11 +132,12 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     if (timed) (void)hipEventRecord(c->ev[1], s);
     launch_msm(a.n, c->d_tab, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[2], s);
-    launch_g2chk(a.n, c->ws, a.status, s);
+    const bool pair = lanes_per_proof() == 2;
+    if (pair) launch_g2chk2(a.n, c->ws, a.status, s); else launch_g2chk(a.n, c->ws, a.status, s);
     if (timed) (void)hipEventRecord(c->ev[3], s);
-    launch_miller(a.n, c->d_tab, c->ws, s);
+    if (pair) launch_miller2(a.n, c->d_tab, c->ws, s); else launch_miller(a.n, c->d_tab, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[4], s);
-    launch_finalexp(a.n, c->ws, a.status, s);
+    if (pair) launch_finalexp2(a.n, c->ws, a.status, s); else launch_finalexp(a.n, c->ws, a.status, s);
     if (timed) (void)hipEventRecord(c->ev[5], s);
 }
 

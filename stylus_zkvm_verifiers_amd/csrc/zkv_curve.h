@@ -52,8 +52,8 @@ struct G2J { Fp2 x, y, z; };
 struct G2A { Fp2 x, y; };
 
 ZKV_HD bool g2_on_twist(const Fp2& x, const Fp2& y) {
-    Fp2 b = ZKV_TWIST_B;
-    return f2_eq(f2_sqr(y), f2_add(f2_mul(f2_sqr(x), x), b));
+    const Fp2C b = ZKV_TWIST_B;
+    return f2_eq(f2_sqr(y), f2_add(f2_mul(f2_sqr(x), x), f2_const(b)));
 }
 ZKV_HD G2J g2j_infinity() { G2J r; r.x = f2_one(); r.y = f2_one(); r.z = f2_zero(); return r; }
 ZKV_HD G2J g2j_dbl(const G2J& p) {
@@ -104,8 +104,8 @@ ZKV_HD G2J g2j_add_affine(const G2J& p, const Fp2& qx, const Fp2& qy) {
 }
 // psi = twist o Frobenius o untwist on Jacobian coordinates
 ZKV_HD G2J g2j_psi(const G2J& p) {
-    const Fp2 G[6] = ZKV_FROB1;
-    G2J r; r.x = f2_mul(f2_conj(p.x), G[2]); r.y = f2_mul(f2_conj(p.y), G[3]); r.z = f2_conj(p.z);
+    const Fp2C G[6] = ZKV_FROB1;
+    G2J r; r.x = f2_mul(f2_conj(p.x), f2_const(G[2])); r.y = f2_mul(f2_conj(p.y), f2_const(G[3])); r.z = f2_conj(p.z);
     return r;
 }
 ZKV_HD bool g2j_eq(const G2J& a, const G2J& b) {
@@ -144,7 +144,8 @@ struct G2H { Fp2 x, y, z; };
 
 ZKV_HD void line_dbl(G2H& T, Fp2& l0, Fp2& l1, Fp2& l3) {
     const Fp two_inv = ZKV_FP_TWO_INV;
-    const Fp2 b3 = ZKV_TWIST_3B;
+    const Fp2C b3c = ZKV_TWIST_3B;
+    const Fp2 b3 = f2_const(b3c);
     Fp2 a = f2_mul_fp(f2_mul(T.x, T.y), two_inv);
     Fp2 b = f2_sqr(T.y), c = f2_sqr(T.z);
     Fp2 e = f2_mul(b3, c);                              // 3 b' Z^2
@@ -170,8 +171,8 @@ ZKV_HD void line_add(G2H& T, const Fp2& qx, const Fp2& qy, Fp2& l0, Fp2& l1, Fp2
     T.z = f2_mul(T.z, e);
 }
 ZKV_HD void g2_frob_affine(Fp2& x, Fp2& y, const Fp2& qx, const Fp2& qy) {
-    const Fp2 G[6] = ZKV_FROB1;
-    x = f2_mul(f2_conj(qx), G[2]); y = f2_mul(f2_conj(qy), G[3]);
+    const Fp2C G[6] = ZKV_FROB1;
+    x = f2_mul(f2_conj(qx), f2_const(G[2])); y = f2_mul(f2_conj(qy), f2_const(G[3]));
 }
 // pi^2 on the twist: multiplication by Fp constants
 ZKV_HD void g2_frob2_affine(Fp2& x, Fp2& y, const Fp2& qx, const Fp2& qy) {
@@ -182,6 +183,7 @@ ZKV_HD void g2_frob2_affine(Fp2& x, Fp2& y, const Fp2& qx, const Fp2& qy) {
 // Affine stepping used only when building the fixed-Q line tables at context set-up (gamma, delta):
 // slope form  line/yP = 1 + (nl * xP/yP) w + (c * 1/yP) w^3  with nl = -lambda, c = lambda xT - yT.
 struct LineAff { Fp2 nl, c; };
+struct LineAffC { Fp2C nl, c; };       // table layout (both components), read by every kernel variant
 ZKV_HD LineAff aff_dbl(G2A& T) {
     Fp2 x2 = f2_sqr(T.x);
     Fp2 lam = f2_mul(f2_add(f2_dbl(x2), x2), f2_inv(f2_dbl(T.y)));
@@ -198,39 +200,6 @@ ZKV_HD LineAff aff_add(G2A& T, const Fp2& qx, const Fp2& qy) {
     Fp2 y3 = f2_sub(f2_mul(lam, f2_sub(T.x, x3)), T.y);
     T.x = x3; T.y = y3;
     return l;
-}
-
-// ---------------------------------------------------------------- final exponentiation
-ZKV_HD Fp12 f12_exp_u(const Fp12& a) {
-    Fp12 acc = a;
-#pragma unroll 1
-    for (int i = 61; i >= 0; i--) {
-        acc = f12_sqr(acc);
-        if ((ZKV_BN_U >> i) & 1ULL) acc = f12_mul(acc, a);
-    }
-    return acc;
-}
-// f^(k (p^12-1)/r) with k = 2u(6u^2+3u+1), gcd(k, r) = 1: equals 1 iff the reduced pairing product is 1.
-ZKV_HD Fp12 final_exp(const Fp12& f) {
-    Fp12 e = f12_mul(f12_conj(f), f12_inv(f));          // ^(p^6-1)
-    e = f12_mul(f12_frob2(e), e);                       // ^(p^2+1)
-    Fp12 y0 = f12_conj(f12_exp_u(e));
-    Fp12 y1 = f12_sqr(y0);
-    Fp12 y2 = f12_sqr(y1);
-    Fp12 y3 = f12_mul(y2, y1);
-    Fp12 y4 = f12_conj(f12_exp_u(y3));
-    Fp12 y5 = f12_sqr(y4);
-    Fp12 y6 = f12_exp_u(y5);                            // conj(conj(.)) folded
-    y3 = f12_conj(y3);
-    Fp12 y7 = f12_mul(y6, y4);
-    Fp12 y8 = f12_mul(y7, y3);
-    Fp12 y9 = f12_mul(y8, y1);
-    Fp12 y10 = f12_mul(y8, y4);
-    Fp12 y11 = f12_mul(y10, e);
-    Fp12 y13 = f12_mul(f12_frob1(y9), y11);
-    Fp12 y14 = f12_mul(f12_frob2(y8), y13);
-    Fp12 y15 = f12_frob3(f12_mul(f12_conj(e), y9));
-    return f12_mul(y15, y14);
 }
 
 }  // namespace zkv

@@ -26,9 +26,16 @@ static unsigned long long zkv_fp_mul_counter = 0;
 namespace zkv {
 
 struct Fp { uint32_t v[8]; };
+// Fp2C: both components, layout-stable (constants, device tables, the one-proof-per-lane kernels).
+struct Fp2C { Fp c0, c1; };
+#if defined(ZKV_PAIRED)
+// Lane-pair mode (k_*2.hip): one proof per PAIR of adjacent lanes; the even lane holds the real component of every
+// Fp2 value, the odd lane the imaginary one, and Fp2 products exchange operands with a DPP quad permute.
+struct Fp2 { Fp h; };
+#else
 struct Fp2 { Fp c0, c1; };
+#endif
 struct Fp6 { Fp2 c0, c1, c2; };
-struct Fp12 { Fp6 c0, c1; };     // c0 = g (w^0,w^2,w^4), c1 = h (w^1,w^3,w^5)
 
 // ---------------------------------------------------------------- carry helpers
 // clang lowers __builtin_addc/__builtin_subc chains to v_add_co/v_addc_co (one instruction per limb);
@@ -149,16 +156,18 @@ ZKV_HD void fp_unpack29(const Fp& a, uint32_t x[9]) {            // 8 x 32 -> 9 
         x[k] = v & 0x1fffffffu;
     }
 }
-ZKV_HD void fp_mac81(int64_t col[18], const uint32_t x[9], const uint32_t y[9]) {   // col += x * y, 81 independent-column MACs
+template <typename COL>
+ZKV_HD void fp_mac81(COL col[18], const uint32_t x[9], const uint32_t y[9]) {   // col += x * y, 81 independent-column MACs
 #pragma unroll
     for (int i = 0; i < 9; i++) {
 #pragma unroll
-        for (int j = 0; j < 9; j++) col[i + j] = (int64_t)((uint64_t)col[i + j] + (uint64_t)x[i] * y[j]);
+        for (int j = 0; j < 9; j++) col[i + j] = (COL)((uint64_t)col[i + j] + (uint64_t)x[i] * y[j]);
     }
 }
 // Montgomery reduction of an 18-column value V >= 0 (V = sum col[k] 2^(29k)): returns V * 2^-261 mod p, canonical.
 // Requires V / 2^261 + p < 2p, i.e. V < p * 2^261 (about 169 p^2).
-ZKV_HD Fp fp_reduce_cols(int64_t col[18]) {
+template <typename COL>                          // int64_t: signed columns (arithmetic carries); uint64_t: all terms >= 0
+ZKV_HD Fp fp_reduce_cols(COL col[18]) {
     const uint32_t P29[9] = ZKV_FP_P29_LIMBS;
     const uint32_t P[8] = ZKV_FP_P_LIMBS;
     const uint32_t M29 = 0x1fffffffu;
@@ -166,8 +175,8 @@ ZKV_HD Fp fp_reduce_cols(int64_t col[18]) {
     for (int i = 0; i < 9; i++) {                 // one 29-bit digit per step
         uint32_t m = ((uint32_t)col[i] * ZKV_FP_INV29) & M29;
 #pragma unroll
-        for (int j = 0; j < 9; j++) col[i + j] = (int64_t)((uint64_t)col[i + j] + (uint64_t)m * P29[j]);
-        col[i + 1] += col[i] >> 29;               // low 29 bits of col[i] are now zero; arithmetic shift
+        for (int j = 0; j < 9; j++) col[i + j] = (COL)((uint64_t)col[i + j] + (uint64_t)m * P29[j]);
+        col[i + 1] += col[i] >> 29;               // low 29 bits of col[i] are now zero; arithmetic shift when signed
     }
     uint32_t r[9];
 #pragma unroll
@@ -234,6 +243,8 @@ ZKV_HD Fp fp_inv(const Fp& a) {
 }
 
 // ---------------------------------------------------------------- Fp2
+#if !defined(ZKV_PAIRED)
+ZKV_HD Fp2 f2_const(const Fp2C& c) { Fp2 r; r.c0 = c.c0; r.c1 = c.c1; return r; }
 ZKV_HD Fp2 f2_zero() { Fp2 r; r.c0 = fp_zero(); r.c1 = fp_zero(); return r; }
 ZKV_HD Fp2 f2_one() { Fp2 r; r.c0 = fp_one(); r.c1 = fp_zero(); return r; }
 ZKV_HD bool f2_is_zero(const Fp2& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
@@ -304,6 +315,102 @@ ZKV_HD Fp2 f2_inv(const Fp2& a) {
     return r;
 }
 
+#else   // ---------------------------------------------------------------- Fp2, lane-pair mode
+#if defined(__HIP_DEVICE_COMPILE__)
+ZKV_HD uint32_t zkv_parity() { return threadIdx.x & 1u; }
+// value held by the other lane of the pair: v_mov_b32_dpp quad_perm:[1,0,3,2]
+ZKV_HD uint32_t zkv_partner_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true); }
+#else
+uint32_t zkv_parity();                      // host emulation of a lane pair (tests/host_sim, two threads)
+uint32_t zkv_partner_u32(uint32_t x);
+#endif
+ZKV_HD Fp zkv_partner(const Fp& a) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = zkv_partner_u32(a.v[i]);
+    return r;
+}
+ZKV_HD Fp fp_sel(bool odd, const Fp& if_odd, const Fp& if_even) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = odd ? if_odd.v[i] : if_even.v[i];
+    return r;
+}
+ZKV_HD Fp2 f2_const(const Fp2C& c) { Fp2 r; r.h = fp_sel(zkv_parity() != 0, c.c1, c.c0); return r; }
+ZKV_HD Fp2 f2_zero() { Fp2 r; r.h = fp_zero(); return r; }
+ZKV_HD Fp2 f2_one() { Fp2 r; r.h = fp_sel(zkv_parity() != 0, fp_zero(), fp_one()); return r; }
+ZKV_HD bool f2_is_zero(const Fp2& a) {
+    uint32_t o = 0;
+    for (int i = 0; i < 8; i++) o |= a.h.v[i];
+    o |= zkv_partner_u32(o);
+    return o == 0;
+}
+ZKV_HD bool f2_eq(const Fp2& a, const Fp2& b) {
+    uint32_t o = 0;
+    for (int i = 0; i < 8; i++) o |= a.h.v[i] ^ b.h.v[i];
+    o |= zkv_partner_u32(o);
+    return o == 0;
+}
+ZKV_HD Fp2 f2_add(const Fp2& a, const Fp2& b) { Fp2 r; r.h = fp_add(a.h, b.h); return r; }
+ZKV_HD Fp2 f2_sub(const Fp2& a, const Fp2& b) { Fp2 r; r.h = fp_sub(a.h, b.h); return r; }
+ZKV_HD Fp2 f2_neg(const Fp2& a) { Fp2 r; r.h = fp_neg(a.h); return r; }
+ZKV_HD Fp2 f2_add_nr(const Fp2& a, const Fp2& b) { Fp2 r; r.h = fp_add_nr(a.h, b.h); return r; }
+ZKV_HD Fp2 f2_dbl(const Fp2& a) { return f2_add(a, a); }
+ZKV_HD Fp2 f2_conj(const Fp2& a) { Fp2 r; r.h = fp_sel(zkv_parity() != 0, fp_neg(a.h), a.h); return r; }
+// (a0 + a1 u)(b0 + b1 u): the even lane forms a0 b0 + a1 (4p - b1), the odd lane a0 b1 + a1 b0 -- two 81-term column
+// products and ONE Montgomery reduction per lane, all terms non-negative (4p - b1 in borrow-free 29-bit limbs).
+// Components may be lazy sums < 2p.
+#if defined(ZKV_FP_MUL_NOINLINE)
+ZKV_HD_NI
+#else
+ZKV_HD
+#endif
+Fp f2_mul_lane(Fp my_a, Fp my_b) {
+#if defined(ZKV_COUNT_FP_MUL)
+    zkv_fp_mul_counter += 2;
+#endif
+    const uint32_t FAT[9] = ZKV_FP_FAT4P_LIMBS;
+    const bool odd = zkv_parity() != 0;
+    Fp ot_a = zkv_partner(my_a), ot_b = zkv_partner(my_b);
+    uint32_t xa[9], xo[9], yb[9], yo[9], U[9], V[9];
+    fp_unpack29(my_a, xa); fp_unpack29(ot_a, xo); fp_unpack29(my_b, yb); fp_unpack29(ot_b, yo);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        U[i] = odd ? yo[i] : yb[i];
+        V[i] = odd ? yb[i] : FAT[i] - yo[i];
+    }
+    uint64_t col[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) col[k] = 0;
+    fp_mac81(col, xa, U); fp_mac81(col, xo, V);
+    return fp_reduce_cols(col);
+}
+ZKV_HD Fp2 f2_mul(const Fp2& a, const Fp2& b) { Fp2 r; r.h = f2_mul_lane(a.h, b.h); return r; }
+ZKV_HD Fp2 f2_sqr(const Fp2& a) {           // canonical input: even lane (a0+a1)(a0-a1), odd lane (2 a1) a0
+    const bool odd = zkv_parity() != 0;
+    Fp o = zkv_partner(a.h);
+    Fp x = fp_add_nr(a.h, fp_sel(odd, a.h, o));
+    Fp y = fp_sel(odd, o, fp_sub(a.h, o));
+    Fp2 r; r.h = fp_mul(x, y);
+    return r;
+}
+ZKV_HD Fp2 f2_mul_fp(const Fp2& a, const Fp& k) { Fp2 r; r.h = fp_mul(a.h, k); return r; }
+ZKV_HD Fp2 f2_mul_xi(const Fp2& a) {          // (9+u)(a0 + a1 u) = (9a0 - a1) + (9a1 + a0) u
+    Fp o = zkv_partner(a.h);
+    Fp t = fp_add(fp_dbl(fp_dbl(fp_dbl(a.h))), a.h);
+    Fp2 r; r.h = fp_add(t, fp_sel(zkv_parity() != 0, o, fp_neg(o)));
+    return r;
+}
+ZKV_HD Fp2 f2_inv(const Fp2& a) {
+    Fp sq = fp_sqr(a.h);
+    Fp n = fp_add(sq, zkv_partner(sq));
+    Fp i = fp_inv(n);
+    Fp m = fp_mul(a.h, i);
+    Fp2 r; r.h = fp_sel(zkv_parity() != 0, fp_neg(m), m);
+    return r;
+}
+#endif  // ZKV_PAIRED
+
 // ---------------------------------------------------------------- Fp6
 ZKV_HD Fp6 f6_zero() { Fp6 r; r.c0 = f2_zero(); r.c1 = f2_zero(); r.c2 = f2_zero(); return r; }
 ZKV_HD Fp6 f6_add(const Fp6& a, const Fp6& b) { Fp6 r; r.c0 = f2_add(a.c0, b.c0); r.c1 = f2_add(a.c1, b.c1); r.c2 = f2_add(a.c2, b.c2); return r; }
@@ -335,85 +442,6 @@ ZKV_HD Fp6 f6_inv(const Fp6& a) {
     Fp2 F = f2_add(f2_mul_xi(f2_add(f2_mul(a.c2, B), f2_mul(a.c1, C))), f2_mul(a.c0, A));
     F = f2_inv(F);
     Fp6 r; r.c0 = f2_mul(A, F); r.c1 = f2_mul(B, F); r.c2 = f2_mul(C, F);
-    return r;
-}
-
-// ---------------------------------------------------------------- Fp12
-ZKV_HD Fp12 f12_one() { Fp12 r; r.c0 = f6_zero(); r.c1 = f6_zero(); r.c0.c0.c0 = fp_one(); return r; }
-ZKV_HD bool f12_is_one(const Fp12& a) {
-    Fp one = fp_one();
-    bool ok = fp_eq(a.c0.c0.c0, one) && fp_is_zero(a.c0.c0.c1);
-    ok = ok && f2_is_zero(a.c0.c1) && f2_is_zero(a.c0.c2);
-    ok = ok && f2_is_zero(a.c1.c0) && f2_is_zero(a.c1.c1) && f2_is_zero(a.c1.c2);
-    return ok;
-}
-ZKV_HD Fp12 f12_mul(const Fp12& a, const Fp12& b) {
-    Fp6 t0 = f6_mul(a.c0, b.c0), t1 = f6_mul(a.c1, b.c1);
-    Fp6 m = f6_mul(f6_add(a.c0, a.c1), f6_add(b.c0, b.c1));
-    Fp12 r; r.c1 = f6_sub(f6_sub(m, t0), t1); r.c0 = f6_add(t0, f6_mul_v(t1));
-    return r;
-}
-// complex squaring: c0 = (a0+a1)(a0+v a1) - a0a1 - v a0a1, c1 = 2 a0a1
-ZKV_HD Fp12 f12_sqr(const Fp12& a) {
-    Fp6 t = f6_mul(a.c0, a.c1);
-    Fp6 s = f6_mul(f6_add(a.c0, a.c1), f6_add(a.c0, f6_mul_v(a.c1)));
-    Fp12 r; r.c0 = f6_sub(f6_sub(s, t), f6_mul_v(t)); r.c1 = f6_add(t, t);
-    return r;
-}
-ZKV_HD Fp12 f12_conj(const Fp12& a) { Fp12 r; r.c0 = a.c0; r.c1 = f6_neg(a.c1); return r; }
-ZKV_HD Fp12 f12_inv(const Fp12& a) {
-    Fp6 t = f6_sub(f6_mul(a.c0, a.c0), f6_mul_v(f6_mul(a.c1, a.c1)));
-    t = f6_inv(t);
-    Fp12 r; r.c0 = f6_mul(a.c0, t); r.c1 = f6_neg(f6_mul(a.c1, t));
-    return r;
-}
-// f * (c0 + (c3 + c4 v) w), 13 Fp2 products
-ZKV_HD Fp12 f12_mul_by_034(const Fp12& f, const Fp2& c0, const Fp2& c3, const Fp2& c4) {
-    Fp6 t0 = f6_mul_fp2(f.c0, c0);
-    Fp6 t1 = f6_mul_by_01(f.c1, c3, c4);
-    Fp6 t2 = f6_mul_by_01(f6_add(f.c0, f.c1), f2_add(c0, c3), c4);
-    Fp12 r; r.c1 = f6_sub(f6_sub(t2, t0), t1); r.c0 = f6_add(t0, f6_mul_v(t1));
-    return r;
-}
-// f * (1 + (c3 + c4 v) w), 10 Fp2 products  (lines scaled by 1/yP)
-ZKV_HD Fp12 f12_mul_by_134(const Fp12& f, const Fp2& c3, const Fp2& c4) {
-    Fp6 hs = f6_mul_by_01(f.c1, c3, c4);
-    Fp6 gs = f6_mul_by_01(f.c0, c3, c4);
-    Fp12 r; r.c0 = f6_add(f.c0, f6_mul_v(hs)); r.c1 = f6_add(f.c1, gs);
-    return r;
-}
-// Frobenius maps on f = sum_k c_k w^k: (c0,c2,c4) = g, (c1,c3,c5) = h.
-ZKV_HD Fp12 f12_frob1(const Fp12& a) {
-    const Fp2 G[6] = ZKV_FROB1;
-    Fp12 r;
-    r.c0.c0 = f2_conj(a.c0.c0);
-    r.c1.c0 = f2_mul(f2_conj(a.c1.c0), G[1]);
-    r.c0.c1 = f2_mul(f2_conj(a.c0.c1), G[2]);
-    r.c1.c1 = f2_mul(f2_conj(a.c1.c1), G[3]);
-    r.c0.c2 = f2_mul(f2_conj(a.c0.c2), G[4]);
-    r.c1.c2 = f2_mul(f2_conj(a.c1.c2), G[5]);
-    return r;
-}
-ZKV_HD Fp12 f12_frob2(const Fp12& a) {
-    const Fp G[6] = ZKV_FROB2;
-    Fp12 r;
-    r.c0.c0 = a.c0.c0;
-    r.c1.c0 = f2_mul_fp(a.c1.c0, G[1]);
-    r.c0.c1 = f2_mul_fp(a.c0.c1, G[2]);
-    r.c1.c1 = f2_mul_fp(a.c1.c1, G[3]);
-    r.c0.c2 = f2_mul_fp(a.c0.c2, G[4]);
-    r.c1.c2 = f2_mul_fp(a.c1.c2, G[5]);
-    return r;
-}
-ZKV_HD Fp12 f12_frob3(const Fp12& a) {
-    const Fp2 G[6] = ZKV_FROB3;
-    Fp12 r;
-    r.c0.c0 = f2_conj(a.c0.c0);
-    r.c1.c0 = f2_mul(f2_conj(a.c1.c0), G[1]);
-    r.c0.c1 = f2_mul(f2_conj(a.c0.c1), G[2]);
-    r.c1.c1 = f2_mul(f2_conj(a.c1.c1), G[3]);
-    r.c0.c2 = f2_mul(f2_conj(a.c0.c2), G[4]);
-    r.c1.c2 = f2_mul(f2_conj(a.c1.c2), G[5]);
     return r;
 }
 

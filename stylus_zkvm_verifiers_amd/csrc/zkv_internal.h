@@ -51,5 +51,9 @@ void launch_msm(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_
 void launch_g2chk(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
 void launch_miller(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
 void launch_finalexp(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
+// lane-pair variants (k_pair.hip): one proof per two lanes, two waves per SIMD
+void launch_g2chk2(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
+void launch_miller2(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
+void launch_finalexp2(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
 
 }  // namespace zkv

@@ -12,9 +12,12 @@
 
 namespace zkv {
 
-struct MRef { uint32_t* p; uint32_t stride; };     // word k of this lane's value: p[k * stride]
+// word k of this lane's value: p[k * stride].  f2w = words between consecutive Fp2 coefficients of the slot:
+// 16 for the full layout (c0 then c1; a paired lane points p at its own component), 8 for a lane-private half slot.
+struct MRef { uint32_t* p; uint32_t stride; uint32_t f2w; };
 
-ZKV_HD MRef m_off(MRef m, int words) { MRef r; r.p = m.p + (size_t)words * m.stride; r.stride = m.stride; return r; }
+ZKV_HD MRef m_ref(uint32_t* p, uint32_t stride, uint32_t f2w = 16) { MRef r; r.p = p; r.stride = stride; r.f2w = f2w; return r; }
+ZKV_HD MRef m_off(MRef m, int words) { MRef r = m; r.p = m.p + (size_t)words * m.stride; return r; }
 ZKV_HD Fp m_ld_fp(MRef m, int word0) {
     Fp r;
 #pragma unroll
@@ -25,24 +28,34 @@ ZKV_HD void m_st_fp(MRef m, int word0, const Fp& a) {
 #pragma unroll
     for (int k = 0; k < 8; k++) m.p[(size_t)(word0 + k) * m.stride] = a.v[k];
 }
+#if defined(ZKV_PAIRED)
+ZKV_HD Fp2 m_ld_f2(MRef m, int idx) { Fp2 r; r.h = m_ld_fp(m, (int)m.f2w * idx); return r; }
+ZKV_HD void m_st_f2(MRef m, int idx, const Fp2& a) { m_st_fp(m, (int)m.f2w * idx, a.h); }
+#else
 ZKV_HD Fp2 m_ld_f2(MRef m, int idx) { Fp2 r; r.c0 = m_ld_fp(m, 16 * idx); r.c1 = m_ld_fp(m, 16 * idx + 8); return r; }
 ZKV_HD void m_st_f2(MRef m, int idx, const Fp2& a) { m_st_fp(m, 16 * idx, a.c0); m_st_fp(m, 16 * idx + 8, a.c1); }
+#endif
 ZKV_HD Fp6 m_ld_f6(MRef m, int idx) { Fp6 r; r.c0 = m_ld_f2(m, idx); r.c1 = m_ld_f2(m, idx + 1); r.c2 = m_ld_f2(m, idx + 2); return r; }
 ZKV_HD void m_st_f6(MRef m, int idx, const Fp6& a) { m_st_f2(m, idx, a.c0); m_st_f2(m, idx + 1, a.c1); m_st_f2(m, idx + 2, a.c2); }
-ZKV_HD void m_st_f12(MRef m, const Fp12& a) { m_st_f6(m, 0, a.c0); m_st_f6(m, 3, a.c1); }
-ZKV_HD Fp12 m_ld_f12(MRef m) { Fp12 r; r.c0 = m_ld_f6(m, 0); r.c1 = m_ld_f6(m, 3); return r; }
+// An Fp12 slot is six Fp2 coefficients g0 g1 g2 h0 h1 h2.
 ZKV_HD void f12m_copy(MRef d, MRef a) {
 #pragma unroll 1
-    for (int k = 0; k < 96; k++) d.p[(size_t)k * d.stride] = a.p[(size_t)k * a.stride];
+    for (int k = 0; k < 6; k++) m_st_f2(d, k, m_ld_f2(a, k));
 }
 ZKV_HD void f12m_set_one(MRef d) {
-    Fp one = fp_one();
+    m_st_f2(d, 0, f2_one());
 #pragma unroll 1
-    for (int k = 0; k < 96; k++) d.p[(size_t)k * d.stride] = k < 8 ? one.v[k] : 0u;
+    for (int k = 1; k < 6; k++) m_st_f2(d, k, f2_zero());
 }
 ZKV_HD void f12m_conj(MRef d) {            // in place: negate h
 #pragma unroll 1
-    for (int k = 6; k < 12; k++) m_st_fp(d, 8 * k, fp_neg(m_ld_fp(d, 8 * k)));
+    for (int k = 3; k < 6; k++) m_st_f2(d, k, f2_neg(m_ld_f2(d, k)));
+}
+ZKV_HD bool f12m_is_one(MRef a) {
+    bool ok = f2_eq(m_ld_f2(a, 0), f2_one());
+#pragma unroll 1
+    for (int k = 1; k < 6; k++) ok = f2_is_zero(m_ld_f2(a, k)) && ok;
+    return ok;
 }
 
 // f <- f^2 (complex squaring, 12 Fp2 products)
@@ -115,9 +128,9 @@ ZKV_HD_NI void f12m_inv(MRef d, MRef a) {
 }
 // d <- pi^k(a), k = 1, 2, 3 (d may alias a)
 ZKV_HD_NI void f12m_frob(MRef d, MRef a, int k) {
-    const Fp2 G1[6] = ZKV_FROB1;
+    const Fp2C G1[6] = ZKV_FROB1;
     const Fp G2[6] = ZKV_FROB2;
-    const Fp2 G3[6] = ZKV_FROB3;
+    const Fp2C G3[6] = ZKV_FROB3;
     // memory order g0 g1 g2 h0 h1 h2 <-> w-powers 0 2 4 1 3 5
     const int wp[6] = {0, 2, 4, 1, 3, 5};
 #pragma unroll 1
@@ -127,7 +140,7 @@ ZKV_HD_NI void f12m_frob(MRef d, MRef a, int k) {
         if (k == 2) c = f2_mul_fp(c, G2[e]);
         else {
             c = f2_conj(c);
-            if (e) c = f2_mul(c, k == 1 ? G1[e] : G3[e]);
+            if (e) c = f2_mul(c, f2_const(k == 1 ? G1[e] : G3[e]));
         }
         m_st_f2(d, i, c);
     }

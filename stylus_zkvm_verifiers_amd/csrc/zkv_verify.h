@@ -41,8 +41,8 @@ struct VkRaw {
 struct VkTables {
     G1A base; uint32_t base_inf; uint32_t var_windows[2];
     G1A msm[2][MSM_MAX_WINDOWS][16];     // msm[b][w][d] = d * 16^w * IC_var[b]   (d = 0 unused)
-    LineAff lines[2][N_LINES];           // gamma, delta: slope-form lines of the fixed-Q Miller loop
-    Fp12 f_alpha_beta;                   // Miller value of (alpha, beta)
+    LineAffC lines[2][N_LINES];          // gamma, delta: slope-form lines of the fixed-Q Miller loop
+    uint32_t f_alpha_beta[96];           // Miller value of (alpha, beta): Fp12 as g0 g1 g2 h0 h1 h2, (c0, c1) each
 };
 
 struct PrepOut {
@@ -70,6 +70,9 @@ ZKV_HD bool raw_is_zero(const uint32_t* a) {
 ZKV_HD bool raw_lt_p(const uint32_t* a) { const uint32_t P[8] = ZKV_FP_P_LIMBS; return !u256_geq(a, P); }
 ZKV_HD bool raw_lt_r(const uint32_t* a) { const uint32_t R[8] = ZKV_FR_R_LIMBS; return !u256_geq(a, R); }
 
+struct Risc0Consts { uint32_t tag_output[8]; uint32_t claim_mid[8]; uint32_t post[8]; };   // see risc0_claim_digest
+
+#if !defined(ZKV_PAIRED)
 // ---------------------------------------------------------------- stage PREP (shared part)
 // words: the 8 proof words a.x a.y b.x_im b.x_re b.y_im b.y_re c.x c.y as raw limbs.
 // Returns false => VerificationFailed (a precompile would reject the point encoding).
@@ -109,7 +112,6 @@ ZKV_HD bool prep_points(uint32_t w[8][8], bool negate_a, PrepOut& o) {
 // risc0/types.rs:44-94: claim digest from (image_id, journal_digest).  tag_output = sha256("risc0.Output"),
 // claim_mid = SHA-256 state after the constant first block of the claim message
 // (sha256("risc0.ReceiptClaim") || input = 0^32), post = SYSTEM_STATE_ZERO_DIGEST words.
-struct Risc0Consts { uint32_t tag_output[8]; uint32_t claim_mid[8]; uint32_t post[8]; };
 
 ZKV_HD void risc0_claim_digest(const Risc0Consts& k, const uint8_t* image_id, const uint8_t* journal, uint32_t h[8]) {
     uint32_t w[16], out[8];
@@ -174,12 +176,14 @@ ZKV_HD void msm_normalize(const VkTables& vk, const PrepOut& in, uint32_t& flags
     out.lys = fp_mul(fp_mul(z2, acc.z), iyl);            // Z^3 / Y
 }
 
+#endif  // !ZKV_PAIRED (PREP and MSM run one proof per lane)
+
 // ---------------------------------------------------------------- stage MILLER
 // Shared-accumulator Miller loop over (A',B) [variable Q, projective], (L,gamma), (C,delta) [fixed Q,
 // precomputed slope lines]; multiplied by the precomputed Miller value of (alpha, beta).
 // fm: the Fp12 accumulator slot, tm: the 3 x Fp2 running point T (both LDS on the device).
-ZKV_HD void fixed_line_mul(MRef fm, const LineAff& L, const Fp& xs, const Fp& ys) {
-    Fp2 c3 = f2_mul_fp(L.nl, xs), c4 = f2_mul_fp(L.c, ys);
+ZKV_HD void fixed_line_mul(MRef fm, const LineAffC& L, const Fp& xs, const Fp& ys) {
+    Fp2 c3 = f2_mul_fp(f2_const(L.nl), xs), c4 = f2_mul_fp(f2_const(L.c), ys);
     f12m_mul_by_134(fm, &c3, &c4);
 }
 ZKV_HD void var_line_mul(MRef fm, const Fp2& l0, const Fp2& l1, const Fp2& l3, const Fp& xs, const Fp& ys) {
@@ -243,13 +247,6 @@ ZKV_HD void exp_u_m(MRef acc, MRef x) {
         if ((ZKV_BN_U >> i) & 1ULL) f12m_mul(acc, acc, x);
     }
 }
-ZKV_HD bool f12m_is_one(MRef a) {
-    Fp one = fp_one();
-    uint32_t o = 0;
-#pragma unroll 1
-    for (int k = 0; k < 96; k++) o |= a.p[(size_t)k * a.stride] ^ (k < 8 ? one.v[k] : 0u);
-    return o == 0;
-}
 // f^(k (p^12-1)/r) == 1 with k = 2u(6u^2+3u+1), gcd(k, r) = 1  (Fuentes-Castaneda hard part; the chain is
 // checked symbolically in tests).  F holds the Miller value on entry (clobbered); E, Y1, Y3, Y4 are scratch
 // slots; acc is the hot accumulator (LDS on the device).
@@ -283,8 +280,12 @@ ZKV_HD bool final_exp_is_one_m(MRef F, MRef E, MRef Y1, MRef Y3, MRef Y4, MRef a
     return f12m_is_one(acc);
 }
 
+#if !defined(ZKV_PAIRED)
 // ---------------------------------------------------------------- context set-up (run once per VK on the device)
-ZKV_HD void setup_lines(const uint32_t q[4][8], LineAff* out) {
+ZKV_HD LineAffC line_to_table(const LineAff& l) {
+    LineAffC r; r.nl.c0 = l.nl.c0; r.nl.c1 = l.nl.c1; r.c.c0 = l.c.c0; r.c.c1 = l.c.c1; return r;
+}
+ZKV_HD void setup_lines(const uint32_t q[4][8], LineAffC* out) {
     G2A Q, T;
     Q.x.c0 = fp_from_raw(q[0]); Q.x.c1 = fp_from_raw(q[1]); Q.y.c0 = fp_from_raw(q[2]); Q.y.c1 = fp_from_raw(q[3]);
     T = Q;
@@ -292,15 +293,15 @@ ZKV_HD void setup_lines(const uint32_t q[4][8], LineAff* out) {
     int li = 0;
 #pragma unroll 1
     for (int i = ZKV_ATE_NAF_LEN - 2; i >= 0; i--) {
-        out[li++] = aff_dbl(T);
+        out[li++] = line_to_table(aff_dbl(T));
         int d = ate_naf(i);
-        if (d != 0) out[li++] = aff_add(T, Q.x, d > 0 ? Q.y : nqy);
+        if (d != 0) out[li++] = line_to_table(aff_add(T, Q.x, d > 0 ? Q.y : nqy));
     }
     Fp2 q1x, q1y, q2x, q2y;
     g2_frob_affine(q1x, q1y, Q.x, Q.y);
     g2_frob2_affine(q2x, q2y, Q.x, Q.y);
-    out[li++] = aff_add(T, q1x, q1y);
-    out[li++] = aff_add(T, q2x, f2_neg(q2y));
+    out[li++] = line_to_table(aff_add(T, q1x, q1y));
+    out[li++] = line_to_table(aff_add(T, q2x, f2_neg(q2y)));
 }
 ZKV_HD G1J g1_mul_raw(const Fp& x, const Fp& y, const uint32_t k[8]) {
     G1J acc = g1j_infinity();
@@ -358,7 +359,9 @@ ZKV_HD void setup_alpha_beta(const VkRaw& vk, VkTables& t, MRef fm, MRef tm) {
     bx.c0 = fp_from_raw(vk.beta[0]); bx.c1 = fp_from_raw(vk.beta[1]);
     by.c0 = fp_from_raw(vk.beta[2]); by.c1 = fp_from_raw(vk.beta[3]);
     miller_loop_m(t, 0, n, bx, by, false, fm, tm);
-    t.f_alpha_beta = m_ld_f12(fm);
+    for (int k = 0; k < 96; k++) t.f_alpha_beta[k] = fm.p[(size_t)k * fm.stride];
 }
+
+#endif  // !ZKV_PAIRED
 
 }  // namespace zkv

@@ -25,7 +25,7 @@ static VkTables* tables(int vm, const uint8_t* cr, const uint8_t* cid) {
     for (int b = 0; b < 2; b++) for (uint32_t w = 0; w < raw.var_windows[b]; w++) setup_msm_row(raw, *t, b, (int)w);
     setup_lines(raw.gamma, t->lines[0]);
     setup_lines(raw.delta, t->lines[1]);
-    { uint32_t ab[96 + 48]; MRef fm{ab, 1}, tm{ab + 96, 1}; setup_alpha_beta(raw, *t, fm, tm); }
+    { uint32_t ab[96 + 48]; MRef fm = m_ref(ab, 1), tm = m_ref(ab + 96, 1); setup_alpha_beta(raw, *t, fm, tm); }
     g_tab[vm] = t; memcpy(g_key[vm], key, 64);
     return t;
 }
@@ -54,15 +54,35 @@ int hs_groth16(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* wor
     g_stage_muls[1] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
     // same slot structure as the kernels: f and T in one buffer (LDS on the device), 5 Fp12 slots for the final exp
     static thread_local uint32_t buf[96 + 48], slots[5 * 96];
-    MRef fm{buf, 1}, tm{buf + 96, 1};
+    MRef fm = m_ref(buf, 1), tm = m_ref(buf + 96, 1);
     miller_loop_m(*t, fl, n, p.bx, p.by, true, fm, tm);
     g_stage_muls[3] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
-    MRef F{slots, 1}, E{slots + 96, 1}, Y1{slots + 192, 1}, Y3{slots + 288, 1}, Y4{slots + 384, 1};
-    m_st_f12(F, t->f_alpha_beta);
+    MRef F = m_ref(slots, 1), E = m_ref(slots + 96, 1), Y1 = m_ref(slots + 192, 1), Y3 = m_ref(slots + 288, 1), Y4 = m_ref(slots + 384, 1);
+    for (int k = 0; k < 96; k++) slots[k] = t->f_alpha_beta[k];
     f12m_mul(F, F, fm);
     int acc = final_exp_is_one_m(F, E, Y1, Y3, Y4, fm) ? 1 : 0;
     g_stage_muls[4] = zkv_fp_mul_counter - c0;
     return acc;
+}
+// Runs PREP + MSM for one proof and exports what the Fp2-heavy stages consume (for the lane-pair host emulation,
+// host_sim_paired.cpp).  Returns the device-table pointer, or NULL when the proof is rejected before the pairing.
+const void* hs_prepare(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* words, const uint8_t* s0, const uint8_t* s1,
+                       uint32_t* flags_out, uint32_t* norm48, uint32_t* b32) {
+    VkTables* t = tables(vm, cr, cid);
+    if (vm == 0) { uint32_t id[8]; load_be256(id, cid); if (!raw_lt_r(id)) return nullptr; }
+    uint32_t w[8][8];
+    for (int k = 0; k < 8; k++) load_be256(w[k], words + 32 * k);
+    PrepOut p; memset(&p, 0, sizeof p);
+    load_be256(p.s[0], s0); load_be256(p.s[1], s1);
+    if (!raw_lt_r(p.s[0]) || !raw_lt_r(p.s[1])) return nullptr;
+    if (!prep_points(w, vm == 0, p)) return nullptr;
+    G1Norm n; uint32_t fl = p.flags;
+    msm_normalize(*t, p, fl, n);
+    *flags_out = fl;
+    const Fp* nf[6] = {&n.axs, &n.ays, &n.lxs, &n.lys, &n.cxs, &n.cys};
+    for (int k = 0; k < 6; k++) memcpy(norm48 + 8 * k, nf[k]->v, 32);
+    memcpy(b32, p.bx.c0.v, 32); memcpy(b32 + 8, p.bx.c1.v, 32); memcpy(b32 + 16, p.by.c0.v, 32); memcpy(b32 + 24, p.by.c1.v, 32);
+    return t;
 }
 void hs_risc0_scalars(const uint8_t* image_id, const uint8_t* journal, uint8_t* digest32, uint8_t* lo32, uint8_t* hi32) {
     Risc0Consts k; host::risc0_consts(k);
@@ -85,7 +105,7 @@ void hs_fp_mulmod(const uint8_t* a, const uint8_t* b, uint8_t* out) {
 // cyclotomic subgroup (x^((p^6-1)(p^2+1)) for x built from the seed bytes)
 int hs_cyclo_sqr_check(const uint8_t* seed384) {
     uint32_t buf[4 * 96];
-    MRef X{buf, 1}, A{buf + 96, 1}, B{buf + 192, 1}, C{buf + 288, 1};
+    MRef X = m_ref(buf, 1), A = m_ref(buf + 96, 1), B = m_ref(buf + 192, 1), C = m_ref(buf + 288, 1);
     for (int k = 0; k < 12; k++) { uint32_t w[8]; load_be256(w, seed384 + 32 * k); w[7] &= 0x0fffffffu; m_st_fp(X, 8 * k, fp_from_raw(w)); }
     f12m_copy(A, X); f12m_conj(A); f12m_inv(B, X); f12m_mul(A, A, B);      // ^(p^6-1)
     f12m_frob(B, A, 2); f12m_mul(A, B, A);                                  // ^(p^2+1)

@@ -1,0 +1,60 @@
+// Host emulation of the lane-pair kernels (stylus_zkvm_verifiers_amd/csrc/k_pair.hip): the same ZKV_PAIRED code the
+// GPU runs, with the two lanes of a pair played by two threads and the DPP operand exchange by a shared slot and a
+// barrier.  TEST ONLY.
+#define ZKV_PAIRED 1
+#include <atomic>
+#include <stdint.h>
+#include <string.h>
+#include <thread>
+#include "../../stylus_zkvm_verifiers_amd/csrc/zkv_verify.h"
+
+static thread_local uint32_t tl_par = 0;
+static volatile uint32_t g_xch[2];
+static std::atomic<int> g_cnt{0}, g_gen{0};
+static void pair_barrier() {
+    int g = g_gen.load(std::memory_order_acquire);
+    if (g_cnt.fetch_add(1, std::memory_order_acq_rel) == 1) { g_cnt.store(0, std::memory_order_relaxed); g_gen.fetch_add(1, std::memory_order_acq_rel); }
+    else while (g_gen.load(std::memory_order_acquire) == g) std::this_thread::yield();
+}
+namespace zkv {
+uint32_t zkv_parity() { return tl_par; }
+uint32_t zkv_partner_u32(uint32_t x) {
+    g_xch[tl_par] = x; pair_barrier();
+    uint32_t r = g_xch[tl_par ^ 1u]; pair_barrier();
+    return r;
+}
+}
+using namespace zkv;
+
+struct Job { const VkTables* t; uint32_t flags; const uint32_t* norm48; const uint32_t* b32; int sub_ok[2]; int accept[2]; };
+
+static void lane(Job* j, uint32_t par) {
+    tl_par = par;
+    G1Norm n; Fp* nf[6] = {&n.axs, &n.ays, &n.lxs, &n.lys, &n.cxs, &n.cys};
+    for (int k = 0; k < 6; k++) memcpy(nf[k]->v, j->norm48 + 8 * k, 32);
+    Fp2 bx, by;
+    memcpy(bx.h.v, j->b32 + 8 * par, 32); memcpy(by.h.v, j->b32 + 16 + 8 * par, 32);
+    bool sub = (j->flags & FL_B_INF) ? true : g2_in_subgroup(bx, by);
+    j->sub_ok[par] = sub ? 1 : 0;
+    if (!sub) { j->accept[par] = 0; return; }
+    // lane-private half slots (f2w = 8) for f, T and the accumulator; full-layout slots (f2w = 16) for the cold values
+    static thread_local uint32_t half[48 + 24];
+    static uint32_t full[5 * 96];                    // shared by the two lanes like the HBM slots
+    MRef fm = m_ref(half, 1, 8), tm = m_ref(half + 48, 1, 8);
+    miller_loop_m(*j->t, j->flags, n, bx, by, true, fm, tm);
+    MRef ab = m_ref((uint32_t*)j->t->f_alpha_beta + 8 * par, 1, 16);
+    MRef F = m_ref(full + 8 * par, 1, 16), E = m_ref(full + 96 + 8 * par, 1, 16);
+    f12m_mul(F, fm, ab);
+    j->accept[par] = final_exp_is_one_m(F, E, m_off(E, 96), m_off(E, 192), m_off(E, 288), fm) ? 1 : 0;
+}
+
+extern "C" int hs2_pairing(const void* tables, uint32_t flags, const uint32_t* norm48, const uint32_t* b32, int* sub_ok) {
+    Job j; j.t = (const VkTables*)tables; j.flags = flags; j.norm48 = norm48; j.b32 = b32;
+    g_cnt = 0;
+    std::thread t1(lane, &j, 1u);
+    lane(&j, 0u);
+    t1.join();
+    if (j.sub_ok[0] != j.sub_ok[1] || j.accept[0] != j.accept[1]) return -1;     // the pair must agree
+    *sub_ok = j.sub_ok[0];
+    return j.accept[0];
+}

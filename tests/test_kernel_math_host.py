@@ -25,6 +25,20 @@ def hs():
     return C.CDLL(lib)
 
 
+@pytest.fixture(scope='module')
+def hs_pair(hs):
+    src = os.path.join(HERE, 'host_sim', 'host_sim_paired.cpp')
+    lib = os.path.join(HERE, 'host_sim', 'libhost_sim_paired.so')
+    csrc = os.path.join(HERE, '..', 'stylus_zkvm_verifiers_amd', 'csrc')
+    deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith('.h')]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wno-unknown-pragmas', '-o', lib, src])
+    L = C.CDLL(lib)
+    L.hs2_pairing.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    hs.hs_prepare.restype = C.c_void_p
+    return L
+
+
 def test_fp_mul_matches_bigint(hs):
     rng = random.Random(7)
     vals = [0, 1, 2, m.P - 1, m.P - 2, (1 << 253), (1 << 253) - 1] + [rng.randrange(m.P) for _ in range(300)]
@@ -75,6 +89,29 @@ def test_groth16_core_on_corpus(hs, verify_corpus, real_proofs):
             proof = H(c['proof'])
             s0 = H(c['vkey']); s1 = m.be32(m.sp1_hash_public_values(H(c['public_values'])))
             acc = hs.hs_groth16(1, None, None, proof[4:], s0, s1)
+        assert acc == (1 if c['status'] == 0 else 0), c['name']
+        n += 1
+    assert n > 40
+
+
+def test_lane_pair_kernels_on_corpus(hs, hs_pair, verify_corpus, real_proofs):
+    """The ZKV_PAIRED code of k_pair.hip (one proof per two lanes, operands exchanged between the lanes), emulated with
+    two host threads: same accept/reject as the golden corpus on every case that reaches the pairing."""
+    r0 = real_proofs['risc0']
+    cr, cid = H(r0['control_root']), H(r0['bn254_control_id'])
+    v = m.Risc0Verifier(); v.initialize(cr, cid)
+    n = 0
+    for c in verify_corpus['cases']:
+        if c['status'] not in (0, 1):
+            continue
+        if c['vm'] == 'risc0':
+            sig = v.signals(m.receipt_claim_ok_digest(H(c['image_id']), H(c['journal_digest'])))
+            args = (0, cr, cid, H(c['seal'])[4:], m.be32(sig[2]), m.be32(sig[3]))
+        else:
+            args = (1, None, None, H(c['proof'])[4:], H(c['vkey']), m.be32(m.sp1_hash_public_values(H(c['public_values']))))
+        fl = C.c_uint32(0); norm = (C.c_uint32 * 48)(); b = (C.c_uint32 * 32)(); sub = C.c_int(0)
+        t = hs.hs_prepare(*args, C.byref(fl), norm, b)
+        acc = hs_pair.hs2_pairing(t, fl.value, norm, b, C.byref(sub)) if t else 0
         assert acc == (1 if c['status'] == 0 else 0), c['name']
         n += 1
     assert n > 40
