@@ -103,6 +103,21 @@ int zkv_sp1_verify_proof(zkv_ctx* ctx, const uint8_t program_vkey[32], const uin
 int zkv_sp1_verify_batch_dev(zkv_ctx* ctx, size_t n, const uint8_t* d_program_vkeys, const uint8_t* d_public_values, size_t pv_len,
                              const uint8_t* d_proofs, uint8_t* d_status, uint8_t* d_recv_selector, void* stream);
 
+/* ------------------------------------------------------------------ precompile-level batches (the inner seam)
+ * The three EVM precompiles the reference STATICCALLs (common/groth16.rs:12-14): ecAdd 0x06 (call site :55),
+ * ecMul 0x07 (:54), ecPairing 0x08 (:121-125), with EIP-196/197 semantics.  ok[i] = 1 when call i succeeds, 0 when
+ * the precompile would fail (coordinate >= Q, point off curve / off twist / outside the order-r subgroup): the
+ * reference maps that to Err(()) (groth16.rs:60-73, 109-128).  Host buffers. */
+#define ZKV_VM_BN254 2
+zkv_ctx* zkv_bn254_ctx_create(int device);
+/* in: n x 128 bytes (x1 y1 x2 y2), out: n x 64 bytes */
+int zkv_bn254_ecadd_batch(zkv_ctx* ctx, size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok);
+/* in: n x 96 bytes (x y scalar), out: n x 64 bytes */
+int zkv_bn254_ecmul_batch(zkv_ctx* ctx, size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok);
+/* in: n calls of k pairs each, k x 192 bytes per call (G1 x y, G2 x_im x_re y_im y_re); result[i] = 1 iff the product
+ * of the k pairings is 1 (the precompile's 32-byte output word), meaningful when ok[i] = 1. */
+int zkv_bn254_pairing_batch(zkv_ctx* ctx, size_t n, size_t k, const uint8_t* in, uint8_t* result, uint8_t* ok);
+
 /* ------------------------------------------------------------------ shared */
 int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_RISC0 / ZKV_VM_SP1 */
 /* Blocks until everything enqueued on the context's stream has finished. */

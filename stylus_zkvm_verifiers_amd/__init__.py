@@ -7,8 +7,9 @@ from . import errors
 from .errors import VerifierError
 from .risc0 import RiscZeroVerifier
 from .sp1 import Sp1Verifier
+from .bn254 import Bn254Precompiles
 
-__all__ = ['RiscZeroVerifier', 'Sp1Verifier', 'VerifierError', 'errors', 'device_count']
+__all__ = ['RiscZeroVerifier', 'Sp1Verifier', 'Bn254Precompiles', 'VerifierError', 'errors', 'device_count']
 
 
 def device_count():

@@ -35,6 +35,10 @@ SYMBOLS = {
     'zkv_sp1_verify_batch': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'zkv_sp1_verify_proof': (_i, [_vp, _cp, _cp, _sz, _cp, _sz, _u8p, _cp]),
     'zkv_sp1_verify_batch_dev': (_i, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    'zkv_bn254_ctx_create': (_vp, [_i]),
+    'zkv_bn254_ecadd_batch': (_i, [_vp, _sz, _vp, _vp, _vp]),
+    'zkv_bn254_ecmul_batch': (_i, [_vp, _sz, _vp, _vp, _vp]),
+    'zkv_bn254_pairing_batch': (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
     'zkv_ctx_vm': (_i, [_vp]),
     'zkv_ctx_synchronize': (_i, [_vp]),
     'zkv_ctx_last_stage_ms': (_i, [_vp, C.POINTER(C.c_float)]),

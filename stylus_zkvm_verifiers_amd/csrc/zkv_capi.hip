@@ -84,19 +84,21 @@ static int ctx_device_init(zkv_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
-    VkRaw raw;
-    if (c->vm == ZKV_VM_RISC0) host::fill_vk_risc0(raw, c->control_root_0, c->control_root_1, c->control_id);
-    else host::fill_vk_sp1(raw);
-    if (c->id_ge_r) memset(raw.fixed_scalar[5], 0, 32);      // never used: every proof fails the range check first
-    VkRaw* d_raw = nullptr;
-    HIP_TRY(hipMalloc(&d_raw, sizeof(VkRaw)));
-    HIP_TRY(hipMalloc(&c->d_tab, sizeof(VkTables)));
-    HIP_TRY(hipMemsetAsync(c->d_tab, 0, sizeof(VkTables), c->stream));
-    HIP_TRY(hipMemcpyAsync(d_raw, &raw, sizeof raw, hipMemcpyHostToDevice, c->stream));
-    launch_setup(d_raw, c->d_tab, c->stream);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(d_raw);
+    if (c->vm != ZKV_VM_BN254) {
+        VkRaw raw;
+        if (c->vm == ZKV_VM_RISC0) host::fill_vk_risc0(raw, c->control_root_0, c->control_root_1, c->control_id);
+        else host::fill_vk_sp1(raw);
+        if (c->id_ge_r) memset(raw.fixed_scalar[5], 0, 32);      // never used: every proof fails the range check first
+        VkRaw* d_raw = nullptr;
+        HIP_TRY(hipMalloc(&d_raw, sizeof(VkRaw)));
+        HIP_TRY(hipMalloc(&c->d_tab, sizeof(VkTables)));
+        HIP_TRY(hipMemsetAsync(c->d_tab, 0, sizeof(VkTables), c->stream));
+        HIP_TRY(hipMemcpyAsync(d_raw, &raw, sizeof raw, hipMemcpyHostToDevice, c->stream));
+        launch_setup(d_raw, c->d_tab, c->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(d_raw);
+    }
     size_t cap = chunk_capacity();
     c->ws.cap = cap;
     if (hipMalloc(&c->ws.prep, sizeof(uint32_t) * WS_PREP_WORDS * cap) != hipSuccess ||
@@ -338,6 +340,46 @@ ZKV_EXPORT int zkv_sp1_verify_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d_v
     if (!c || c->vm != ZKV_VM_SP1) return ZKV_ERR_WRONG_CTX;
     if (n && !d_pv) return ZKV_ERR_INVALID_ARG;
     return run_dev_batch(c, n, d_proofs, d_vkeys, nullptr, d_pv, pv_len, d_status, d_recv, stream);
+}
+
+// ------------------------------------------------------------------ precompile-level batches
+ZKV_EXPORT zkv_ctx* zkv_bn254_ctx_create(int device) {
+    zkv_ctx* c = new (std::nothrow) zkv_ctx();
+    if (!c) return nullptr;
+    c->vm = ZKV_VM_BN254; c->device = device; c->initialized = true;
+    memset(&c->consts, 0, sizeof c->consts);
+    return c;
+}
+// kind 0 = ecAdd (128 -> 64), 1 = ecMul (96 -> 64), 2 = ecPairing (k*192 -> result byte)
+static int run_precompile(zkv_ctx* c, int kind, size_t n, size_t k, const uint8_t* in, uint8_t* out, uint8_t* ok) {
+    if (!c || c->vm != ZKV_VM_BN254) return ZKV_ERR_WRONG_CTX;
+    if (n && (!in || !out || !ok)) return ZKV_ERR_INVALID_ARG;
+    if (!n) return ZKV_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ctx_device_init(c);
+    if (rc != ZKV_OK) return rc;
+    const size_t in_sz = kind == 0 ? 128 : kind == 1 ? 96 : 192 * k, out_sz = kind == 2 ? 1 : 64, cap = c->ws.cap;
+    for (size_t base = 0; base < n; base += cap) {
+        size_t m = n - base < cap ? n - base : cap;
+        if ((rc = grow(&c->d_blob, &c->blob_cap, m * in_sz + 8)) != ZKV_OK) return rc;
+        if ((rc = grow(&c->d_pv, &c->pv_cap, m * out_sz + 8)) != ZKV_OK) return rc;
+        if (in_sz) HIP_TRY(hipMemcpyAsync(c->d_blob, in + base * in_sz, m * in_sz, hipMemcpyHostToDevice, c->stream));
+        if (kind == 0) launch_ecadd(m, c->d_blob, c->d_pv, c->d_status, c->stream);
+        else if (kind == 1) launch_ecmul(m, c->d_blob, c->d_pv, c->d_status, c->stream);
+        else launch_pairing(m, (uint32_t)k, c->d_blob, c->ws, c->d_pv, c->d_status, c->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out + base * out_sz, c->d_pv, m * out_sz, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(ok + base, c->d_status, m, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return ZKV_OK;
+}
+ZKV_EXPORT int zkv_bn254_ecadd_batch(zkv_ctx* c, size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok) { return run_precompile(c, 0, n, 0, in, out, ok); }
+ZKV_EXPORT int zkv_bn254_ecmul_batch(zkv_ctx* c, size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok) { return run_precompile(c, 1, n, 0, in, out, ok); }
+ZKV_EXPORT int zkv_bn254_pairing_batch(zkv_ctx* c, size_t n, size_t k, const uint8_t* in, uint8_t* result, uint8_t* ok) {
+    if (k > 64) return ZKV_ERR_INVALID_ARG;
+    uint8_t dummy = 0;
+    return run_precompile(c, 2, n, k, k ? in : &dummy, result, ok);
 }
 
 // ------------------------------------------------------------------ shared

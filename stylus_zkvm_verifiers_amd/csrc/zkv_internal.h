@@ -56,4 +56,9 @@ void launch_g2chk2(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s
 void launch_miller2(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
 void launch_finalexp2(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
 
+// precompile-level batches (k_precompile.hip)
+void launch_ecadd(size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok, hipStream_t s);
+void launch_ecmul(size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok, hipStream_t s);
+void launch_pairing(size_t n, uint32_t k, const uint8_t* in, const Workspace& ws, uint8_t* result, uint8_t* ok, hipStream_t s);
+
 }  // namespace zkv

@@ -99,3 +99,53 @@ def test_empty_batch(r0, sp1):
     assert len(st) == 0
     st, rv = sp1.verify_batch([], [], [])
     assert len(st) == 0
+
+
+def test_precompile_seam_matches_kats_and_oracle(zkv, precompile_kats):
+    """Inner seam: batched ecAdd / ecMul / ecPairing with EIP-196/197 semantics against the golden KATs
+    (spec model) and the C oracle on seeded random inputs."""
+    import random
+    import oracle_lib as ol
+    pc = zkv.Bn254Precompiles()
+    adds = [H(c['input']) for c in precompile_kats['ecadd'] if len(c['input']) == 256]
+    want = [c['output'] for c in precompile_kats['ecadd'] if len(c['input']) == 256]
+    got = pc.ecadd(adds)
+    assert [g.hex() if g is not None else None for g in got] == want
+    muls = [c for c in precompile_kats['ecmul']]
+    got = pc.ecmul([H(c['input']) for c in muls])
+    assert [g.hex() if g is not None else None for g in got] == [c['output'] for c in muls]
+    for k in (1, 2):
+        cases = [c for c in precompile_kats['pairing'] if len(c['input']) == 384 * k]
+        got = pc.pairing([H(c['input']) for c in cases], k)
+        for c, g in zip(cases, got):
+            exp = None if c['output'] is None else (int(c['output'], 16) != 0)
+            assert g == exp, c['name']
+    assert pc.pairing([b''], 0) == [True]                       # empty input: product of no pairings is 1
+    # random ecMul / ecAdd against the C oracle
+    rng = random.Random(99)
+    G = (1).to_bytes(32, 'big') + (2).to_bytes(32, 'big')
+    pts = [ol.ecmul(G + rng.randrange(1 << 256).to_bytes(32, 'big')) for _ in range(24)]
+    muls = [p + rng.randrange(1 << 256).to_bytes(32, 'big') for p in pts]
+    assert pc.ecmul(muls) == [ol.ecmul(m) for m in muls]
+    adds = [pts[i] + pts[(i * 5 + 1) % len(pts)] for i in range(len(pts))] + [pts[0] + pts[0], pts[1] + bytes(64)]
+    assert pc.ecadd(adds) == [ol.ecadd(a) for a in adds]
+    pc.close()
+
+
+def test_groth16_pairing_through_the_precompile_seam(zkv, real_proofs):
+    """The reference's own 768-byte ecPairing calldata for the real RISC Zero proof (groth16.rs:109-119) -> 1."""
+    import oracle_lib as ol
+    import spec_model as m
+    r = real_proofs['risc0']
+    seal = H(r['seal'])
+    w = [seal[4 + 32 * i:36 + 32 * i] for i in range(8)]
+    ax, ay = m.negate_g1_words(int.from_bytes(w[0], 'big'), int.from_bytes(w[1], 'big'))
+    vk = m.RISC0_VK
+    g2 = lambda q: b''.join(m.be32(v) for v in (q[0][0], q[0][1], q[1][0], q[1][1]))
+    data = (m.be32(ax) + m.be32(ay) + b''.join(w[2:6]) + m.be32(vk['alpha1'][0]) + m.be32(vk['alpha1'][1]) + g2(vk['beta2'])
+            + H(r['vk_x'][0]) + H(r['vk_x'][1]) + g2(vk['gamma2']) + w[6] + w[7] + g2(vk['delta2']))
+    pc = zkv.Bn254Precompiles()
+    assert pc.pairing([data], 4) == [True]
+    bad = bytearray(data); bad[100] ^= 1
+    assert pc.pairing([bytes(bad)], 4) == [ol.ecpairing(bytes(bad)) if ol.ecpairing(bytes(bad)) is None else bool(ol.ecpairing(bytes(bad))[-1])]
+    pc.close()
