@@ -79,6 +79,21 @@ class Shard:
         self.stage_samples += 1
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes on this same default workload; tools/summarize_profiles.py).  None when no profile covers the kernel."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))):
+        try:
+            v = json.load(open(f)).get('bytes_per_launch', {}).get(kernel)
+        except (OSError, ValueError):
+            v = None
+        if v is not None:
+            best = v
+    return best
+
+
 def host_cores():
     """CPU threads this process may actually use: affinity mask, capped by the cgroup CPU quota when one is set."""
     try:
@@ -209,6 +224,9 @@ def main():
         last_chunk = dom.n - (launches - 1) * per_launch          # events bracket the last chunk of a step
         bpp = BYTES_PER_PROOF[dom.vm]
         achieved = last_chunk * bpp / (avg[k] * 1e-3) / 1e9
+        pair = os.environ.get('ZKV_LANES_PER_PROOF', '2') != '1'
+        kname = 'k_' + STAGES[k] + ('_risc0' if k == 0 and dom.vm == 'risc0' else '_sp1' if k == 0 else '') + ('2' if pair and k >= 2 else '')
+        traffic = pmc_traffic(kname) if (args.workload == 'risc0_2p16' and not args.n) else None
         out = {
             'metric': 'Groth16 proofs verified/sec (BN254)', 'value': value, 'unit': 'proofs/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
@@ -216,8 +234,8 @@ def main():
             'config': {'workload': args.workload, 'proofs_per_gpu': n_rank, 'global_batch': total,
                        'mutated_fraction': (1.0 / args.mutate_every) if args.mutate_every else 0.0,
                        'parallelism': 'dp%d (independent shards, no data-path collective)' % world},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_' + STAGES[k], 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+            'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel_ms': float(avg[k]), 'proofs_per_launch': int(last_chunk), 'algorithmic_bytes_per_proof': bpp},
             'stage_ms': {STAGES[i]: float(avg[i]) for i in range(5)},
             'parity': {'accept_reject_matches_construction': parity_all, 'ok_counts_rank0': ok_counts,

@@ -242,6 +242,49 @@ ZKV_HD Fp fp_inv(const Fp& a) {
     return acc;
 }
 
+// N independent modular additions / subtractions, carry chains interleaved limb by limb (same idea as *_x2).
+template <int N>
+ZKV_HD void fp_add_n(const Fp (&a)[N], const Fp (&b)[N], Fp (&r)[N]) {
+    const uint32_t P[8] = ZKV_FP_P_LIMBS;
+    Fp t[N], s[N]; uint32_t c[N], w[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) { c[k] = 0; w[k] = 0; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int k = 0; k < N; k++) t[k].v[i] = addc(a[k].v[i], b[k].v[i], c[k]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int k = 0; k < N; k++) s[k].v[i] = subb(t[k].v[i], P[i], w[k]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int k = 0; k < N; k++) r[k].v[i] = w[k] ? t[k].v[i] : s[k].v[i];
+    }
+}
+template <int N>
+ZKV_HD void fp_sub_n(const Fp (&a)[N], const Fp (&b)[N], Fp (&r)[N]) {
+    const uint32_t P[8] = ZKV_FP_P_LIMBS;
+    Fp t[N]; uint32_t w[N], c[N], m[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) { c[k] = 0; w[k] = 0; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int k = 0; k < N; k++) t[k].v[i] = subb(a[k].v[i], b[k].v[i], w[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) m[k] = 0u - w[k];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int k = 0; k < N; k++) r[k].v[i] = addc(t[k].v[i], P[i] & m[k], c[k]);
+    }
+}
+
 // ---------------------------------------------------------------- Fp2
 #if !defined(ZKV_PAIRED)
 ZKV_HD Fp2 f2_const(const Fp2C& c) { Fp2 r; r.c0 = c.c0; r.c1 = c.c1; return r; }
@@ -413,17 +456,32 @@ ZKV_HD Fp2 f2_inv(const Fp2& a) {
 
 // ---------------------------------------------------------------- Fp6
 ZKV_HD Fp6 f6_zero() { Fp6 r; r.c0 = f2_zero(); r.c1 = f2_zero(); r.c2 = f2_zero(); return r; }
-ZKV_HD Fp6 f6_add(const Fp6& a, const Fp6& b) { Fp6 r; r.c0 = f2_add(a.c0, b.c0); r.c1 = f2_add(a.c1, b.c1); r.c2 = f2_add(a.c2, b.c2); return r; }
-ZKV_HD Fp6 f6_sub(const Fp6& a, const Fp6& b) { Fp6 r; r.c0 = f2_sub(a.c0, b.c0); r.c1 = f2_sub(a.c1, b.c1); r.c2 = f2_sub(a.c2, b.c2); return r; }
-ZKV_HD Fp6 f6_neg(const Fp6& a) { Fp6 r; r.c0 = f2_neg(a.c0); r.c1 = f2_neg(a.c1); r.c2 = f2_neg(a.c2); return r; }
+// Fp6 as a flat array of Fp components (3 per lane in lane-pair mode, 6 otherwise) for the interleaved chains.
+#if defined(ZKV_PAIRED)
+constexpr int F6N = 3;
+ZKV_HD void f6_flat(const Fp6& a, Fp (&o)[3]) { o[0] = a.c0.h; o[1] = a.c1.h; o[2] = a.c2.h; }
+ZKV_HD Fp6 f6_unflat(const Fp (&o)[3]) { Fp6 r; r.c0.h = o[0]; r.c1.h = o[1]; r.c2.h = o[2]; return r; }
+#else
+constexpr int F6N = 6;
+ZKV_HD void f6_flat(const Fp6& a, Fp (&o)[6]) { o[0] = a.c0.c0; o[1] = a.c0.c1; o[2] = a.c1.c0; o[3] = a.c1.c1; o[4] = a.c2.c0; o[5] = a.c2.c1; }
+ZKV_HD Fp6 f6_unflat(const Fp (&o)[6]) { Fp6 r; r.c0.c0 = o[0]; r.c0.c1 = o[1]; r.c1.c0 = o[2]; r.c1.c1 = o[3]; r.c2.c0 = o[4]; r.c2.c1 = o[5]; return r; }
+#endif
+ZKV_HD Fp6 f6_add(const Fp6& a, const Fp6& b) { Fp x[F6N], y[F6N], r[F6N]; f6_flat(a, x); f6_flat(b, y); fp_add_n<F6N>(x, y, r); return f6_unflat(r); }
+ZKV_HD Fp6 f6_sub(const Fp6& a, const Fp6& b) { Fp x[F6N], y[F6N], r[F6N]; f6_flat(a, x); f6_flat(b, y); fp_sub_n<F6N>(x, y, r); return f6_unflat(r); }
+ZKV_HD Fp6 f6_neg(const Fp6& a) { Fp x[F6N], z[F6N], r[F6N]; f6_flat(a, x); for (int k = 0; k < F6N; k++) z[k] = fp_zero(); fp_sub_n<F6N>(z, x, r); return f6_unflat(r); }
 ZKV_HD Fp6 f6_mul_v(const Fp6& a) { Fp6 r; r.c0 = f2_mul_xi(a.c2); r.c1 = a.c0; r.c2 = a.c1; return r; }
 ZKV_HD Fp6 f6_mul(const Fp6& a, const Fp6& b) {
     Fp2 v0 = f2_mul(a.c0, b.c0), v1 = f2_mul(a.c1, b.c1), v2 = f2_mul(a.c2, b.c2);
-    Fp6 r;
-    r.c0 = f2_add(v0, f2_mul_xi(f2_sub(f2_sub(f2_mul(f2_add_nr(a.c1, a.c2), f2_add_nr(b.c1, b.c2)), v1), v2)));
-    r.c1 = f2_add(f2_sub(f2_sub(f2_mul(f2_add_nr(a.c0, a.c1), f2_add_nr(b.c0, b.c1)), v0), v1), f2_mul_xi(v2));
-    r.c2 = f2_add(f2_sub(f2_sub(f2_mul(f2_add_nr(a.c0, a.c2), f2_add_nr(b.c0, b.c2)), v0), v2), v1);
-    return r;
+    Fp6 t, u, w;
+    t.c0 = f2_mul(f2_add_nr(a.c1, a.c2), f2_add_nr(b.c1, b.c2));
+    t.c1 = f2_mul(f2_add_nr(a.c0, a.c1), f2_add_nr(b.c0, b.c1));
+    t.c2 = f2_mul(f2_add_nr(a.c0, a.c2), f2_add_nr(b.c0, b.c2));
+    u.c0 = v1; u.c1 = v0; u.c2 = v0;
+    w.c0 = v2; w.c1 = v1; w.c2 = v2;
+    t = f6_sub(f6_sub(t, u), w);                         // the three Karatsuba cross terms, chains interleaved
+    u.c0 = v0; u.c1 = t.c1; u.c2 = t.c2;
+    w.c0 = f2_mul_xi(t.c0); w.c1 = f2_mul_xi(v2); w.c2 = v1;
+    return f6_add(u, w);
 }
 // a * (b0 + b1 v)   (5 Fp2 products)
 ZKV_HD Fp6 f6_mul_by_01(const Fp6& a, const Fp2& b0, const Fp2& b1) {

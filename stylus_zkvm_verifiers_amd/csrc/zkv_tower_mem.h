@@ -101,6 +101,16 @@ ZKV_HD_NI void f12m_mul(MRef d, MRef a, MRef b) {
     m_st_f6(d, 3, f6_sub(f6_sub(m, t0), t1));
     m_st_f6(d, 0, f6_add(t0, f6_mul_v(t1)));
 }
+// d <- a * conj(b)  (conj(b) = b^-1 for b in the cyclotomic subgroup)
+ZKV_HD_NI void f12m_mul_conj(MRef d, MRef a, MRef b) {
+    Fp6 ag = m_ld_f6(a, 0), bg = m_ld_f6(b, 0);
+    Fp6 t0 = f6_mul(ag, bg);
+    Fp6 ah = m_ld_f6(a, 3), bh = f6_neg(m_ld_f6(b, 3));
+    Fp6 t1 = f6_mul(ah, bh);
+    Fp6 m = f6_mul(f6_add(ag, ah), f6_add(bg, bh));
+    m_st_f6(d, 3, f6_sub(f6_sub(m, t0), t1));
+    m_st_f6(d, 0, f6_add(t0, f6_mul_v(t1)));
+}
 // f <- f * (c0 + (c3 + c4 v) w)
 ZKV_HD_NI void f12m_mul_by_034(MRef f, const Fp2* c0, const Fp2* c3, const Fp2* c4) {
     Fp6 g = m_ld_f6(f, 0), h = m_ld_f6(f, 3);

@@ -238,13 +238,20 @@ ZKV_HD void miller_loop_m(const VkTables& vk, uint32_t flags, const G1Norm& n, c
 }
 
 // ---------------------------------------------------------------- stage FINALEXP
-// acc <- x^u  (acc and x are different slots; x in the cyclotomic subgroup)
+// acc <- x^u  (acc and x are different slots; x in the cyclotomic subgroup).  Signed-digit (NAF) square-and-multiply:
+// 62 cyclotomic squarings and 23 multiplications, the -1 digits multiply by conj(x) = x^-1.
+ZKV_HD int8_t u_naf(int i) {
+    const int8_t NAF[ZKV_U_NAF_LEN] = ZKV_U_NAF;
+    return NAF[i];
+}
 ZKV_HD void exp_u_m(MRef acc, MRef x) {
     f12m_copy(acc, x);
 #pragma unroll 1
-    for (int i = 61; i >= 0; i--) {
+    for (int i = ZKV_U_NAF_LEN - 2; i >= 0; i--) {
         f12m_cyclo_sqr(acc);
-        if ((ZKV_BN_U >> i) & 1ULL) f12m_mul(acc, acc, x);
+        int d = u_naf(i);
+        if (d > 0) f12m_mul(acc, acc, x);
+        else if (d < 0) f12m_mul_conj(acc, acc, x);
     }
 }
 // f^(k (p^12-1)/r) == 1 with k = 2u(6u^2+3u+1), gcd(k, r) = 1  (Fuentes-Castaneda hard part; the chain is
