@@ -16,17 +16,47 @@ __device__ __forceinline__ void store_prep(const Workspace& ws, size_t i, const 
     }
 }
 
+// Fixed-stride batches (the HBM-resident fast path): the 64 seals of a wavefront are 16,640 contiguous bytes; the wave
+// copies them to LDS with fully coalesced dword loads (256 B per wave-instruction) and every lane then reads its own
+// 65 words from LDS (row stride 65 dwords: conflict-free).  Ragged batches read their records straight from HBM.
+struct SealReader {
+    const uint32_t* lds_row;     // non-null: staged record of this lane (words are still big-endian bytes)
+    const uint8_t* rec;          // otherwise: the record in HBM
+    __device__ __forceinline__ uint32_t word(int k) const {
+        return lds_row ? __builtin_bswap32(lds_row[k]) : load_be32(rec + 4 * k);
+    }
+    __device__ __forceinline__ void u256(uint32_t limbs[8], int word0) const {
+#pragma unroll 1
+        for (int j = 0; j < 8; j++) limbs[7 - j] = word(word0 + j);
+    }
+};
+__device__ __forceinline__ bool stage_seals(const PrepArgs& a, uint32_t* lds) {
+    if (a.off || a.stride != 260 || ((uintptr_t)a.blob & 3u)) return false;          // wave-uniform
+    size_t base = (size_t)blockIdx.x * ZKV_BLOCK;
+    size_t m = a.n - base < ZKV_BLOCK ? a.n - base : ZKV_BLOCK;
+    const uint32_t* src = (const uint32_t*)(a.blob + base * 260);
+    uint32_t total = (uint32_t)m * 65u;
+#pragma unroll 1
+    for (uint32_t j = threadIdx.x; j < total; j += ZKV_BLOCK) lds[j] = src[j];
+    __syncthreads();
+    return true;
+}
+
 // shared front: locate the record, run the reference's ordered checks (len < 4, selector, strict decode).
 // Returns true when the 8 words should be parsed; otherwise *st holds the final status.
-__device__ __forceinline__ bool front_checks(const PrepArgs& a, size_t i, const uint8_t*& rec, uint8_t& st) {
+__device__ __forceinline__ bool front_checks(const PrepArgs& a, size_t i, bool staged, const uint32_t* lds, SealReader& rd, uint8_t& st) {
     size_t len;
-    if (a.off) { rec = a.blob + a.off[i]; len = (size_t)(a.off[i + 1] - a.off[i]); }
-    else { rec = a.blob + i * (size_t)a.stride; len = a.stride; }
+    rd.lds_row = nullptr;
+    if (a.off) { rd.rec = a.blob + a.off[i]; len = (size_t)(a.off[i + 1] - a.off[i]); }
+    else {
+        rd.rec = a.blob + i * (size_t)a.stride; len = a.stride;
+        if (staged) rd.lds_row = lds + threadIdx.x * 65u;
+    }
     uint32_t rv = 0;
     bool go = false;
     if (len < 4) st = ST_INVALID_PROOF_DATA;                       // verifier.rs:151 / sp1 verifier.rs:64
     else {
-        uint32_t sel = load_be32(rec);
+        uint32_t sel = rd.word(0);
         if (sel != a.selector_be) { st = ST_SELECTOR_MISMATCH; rv = sel; }        // :155-165 / :68-78
         else if (len != 260) st = ST_INVALID_PROOF_DATA;            // strict abi_decode of 8 static words
         else if (a.force_fail) st = ST_VERIFICATION_FAILED;
@@ -40,11 +70,13 @@ __device__ __forceinline__ bool front_checks(const PrepArgs& a, size_t i, const 
 }
 
 __global__ __launch_bounds__(ZKV_BLOCK) void k_prep_risc0(PrepArgs a, Risc0Consts k, Workspace ws) {
+    __shared__ uint32_t seal_lds[ZKV_BLOCK * 65];
+    const bool staged = stage_seals(a, seal_lds);
     size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (i >= a.n) return;
-    const uint8_t* rec; uint8_t st;
+    SealReader rd; uint8_t st;
     uint32_t flags = 0;
-    if (front_checks(a, i, rec, st)) {
+    if (front_checks(a, i, staged, seal_lds, rd, st)) {
         PrepOut o;
         uint32_t h[8];
         if (a.in32_b) risc0_claim_digest(k, a.in32_a + 32 * i, a.in32_b + 32 * i, h);
@@ -55,7 +87,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_prep_risc0(PrepArgs a, Risc0Const
         risc0_split_digest(h, o.s[0], o.s[1]);                      // 128-bit halves: always < R
         uint32_t w[8][8];
 #pragma unroll 1
-        for (int j = 0; j < 8; j++) load_be256(w[j], rec + 4 + 32 * j);
+        for (int j = 0; j < 8; j++) rd.u256(w[j], 1 + 8 * j);
         if (prep_points(w, true, o)) { flags = o.flags; store_prep(ws, i, o); }
     }
     ws.flags[i] = flags;
@@ -63,11 +95,13 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_prep_risc0(PrepArgs a, Risc0Const
 }
 
 __global__ __launch_bounds__(ZKV_BLOCK) void k_prep_sp1(PrepArgs a, Workspace ws) {
+    __shared__ uint32_t seal_lds[ZKV_BLOCK * 65];
+    const bool staged = stage_seals(a, seal_lds);
     size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (i >= a.n) return;
-    const uint8_t* rec; uint8_t st;
+    SealReader rd; uint8_t st;
     uint32_t flags = 0;
-    if (front_checks(a, i, rec, st)) {
+    if (front_checks(a, i, staged, seal_lds, rd, st)) {
         PrepOut o;
         load_be256(o.s[0], a.in32_a + 32 * i);                      // U256::from_be_bytes(program_vkey), sp1/types.rs:24
         const uint8_t* pv; size_t pvl;
@@ -81,7 +115,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_prep_sp1(PrepArgs a, Workspace ws
         if (raw_lt_r(o.s[0])) {                                     // groth16.rs:32
             uint32_t w[8][8];
 #pragma unroll 1
-            for (int j = 0; j < 8; j++) load_be256(w[j], rec + 4 + 32 * j);
+            for (int j = 0; j < 8; j++) rd.u256(w[j], 1 + 8 * j);
             if (prep_points(w, false, o)) { flags = o.flags; store_prep(ws, i, o); }
         }
     }

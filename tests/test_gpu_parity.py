@@ -149,3 +149,43 @@ def test_groth16_pairing_through_the_precompile_seam(zkv, real_proofs):
     bad = bytearray(data); bad[100] ^= 1
     assert pc.pairing([bytes(bad)], 4) == [ol.ecpairing(bytes(bad)) if ol.ecpairing(bytes(bad)) is None else bool(ol.ecpairing(bytes(bad))[-1])]
     pc.close()
+
+
+def test_device_resident_fast_path_matches_oracle(zkv, r0, sp1, real_proofs):
+    """Fixed-stride, HBM-resident entry points (coalesced LDS staging of the seals) on a seeded synthetic batch with every
+    mutation class: statuses equal the CPU oracle and the ragged host-pointer path; partial last wavefront included."""
+    import torch
+    import oracle_lib as ol
+    from stylus_zkvm_verifiers_amd import synth
+    dev = torch.device('cuda', 0)
+    r = real_proofs['risc0']
+    n = 200                                                    # not a multiple of 64
+    seals, mut, mclass, flip = synth.make_batch('risc0', H(r['seal']), n, 0x5A4B5611, pool=4, mutate_every=5)
+    ids = np.tile(np.frombuffer(H(r['image_id']), dtype=np.uint8), (n, 1))
+    jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (n, 1)); jds[flip, 0] ^= 1
+    d_seals, d_ids, d_jds = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (seals, ids, jds))
+    d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev); d_rv = torch.zeros((n, 4), dtype=torch.uint8, device=dev)
+    r0.verify_batch_dev(n, d_seals.data_ptr(), d_ids.data_ptr(), d_jds.data_ptr(), d_st.data_ptr(), d_rv.data_ptr(),
+                        torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    st = d_st.cpu().numpy(); rv = d_rv.cpu().numpy()
+    orc = ol.Risc0Oracle(); orc.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    ost, orv = orc.verify_batch([x.tobytes() for x in seals], [x.tobytes() for x in ids], [x.tobytes() for x in jds], threads=8)
+    assert (st == ost).all()
+    assert (rv.reshape(-1) == orv).all()
+    hst, hrv = r0.verify_batch([x.tobytes() for x in seals], [x.tobytes() for x in ids], [x.tobytes() for x in jds])
+    assert (hst == st).all() and (hrv == rv).all()
+    assert ((st == 0) == ~mut).all() and set(st[mut]) == {1, 5}
+    # SP1, 96-byte public values
+    s = real_proofs['sp1']
+    n = 130
+    proofs, mut, mclass, flip = synth.make_batch('sp1', H(s['proof']), n, 0x5A4B5612, pool=4, mutate_every=5)
+    vk = np.tile(np.frombuffer(H(s['vkey']), dtype=np.uint8), (n, 1))
+    pv = np.tile(np.frombuffer(H(s['public_values']), dtype=np.uint8), (n, 1)); pv[flip, -1] ^= 1
+    d_p, d_vk, d_pv = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (proofs, vk, pv))
+    d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+    sp1.verify_batch_dev(n, d_vk.data_ptr(), d_pv.data_ptr(), 96, d_p.data_ptr(), d_st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    st = d_st.cpu().numpy()
+    ost, _ = ol.sp1_verify_batch([x.tobytes() for x in vk], [x.tobytes() for x in pv], [x.tobytes() for x in proofs], threads=8)
+    assert (st == ost).all() and ((st == 0) == ~mut).all()
