@@ -120,6 +120,10 @@ int zkv_bn254_pairing_batch(zkv_ctx* ctx, size_t n, size_t k, const uint8_t* in,
 
 /* ------------------------------------------------------------------ shared */
 int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_RISC0 / ZKV_VM_SP1 */
+/* Tuning knob (no reference counterpart): kernel mapping of the G2 / Miller / final-exponentiation stages.
+ * 2 = one proof per pair of lanes (default, two wavefronts per SIMD), 1 = one proof per lane, 0 = library default
+ * (environment ZKV_LANES_PER_PROOF).  Results are identical. */
+int zkv_ctx_set_lanes_per_proof(zkv_ctx* ctx, int lanes);
 /* Blocks until everything enqueued on the context's stream has finished. */
 int zkv_ctx_synchronize(zkv_ctx* ctx);
 /* HIP-event durations (ms) of the stages of the most recent batch chunk on this context:

@@ -17,7 +17,7 @@ using namespace zkv;
 #define ZKV_EXPORT extern "C" __attribute__((visibility("default")))
 
 struct zkv_ctx {
-    int vm = 0, device = 0;
+    int vm = 0, device = 0, lanes = 0;       // lanes: 0 = library default, 1 or 2 = lanes per proof for the Fp2-heavy stages
     bool initialized = false, id_ge_r = false;
     uint8_t control_root_0[16] = {0}, control_root_1[16] = {0}, control_id[32] = {0}, selector[4] = {0};
     Risc0Consts consts;
@@ -134,7 +134,7 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     if (timed) (void)hipEventRecord(c->ev[1], s);
     launch_msm(a.n, c->d_tab, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[2], s);
-    const bool pair = lanes_per_proof() == 2;
+    const bool pair = (c->lanes ? c->lanes : lanes_per_proof()) == 2;
     if (pair) launch_g2chk2(a.n, c->ws, a.status, s); else launch_g2chk(a.n, c->ws, a.status, s);
     if (timed) (void)hipEventRecord(c->ev[3], s);
     if (pair) launch_miller2(a.n, c->d_tab, c->ws, s); else launch_miller(a.n, c->d_tab, c->ws, s);
@@ -384,6 +384,12 @@ ZKV_EXPORT int zkv_bn254_pairing_batch(zkv_ctx* c, size_t n, size_t k, const uin
 
 // ------------------------------------------------------------------ shared
 ZKV_EXPORT int zkv_ctx_vm(const zkv_ctx* c) { return c ? c->vm : ZKV_ERR_INVALID_ARG; }
+ZKV_EXPORT int zkv_ctx_set_lanes_per_proof(zkv_ctx* c, int lanes) {
+    if (!c || (lanes != 0 && lanes != 1 && lanes != 2)) return ZKV_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->lanes = lanes;
+    return ZKV_OK;
+}
 ZKV_EXPORT int zkv_ctx_synchronize(zkv_ctx* c) {
     if (!c) return ZKV_ERR_INVALID_ARG;
     if (!c->dev_ready) return ZKV_OK;

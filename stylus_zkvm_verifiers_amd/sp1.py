@@ -55,6 +55,10 @@ class Sp1Verifier:
         _lib.check(self._L.zkv_sp1_verify_batch_dev(self._h, n, d_vkeys, d_public_values, pv_len, d_proofs, d_status,
                                                     d_recv or None, stream or None), 'zkv_sp1_verify_batch_dev')
 
+    def set_lanes_per_proof(self, lanes):
+        """Kernel mapping of the Fp2-heavy stages: 2 = lane pairs (default), 1 = one proof per lane; same results."""
+        _lib.check(self._L.zkv_ctx_set_lanes_per_proof(self._h, lanes), 'zkv_ctx_set_lanes_per_proof')
+
     def synchronize(self):
         _lib.check(self._L.zkv_ctx_synchronize(self._h), 'zkv_ctx_synchronize')
 

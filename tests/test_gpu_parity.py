@@ -189,3 +189,32 @@ def test_device_resident_fast_path_matches_oracle(zkv, r0, sp1, real_proofs):
     st = d_st.cpu().numpy()
     ost, _ = ol.sp1_verify_batch([x.tobytes() for x in vk], [x.tobytes() for x in pv], [x.tobytes() for x in proofs], threads=8)
     assert (st == ost).all() and ((st == 0) == ~mut).all()
+
+
+def test_both_kernel_mappings_agree_on_a_2p13_batch(zkv, real_proofs):
+    """8,192 seeded proofs (every mutation class, 1/16 mutated) through the lane-pair kernels and the one-proof-per-lane kernels:
+    identical statuses, accept <=> not mutated on the whole batch, and equality with the CPU oracle on a 1,024-proof sample."""
+    import torch
+    import oracle_lib as ol
+    from stylus_zkvm_verifiers_amd import synth
+    dev = torch.device('cuda', 0)
+    r = real_proofs['risc0']
+    n = 1 << 13
+    seals, mut, mclass, flip = synth.make_batch('risc0', H(r['seal']), n, 0x5A4B5621, pool=8, mutate_every=16)
+    ids = np.tile(np.frombuffer(H(r['image_id']), dtype=np.uint8), (n, 1))
+    jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (n, 1)); jds[flip, 0] ^= 1
+    d_seals, d_ids, d_jds = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (seals, ids, jds))
+    out = {}
+    for lanes in (2, 1):
+        v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id'])); v.set_lanes_per_proof(lanes)
+        d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+        v.verify_batch_dev(n, d_seals.data_ptr(), d_ids.data_ptr(), d_jds.data_ptr(), d_st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out[lanes] = d_st.cpu().numpy()
+        v.close()
+    assert (out[1] == out[2]).all()
+    assert ((out[2] == 0) == ~mut).all()
+    k = 1024
+    orc = ol.Risc0Oracle(); orc.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    ost, _ = orc.verify_batch([x.tobytes() for x in seals[:k]], [x.tobytes() for x in ids[:k]], [x.tobytes() for x in jds[:k]], threads=8)
+    assert (out[2][:k] == ost).all()
