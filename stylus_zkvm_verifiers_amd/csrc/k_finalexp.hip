@@ -11,7 +11,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_finalexp(size_t n, Workspace ws, 
     uint32_t flags = ws.flags[i];
     if (!(flags & FL_ALIVE)) return;
     uint32_t st = (uint32_t)ws.cap;
-    MRef acc = m_ref(lds + threadIdx.x, ZKV_BLOCK);
+    LRef acc = l_ref(lds + threadIdx.x);
     MRef F = m_ref(ws.f + i, st);
     MRef E = m_ref(ws.fe + i, st);
     MRef Y1 = m_off(E, 96), Y3 = m_off(E, 192), Y4 = m_off(E, 288);

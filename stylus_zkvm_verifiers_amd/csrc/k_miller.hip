@@ -19,8 +19,8 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_miller(size_t n, const VkTables* 
     Fp2 bx, by;
     bx.c0 = ws_ld(ws.prep, ws.cap, 32, i); bx.c1 = ws_ld(ws.prep, ws.cap, 40, i);
     by.c0 = ws_ld(ws.prep, ws.cap, 48, i); by.c1 = ws_ld(ws.prep, ws.cap, 56, i);
-    MRef fm = m_ref(lds + threadIdx.x, ZKV_BLOCK);
-    MRef tm = m_ref(lds + 96 * ZKV_BLOCK + threadIdx.x, ZKV_BLOCK);
+    LRef fm = l_ref(lds + threadIdx.x);
+    LRef tm = l_ref(lds + 96 * ZKV_BLOCK + threadIdx.x);
     miller_loop_m(*vk, flags, nm, bx, by, true, fm, tm);
     MRef ab = m_ref((uint32_t*)(vk->f_alpha_beta), 1);
     MRef out = m_ref(ws.f + i, (uint32_t)ws.cap);

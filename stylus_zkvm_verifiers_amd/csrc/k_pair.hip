@@ -37,8 +37,8 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller2(size_t n, const VkTabl
     nm.lxs = ws_ld(ws.norm, ws.cap, 16, i); nm.lys = ws_ld(ws.norm, ws.cap, 24, i);
     nm.cxs = ws_ld(ws.norm, ws.cap, 32, i); nm.cys = ws_ld(ws.norm, ws.cap, 40, i);
     Fp2 bx = ld_b(ws, 32, i), by = ld_b(ws, 48, i);
-    MRef fm = m_ref(lds + threadIdx.x, ZKV_BLOCK, 8);
-    MRef tm = m_ref(lds + 48 * ZKV_BLOCK + threadIdx.x, ZKV_BLOCK, 8);
+    LRef fm = l_ref(lds + threadIdx.x);
+    LRef tm = l_ref(lds + 48 * ZKV_BLOCK + threadIdx.x);
     miller_loop_m(*vk, flags, nm, bx, by, true, fm, tm);
     MRef ab = m_ref((uint32_t*)(vk->f_alpha_beta) + 8 * par, 1, 16);
     MRef out = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, (uint32_t)ws.cap, 16);
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_finalexp2(size_t n, Workspace 
     if (!(flags & FL_ALIVE)) return;
     const uint32_t par = threadIdx.x & 1u;
     const uint32_t st = (uint32_t)ws.cap;
-    MRef acc = m_ref(lds + threadIdx.x, ZKV_BLOCK, 8);
+    LRef acc = l_ref(lds + threadIdx.x);
     MRef F = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, st, 16);
     MRef E = m_ref(ws.fe + (size_t)(8 * par) * ws.cap + i, st, 16);
     MRef Y1 = m_off(E, 96), Y3 = m_off(E, 192), Y4 = m_off(E, 288);

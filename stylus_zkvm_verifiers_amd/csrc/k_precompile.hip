@@ -65,8 +65,8 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_pairing(size_t n, uint32_t k, con
     size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint8_t* base = in + (size_t)192 * k * i;
-    MRef fm = m_ref(lds + threadIdx.x, ZKV_BLOCK);
-    MRef tm = m_ref(lds + 96 * ZKV_BLOCK + threadIdx.x, ZKV_BLOCK);
+    LRef fm = l_ref(lds + threadIdx.x);
+    LRef tm = l_ref(lds + 96 * ZKV_BLOCK + threadIdx.x);
     const uint32_t st = (uint32_t)ws.cap;
     MRef P = m_ref(ws.f + i, st), E = m_ref(ws.fe + i, st);
     f12m_set_one(P);

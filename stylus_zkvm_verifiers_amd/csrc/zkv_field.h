@@ -414,9 +414,10 @@ Fp f2_mul_lane(Fp my_a, Fp my_b) {
 #endif
     const uint32_t FAT[9] = ZKV_FP_FAT4P_LIMBS;
     const bool odd = zkv_parity() != 0;
-    Fp ot_a = zkv_partner(my_a), ot_b = zkv_partner(my_b);
     uint32_t xa[9], xo[9], yb[9], yo[9], U[9], V[9];
-    fp_unpack29(my_a, xa); fp_unpack29(ot_a, xo); fp_unpack29(my_b, yb); fp_unpack29(ot_b, yo);
+    fp_unpack29(my_a, xa); fp_unpack29(my_b, yb);        // each lane unpacks its own operands once ...
+#pragma unroll
+    for (int i = 0; i < 9; i++) { xo[i] = zkv_partner_u32(xa[i]); yo[i] = zkv_partner_u32(yb[i]); }   // ... and swaps the limbs
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         U[i] = odd ? yo[i] : yb[i];

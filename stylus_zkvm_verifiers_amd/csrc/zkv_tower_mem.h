@@ -12,46 +12,72 @@
 
 namespace zkv {
 
-// word k of this lane's value: p[k * stride].  f2w = words between consecutive Fp2 coefficients of the slot:
-// 16 for the full layout (c0 then c1; a paired lane points p at its own component), 8 for a lane-private half slot.
-struct MRef { uint32_t* p; uint32_t stride; uint32_t f2w; };
-
+// MRef: generic slot, word k of this lane's value at p[k * stride] (HBM struct-of-arrays, constants, host tests).
+// f2w = words between consecutive Fp2 coefficients of the slot: 16 for the full layout (c0 then c1; a paired lane points p
+// at its own component), 8 for a lane-private half slot.
+struct MRef {
+    uint32_t* p; uint32_t stride; uint32_t f2w;
+    ZKV_HD uint32_t ld(int k) const { return p[(size_t)k * stride]; }
+    ZKV_HD void st(int k, uint32_t v) const { p[(size_t)k * stride] = v; }
+    ZKV_HD int fw() const { return (int)f2w; }
+};
 ZKV_HD MRef m_ref(uint32_t* p, uint32_t stride, uint32_t f2w = 16) { MRef r; r.p = p; r.stride = stride; r.f2w = f2w; return r; }
 ZKV_HD MRef m_off(MRef m, int words) { MRef r = m; r.p = m.p + (size_t)words * m.stride; return r; }
-ZKV_HD Fp m_ld_fp(MRef m, int word0) {
+
+// LRef: lane-interleaved LDS slot of a one-wavefront workgroup, word k at p[k * 64].  The pointer is typed as LDS
+// (address space 3) and the stride is a compile-time constant, so every access is a ds_read_b32 / ds_write_b32 with an
+// immediate offset: no address arithmetic, no flat-address lookup, conflict-free banks.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) uint32_t zkv_lds_u32;
+#else
+typedef uint32_t zkv_lds_u32;
+#endif
+struct LRef {
+    zkv_lds_u32* p;
+    ZKV_HD uint32_t ld(int k) const { return p[k * 64]; }
+    ZKV_HD void st(int k, uint32_t v) const { p[k * 64] = v; }
+#if defined(ZKV_PAIRED)
+    ZKV_HD int fw() const { return 8; }
+#else
+    ZKV_HD int fw() const { return 16; }
+#endif
+};
+ZKV_HD LRef l_ref(uint32_t* lds_base_plus_lane) { LRef r; r.p = (zkv_lds_u32*)lds_base_plus_lane; return r; }
+
+template <class R> ZKV_HD Fp m_ld_fp(R m, int word0) {
     Fp r;
 #pragma unroll
-    for (int k = 0; k < 8; k++) r.v[k] = m.p[(size_t)(word0 + k) * m.stride];
+    for (int k = 0; k < 8; k++) r.v[k] = m.ld(word0 + k);
     return r;
 }
-ZKV_HD void m_st_fp(MRef m, int word0, const Fp& a) {
+template <class R> ZKV_HD void m_st_fp(R m, int word0, const Fp& a) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) m.p[(size_t)(word0 + k) * m.stride] = a.v[k];
+    for (int k = 0; k < 8; k++) m.st(word0 + k, a.v[k]);
 }
 #if defined(ZKV_PAIRED)
-ZKV_HD Fp2 m_ld_f2(MRef m, int idx) { Fp2 r; r.h = m_ld_fp(m, (int)m.f2w * idx); return r; }
-ZKV_HD void m_st_f2(MRef m, int idx, const Fp2& a) { m_st_fp(m, (int)m.f2w * idx, a.h); }
+template <class R> ZKV_HD Fp2 m_ld_f2(R m, int idx) { Fp2 r; r.h = m_ld_fp(m, m.fw() * idx); return r; }
+template <class R> ZKV_HD void m_st_f2(R m, int idx, const Fp2& a) { m_st_fp(m, m.fw() * idx, a.h); }
 #else
-ZKV_HD Fp2 m_ld_f2(MRef m, int idx) { Fp2 r; r.c0 = m_ld_fp(m, 16 * idx); r.c1 = m_ld_fp(m, 16 * idx + 8); return r; }
-ZKV_HD void m_st_f2(MRef m, int idx, const Fp2& a) { m_st_fp(m, 16 * idx, a.c0); m_st_fp(m, 16 * idx + 8, a.c1); }
+template <class R> ZKV_HD Fp2 m_ld_f2(R m, int idx) { Fp2 r; r.c0 = m_ld_fp(m, 16 * idx); r.c1 = m_ld_fp(m, 16 * idx + 8); return r; }
+template <class R> ZKV_HD void m_st_f2(R m, int idx, const Fp2& a) { m_st_fp(m, 16 * idx, a.c0); m_st_fp(m, 16 * idx + 8, a.c1); }
 #endif
-ZKV_HD Fp6 m_ld_f6(MRef m, int idx) { Fp6 r; r.c0 = m_ld_f2(m, idx); r.c1 = m_ld_f2(m, idx + 1); r.c2 = m_ld_f2(m, idx + 2); return r; }
-ZKV_HD void m_st_f6(MRef m, int idx, const Fp6& a) { m_st_f2(m, idx, a.c0); m_st_f2(m, idx + 1, a.c1); m_st_f2(m, idx + 2, a.c2); }
+template <class R> ZKV_HD Fp6 m_ld_f6(R m, int idx) { Fp6 r; r.c0 = m_ld_f2(m, idx); r.c1 = m_ld_f2(m, idx + 1); r.c2 = m_ld_f2(m, idx + 2); return r; }
+template <class R> ZKV_HD void m_st_f6(R m, int idx, const Fp6& a) { m_st_f2(m, idx, a.c0); m_st_f2(m, idx + 1, a.c1); m_st_f2(m, idx + 2, a.c2); }
 // An Fp12 slot is six Fp2 coefficients g0 g1 g2 h0 h1 h2.
-ZKV_HD void f12m_copy(MRef d, MRef a) {
+template <class RD, class RA> ZKV_HD void f12m_copy(RD d, RA a) {
 #pragma unroll 1
     for (int k = 0; k < 6; k++) m_st_f2(d, k, m_ld_f2(a, k));
 }
-ZKV_HD void f12m_set_one(MRef d) {
+template <class RD> ZKV_HD void f12m_set_one(RD d) {
     m_st_f2(d, 0, f2_one());
 #pragma unroll 1
     for (int k = 1; k < 6; k++) m_st_f2(d, k, f2_zero());
 }
-ZKV_HD void f12m_conj(MRef d) {            // in place: negate h
+template <class RD> ZKV_HD void f12m_conj(RD d) {            // in place: negate h
 #pragma unroll 1
     for (int k = 3; k < 6; k++) m_st_f2(d, k, f2_neg(m_ld_f2(d, k)));
 }
-ZKV_HD bool f12m_is_one(MRef a) {
+template <class RA> ZKV_HD bool f12m_is_one(RA a) {
     bool ok = f2_eq(m_ld_f2(a, 0), f2_one());
 #pragma unroll 1
     for (int k = 1; k < 6; k++) ok = f2_is_zero(m_ld_f2(a, k)) && ok;
@@ -59,7 +85,7 @@ ZKV_HD bool f12m_is_one(MRef a) {
 }
 
 // f <- f^2 (complex squaring, 12 Fp2 products)
-ZKV_HD_NI void f12m_sqr(MRef f) {
+template <class RF> ZKV_HD_NI void f12m_sqr(RF f) {
     Fp6 g = m_ld_f6(f, 0), h = m_ld_f6(f, 3);
     Fp6 t = f6_mul(g, h);
     Fp6 s = f6_mul(f6_add(g, h), f6_add(g, f6_mul_v(h)));
@@ -73,7 +99,7 @@ ZKV_HD void fp4_sqr(const Fp2& a, const Fp2& b, Fp2& t0, Fp2& t1) {     // (a + 
     t0 = f2_sub(f2_sub(f2_mul(f2_add(a, b), f2_add(f2_mul_xi(b), a)), tmp), f2_mul_xi(tmp));
     t1 = f2_dbl(tmp);
 }
-ZKV_HD_NI void f12m_cyclo_sqr(MRef f) {
+template <class RF> ZKV_HD_NI void f12m_cyclo_sqr(RF f) {
     // memory order g0 g1 g2 h0 h1 h2; pairs (g0,h1), (h0,g2), (g1,h2)
     Fp2 z0 = m_ld_f2(f, 0), z1 = m_ld_f2(f, 4), t0, t1;
     fp4_sqr(z0, z1, t0, t1);
@@ -92,7 +118,7 @@ ZKV_HD_NI void f12m_cyclo_sqr(MRef f) {
     m_st_f2(f, 3, z2); m_st_f2(f, 2, z3); m_st_f2(f, 1, z4); m_st_f2(f, 5, z5);
 }
 // d <- a * b (d may alias a or b)
-ZKV_HD_NI void f12m_mul(MRef d, MRef a, MRef b) {
+template <class RD, class RA, class RB> ZKV_HD_NI void f12m_mul(RD d, RA a, RB b) {
     Fp6 ag = m_ld_f6(a, 0), bg = m_ld_f6(b, 0);
     Fp6 t0 = f6_mul(ag, bg);
     Fp6 ah = m_ld_f6(a, 3), bh = m_ld_f6(b, 3);
@@ -102,7 +128,7 @@ ZKV_HD_NI void f12m_mul(MRef d, MRef a, MRef b) {
     m_st_f6(d, 0, f6_add(t0, f6_mul_v(t1)));
 }
 // d <- a * conj(b)  (conj(b) = b^-1 for b in the cyclotomic subgroup)
-ZKV_HD_NI void f12m_mul_conj(MRef d, MRef a, MRef b) {
+template <class RD, class RA, class RB> ZKV_HD_NI void f12m_mul_conj(RD d, RA a, RB b) {
     Fp6 ag = m_ld_f6(a, 0), bg = m_ld_f6(b, 0);
     Fp6 t0 = f6_mul(ag, bg);
     Fp6 ah = m_ld_f6(a, 3), bh = f6_neg(m_ld_f6(b, 3));
@@ -112,7 +138,7 @@ ZKV_HD_NI void f12m_mul_conj(MRef d, MRef a, MRef b) {
     m_st_f6(d, 0, f6_add(t0, f6_mul_v(t1)));
 }
 // f <- f * (c0 + (c3 + c4 v) w)
-ZKV_HD_NI void f12m_mul_by_034(MRef f, const Fp2* c0, const Fp2* c3, const Fp2* c4) {
+template <class RF> ZKV_HD_NI void f12m_mul_by_034(RF f, const Fp2* c0, const Fp2* c3, const Fp2* c4) {
     Fp6 g = m_ld_f6(f, 0), h = m_ld_f6(f, 3);
     Fp6 t0 = f6_mul_fp2(g, *c0);
     Fp6 t1 = f6_mul_by_01(h, *c3, *c4);
@@ -121,7 +147,7 @@ ZKV_HD_NI void f12m_mul_by_034(MRef f, const Fp2* c0, const Fp2* c3, const Fp2* 
     m_st_f6(f, 0, f6_add(t0, f6_mul_v(t1)));
 }
 // f <- f * (1 + (c3 + c4 v) w)
-ZKV_HD_NI void f12m_mul_by_134(MRef f, const Fp2* c3, const Fp2* c4) {
+template <class RF> ZKV_HD_NI void f12m_mul_by_134(RF f, const Fp2* c3, const Fp2* c4) {
     Fp6 g = m_ld_f6(f, 0), h = m_ld_f6(f, 3);
     Fp6 hs = f6_mul_by_01(h, *c3, *c4);
     Fp6 gs = f6_mul_by_01(g, *c3, *c4);
@@ -129,7 +155,7 @@ ZKV_HD_NI void f12m_mul_by_134(MRef f, const Fp2* c3, const Fp2* c4) {
     m_st_f6(f, 3, f6_add(h, gs));
 }
 // d <- a^-1
-ZKV_HD_NI void f12m_inv(MRef d, MRef a) {
+template <class RD, class RA> ZKV_HD_NI void f12m_inv(RD d, RA a) {
     Fp6 g = m_ld_f6(a, 0), h = m_ld_f6(a, 3);
     Fp6 t = f6_sub(f6_mul(g, g), f6_mul_v(f6_mul(h, h)));
     t = f6_inv(t);
@@ -137,7 +163,7 @@ ZKV_HD_NI void f12m_inv(MRef d, MRef a) {
     m_st_f6(d, 3, f6_neg(f6_mul(h, t)));
 }
 // d <- pi^k(a), k = 1, 2, 3 (d may alias a)
-ZKV_HD_NI void f12m_frob(MRef d, MRef a, int k) {
+template <class RD, class RA> ZKV_HD_NI void f12m_frob(RD d, RA a, int k) {
     const Fp2C G1[6] = ZKV_FROB1;
     const Fp G2[6] = ZKV_FROB2;
     const Fp2C G3[6] = ZKV_FROB3;
@@ -157,12 +183,12 @@ ZKV_HD_NI void f12m_frob(MRef d, MRef a, int k) {
 }
 
 // T <- 2T with tangent-line coefficients (T is 3 Fp2 in memory)
-ZKV_HD_NI void g2m_line_dbl(MRef Tm, Fp2* l0, Fp2* l1, Fp2* l3) {
+template <class RT> ZKV_HD_NI void g2m_line_dbl(RT Tm, Fp2* l0, Fp2* l1, Fp2* l3) {
     G2H T; T.x = m_ld_f2(Tm, 0); T.y = m_ld_f2(Tm, 1); T.z = m_ld_f2(Tm, 2);
     line_dbl(T, *l0, *l1, *l3);
     m_st_f2(Tm, 0, T.x); m_st_f2(Tm, 1, T.y); m_st_f2(Tm, 2, T.z);
 }
-ZKV_HD_NI void g2m_line_add(MRef Tm, const Fp2* qx, const Fp2* qy, Fp2* l0, Fp2* l1, Fp2* l3) {
+template <class RT> ZKV_HD_NI void g2m_line_add(RT Tm, const Fp2* qx, const Fp2* qy, Fp2* l0, Fp2* l1, Fp2* l3) {
     G2H T; T.x = m_ld_f2(Tm, 0); T.y = m_ld_f2(Tm, 1); T.z = m_ld_f2(Tm, 2);
     line_add(T, *qx, *qy, *l0, *l1, *l3);
     m_st_f2(Tm, 0, T.x); m_st_f2(Tm, 1, T.y); m_st_f2(Tm, 2, T.z);

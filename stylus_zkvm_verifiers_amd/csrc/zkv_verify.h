@@ -182,16 +182,17 @@ ZKV_HD void msm_normalize(const VkTables& vk, const PrepOut& in, uint32_t& flags
 // Shared-accumulator Miller loop over (A',B) [variable Q, projective], (L,gamma), (C,delta) [fixed Q,
 // precomputed slope lines]; multiplied by the precomputed Miller value of (alpha, beta).
 // fm: the Fp12 accumulator slot, tm: the 3 x Fp2 running point T (both LDS on the device).
-ZKV_HD void fixed_line_mul(MRef fm, const LineAffC& L, const Fp& xs, const Fp& ys) {
+template <class RF> ZKV_HD void fixed_line_mul(RF fm, const LineAffC& L, const Fp& xs, const Fp& ys) {
     Fp2 c3 = f2_mul_fp(f2_const(L.nl), xs), c4 = f2_mul_fp(f2_const(L.c), ys);
     f12m_mul_by_134(fm, &c3, &c4);
 }
-ZKV_HD void var_line_mul(MRef fm, const Fp2& l0, const Fp2& l1, const Fp2& l3, const Fp& xs, const Fp& ys) {
+template <class RF> ZKV_HD void var_line_mul(RF fm, const Fp2& l0, const Fp2& l1, const Fp2& l3, const Fp& xs, const Fp& ys) {
     Fp2 c3 = f2_mul_fp(l1, xs), c4 = f2_mul_fp(l3, ys);
     f12m_mul_by_034(fm, &l0, &c3, &c4);
 }
+template <class RF, class RT>
 ZKV_HD void miller_loop_m(const VkTables& vk, uint32_t flags, const G1Norm& n, const Fp2& bx, const Fp2& by,
-                          bool with_fixed, MRef fm, MRef tm) {
+                          bool with_fixed, RF fm, RT tm) {
     bool do_ab = !(flags & (FL_A_INF | FL_B_INF));
     bool do_l = with_fixed && !(flags & FL_L_INF), do_c = with_fixed && !(flags & FL_C_INF);
     f12m_set_one(fm);
@@ -244,7 +245,7 @@ ZKV_HD int8_t u_naf(int i) {
     const int8_t NAF[ZKV_U_NAF_LEN] = ZKV_U_NAF;
     return NAF[i];
 }
-ZKV_HD void exp_u_m(MRef acc, MRef x) {
+template <class RA, class RX> ZKV_HD void exp_u_m(RA acc, RX x) {
     f12m_copy(acc, x);
 #pragma unroll 1
     for (int i = ZKV_U_NAF_LEN - 2; i >= 0; i--) {
@@ -257,7 +258,7 @@ ZKV_HD void exp_u_m(MRef acc, MRef x) {
 // f^(k (p^12-1)/r) == 1 with k = 2u(6u^2+3u+1), gcd(k, r) = 1  (Fuentes-Castaneda hard part; the chain is
 // checked symbolically in tests).  F holds the Miller value on entry (clobbered); E, Y1, Y3, Y4 are scratch
 // slots; acc is the hot accumulator (LDS on the device).
-ZKV_HD bool final_exp_is_one_m(MRef F, MRef E, MRef Y1, MRef Y3, MRef Y4, MRef acc) {
+template <class RA> ZKV_HD bool final_exp_is_one_m(MRef F, MRef E, MRef Y1, MRef Y3, MRef Y4, RA acc) {
     f12m_copy(acc, F); f12m_conj(acc);
     f12m_inv(F, F);
     f12m_mul(acc, acc, F);                  // f^(p^6-1)
