@@ -148,19 +148,24 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='risc0_2p16', choices=list(SEEDS))
-    ap.add_argument('--n', type=int, default=0, help='override proofs per GPU')
+    ap.add_argument('--proofs', dest='n', type=int, default=0, help='override proofs per GPU')
     ap.add_argument('--mutate-every', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--rehearse-single-gpu', action='store_true',
+                    help='multi-process rehearsal on a one-GPU box: every rank uses cuda:0 and the collectives run over gloo on host tensors')
     args = ap.parse_args()
 
     from stylus_zkvm_verifiers_amd import parallel
-    rank, local_rank, world = parallel.init_distributed()
+    rank, local_rank, world = parallel.init_distributed('gloo' if args.rehearse_single_gpu else None)
     assert world == args.gpus, 'launch one process per GPU (WORLD_SIZE=%d, --gpus %d)' % (world, args.gpus)
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)')
+    if args.rehearse_single_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    cdev = torch.device('cpu') if args.rehearse_single_gpu else dev          # where the collectives' tensors live
     g = golden()
     seed = SEEDS[args.workload] + 0x1000 * rank
     if args.workload == 'risc0_2p16':
@@ -196,7 +201,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -206,7 +211,7 @@ def main():
         st = s.d_status.cpu().numpy()
         ok_counts.append(int((st == 0).sum()))
         parity &= bool(((st == 0) == ~s.mutated).all())
-    flag = torch.tensor([1 if parity else 0], dtype=torch.int32, device=dev)
+    flag = torch.tensor([1 if parity else 0], dtype=torch.int32, device=cdev)
     if world > 1:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     parity_all = bool(flag.item())
