@@ -118,6 +118,13 @@ int zkv_bn254_ecmul_batch(zkv_ctx* ctx, size_t n, const uint8_t* in, uint8_t* ou
  * of the k pairings is 1 (the precompile's 32-byte output word), meaningful when ok[i] = 1. */
 int zkv_bn254_pairing_batch(zkv_ctx* ctx, size_t n, size_t k, const uint8_t* in, uint8_t* result, uint8_t* ok);
 
+/* ------------------------------------------------------------------ Groth16 core pieces
+ * Groth16Verifier::compute_vk_x (common/groth16.rs:51-58) for a batch: vk_x = IC[0] + sum s_i IC[i+1] with the context's
+ * fixed signals (RISC Zero: control root halves and bn254 control id) and the two per-proof signals given here as
+ * n x 2 x 32 big-endian bytes (RISC Zero: claim digest low / high halves; SP1: program vkey, public-values hash).
+ * Signals must be < R (the reference rejects the proof before this step otherwise).  out: n x 64 bytes (x, y), (0,0) = infinity. */
+int zkv_ctx_vk_x_batch(zkv_ctx* ctx, size_t n, const uint8_t* var_signals, uint8_t* out);
+
 /* ------------------------------------------------------------------ shared */
 int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_RISC0 / ZKV_VM_SP1 */
 /* Tuning knob (no reference counterpart): kernel mapping of the G2 / Miller / final-exponentiation stages.

@@ -39,6 +39,7 @@ SYMBOLS = {
     'zkv_bn254_ecadd_batch': (_i, [_vp, _sz, _vp, _vp, _vp]),
     'zkv_bn254_ecmul_batch': (_i, [_vp, _sz, _vp, _vp, _vp]),
     'zkv_bn254_pairing_batch': (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
+    'zkv_ctx_vk_x_batch': (_i, [_vp, _sz, _vp, _vp]),
     'zkv_ctx_vm': (_i, [_vp]),
     'zkv_ctx_set_lanes_per_proof': (_i, [_vp, _i]),
     'zkv_ctx_synchronize': (_i, [_vp]),

@@ -25,6 +25,33 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_msm(size_t n, const VkTables* __r
     ws.flags[i] = flags;
 }
 
+// compute_vk_x alone (zkv_ctx_vk_x_batch): same tables and window walk as k_msm, affine result as 64 big-endian bytes.
+__global__ __launch_bounds__(ZKV_BLOCK) void k_vk_x(size_t n, const VkTables* __restrict__ vk, const uint8_t* __restrict__ sig, uint8_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    PrepOut in;
+    load_be256(in.s[0], sig + 64 * i); load_be256(in.s[1], sig + 64 * i + 32);
+    G1J acc = msm_accumulate(*vk, in);
+    G1A a; uint32_t inf;
+    g1j_to_affine(acc, a, inf);
+    uint32_t r[8];
+    uint8_t* o = out + 64 * i;
+#pragma unroll 1
+    for (int c = 0; c < 2; c++) {
+        fp_to_raw(r, c ? a.y : a.x);
+#pragma unroll 1
+        for (int k = 0; k < 8; k++) {
+            uint32_t v = r[7 - k];
+            o[32 * c + 4 * k] = (uint8_t)(v >> 24); o[32 * c + 4 * k + 1] = (uint8_t)(v >> 16);
+            o[32 * c + 4 * k + 2] = (uint8_t)(v >> 8); o[32 * c + 4 * k + 3] = (uint8_t)v;
+        }
+    }
+}
+void launch_vk_x(size_t n, const VkTables* d_tab, const uint8_t* sig, uint8_t* out, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_vk_x, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, d_tab, sig, out);
+}
+
 void launch_msm(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_msm, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, d_tab, ws);

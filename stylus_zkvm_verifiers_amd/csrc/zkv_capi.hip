@@ -382,6 +382,29 @@ ZKV_EXPORT int zkv_bn254_pairing_batch(zkv_ctx* c, size_t n, size_t k, const uin
     return run_precompile(c, 2, n, k, k ? in : &dummy, result, ok);
 }
 
+// ------------------------------------------------------------------ Groth16 core pieces
+ZKV_EXPORT int zkv_ctx_vk_x_batch(zkv_ctx* c, size_t n, const uint8_t* var_signals, uint8_t* out) {
+    if (!c || c->vm == ZKV_VM_BN254) return ZKV_ERR_WRONG_CTX;
+    if (c->vm == ZKV_VM_RISC0 && !c->initialized) return ZKV_ERR_INVALID_ARG;
+    if (n && (!var_signals || !out)) return ZKV_ERR_INVALID_ARG;
+    if (!n) return ZKV_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ctx_device_init(c);
+    if (rc != ZKV_OK) return rc;
+    const size_t cap = c->ws.cap;
+    for (size_t base = 0; base < n; base += cap) {
+        size_t m = n - base < cap ? n - base : cap;
+        if ((rc = grow(&c->d_blob, &c->blob_cap, m * 64 + 8)) != ZKV_OK) return rc;
+        if ((rc = grow(&c->d_pv, &c->pv_cap, m * 64 + 8)) != ZKV_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_blob, var_signals + 64 * base, 64 * m, hipMemcpyHostToDevice, c->stream));
+        launch_vk_x(m, c->d_tab, c->d_blob, c->d_pv, c->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out + 64 * base, c->d_pv, 64 * m, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return ZKV_OK;
+}
+
 // ------------------------------------------------------------------ shared
 ZKV_EXPORT int zkv_ctx_vm(const zkv_ctx* c) { return c ? c->vm : ZKV_ERR_INVALID_ARG; }
 ZKV_EXPORT int zkv_ctx_set_lanes_per_proof(zkv_ctx* c, int lanes) {

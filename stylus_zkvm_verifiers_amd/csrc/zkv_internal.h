@@ -48,6 +48,7 @@ void launch_setup(const VkRaw* d_raw, VkTables* d_tab, hipStream_t s);
 void launch_prep_risc0(const PrepArgs& a, const Risc0Consts& k, const Workspace& ws, hipStream_t s);
 void launch_prep_sp1(const PrepArgs& a, const Workspace& ws, hipStream_t s);
 void launch_msm(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
+void launch_vk_x(size_t n, const VkTables* d_tab, const uint8_t* sig, uint8_t* out, hipStream_t s);
 void launch_g2chk(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
 void launch_miller(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
 void launch_finalexp(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);

@@ -145,7 +145,7 @@ ZKV_HD void risc0_split_digest(const uint32_t h[8], uint32_t lo[8], uint32_t hi[
 
 // ---------------------------------------------------------------- stage MSM + G1 normalisation
 // vk_x = base + sum_b s_b * IC_var[b] (groth16.rs:51-58), then x/y and 1/y of A', L, C with one inversion.
-ZKV_HD void msm_normalize(const VkTables& vk, const PrepOut& in, uint32_t& flags, G1Norm& out) {
+ZKV_HD G1J msm_accumulate(const VkTables& vk, const PrepOut& in) {
     G1J acc;
     if (vk.base_inf) acc = g1j_infinity();
     else { acc.x = vk.base.x; acc.y = vk.base.y; acc.z = fp_one(); }
@@ -160,6 +160,10 @@ ZKV_HD void msm_normalize(const VkTables& vk, const PrepOut& in, uint32_t& flags
             }
         }
     }
+    return acc;
+}
+ZKV_HD void msm_normalize(const VkTables& vk, const PrepOut& in, uint32_t& flags, G1Norm& out) {
+    G1J acc = msm_accumulate(vk, in);
     Fp one = fp_one();
     bool linf = fp_is_zero(acc.z), ainf = (flags & FL_A_INF) != 0, cinf = (flags & FL_C_INF) != 0;
     if (linf) flags |= FL_L_INF;

@@ -55,6 +55,15 @@ class Sp1Verifier:
         _lib.check(self._L.zkv_sp1_verify_batch_dev(self._h, n, d_vkeys, d_public_values, pv_len, d_proofs, d_status,
                                                     d_recv or None, stream or None), 'zkv_sp1_verify_batch_dev')
 
+    def vk_x_batch(self, var_signals):
+        """Groth16Verifier::compute_vk_x (common/groth16.rs:51-58) for a batch: var_signals = list of (s_a, s_b) 32-byte pairs
+        (the two per-proof signals); returns 64-byte affine points."""
+        n = len(var_signals)
+        blob = b''.join(bytes(a) + bytes(b) for a, b in var_signals) + b'\0'
+        out = np.zeros(max(64 * n, 1), dtype=np.uint8)
+        _lib.check(self._L.zkv_ctx_vk_x_batch(self._h, n, blob, out.ctypes.data), 'zkv_ctx_vk_x_batch')
+        return [out[64 * i:64 * i + 64].tobytes() for i in range(n)]
+
     def set_lanes_per_proof(self, lanes):
         """Kernel mapping of the Fp2-heavy stages: 2 = lane pairs (default), 1 = one proof per lane; same results."""
         _lib.check(self._L.zkv_ctx_set_lanes_per_proof(self._h, lanes), 'zkv_ctx_set_lanes_per_proof')

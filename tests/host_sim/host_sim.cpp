@@ -84,6 +84,19 @@ const void* hs_prepare(int vm, const uint8_t* cr, const uint8_t* cid, const uint
     memcpy(b32, p.bx.c0.v, 32); memcpy(b32 + 8, p.bx.c1.v, 32); memcpy(b32 + 16, p.by.c0.v, 32); memcpy(b32 + 24, p.by.c1.v, 32);
     return t;
 }
+// compute_vk_x through the windowed fixed-base tables (the k_msm / k_vk_x code), affine result as 64 big-endian bytes
+void hs_vk_x(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* s0, const uint8_t* s1, uint8_t* out64) {
+    VkTables* t = tables(vm, cr, cid);
+    PrepOut p; memset(&p, 0, sizeof p);
+    load_be256(p.s[0], s0); load_be256(p.s[1], s1);
+    G1J acc = msm_accumulate(*t, p);
+    G1A a; uint32_t inf; g1j_to_affine(acc, a, inf);
+    uint32_t r[8];
+    for (int c = 0; c < 2; c++) {
+        fp_to_raw(r, c ? a.y : a.x);
+        for (int i = 0; i < 8; i++) for (int k = 0; k < 4; k++) out64[32 * c + 31 - 4 * i - k] = r[i] >> (8 * k);
+    }
+}
 void hs_risc0_scalars(const uint8_t* image_id, const uint8_t* journal, uint8_t* digest32, uint8_t* lo32, uint8_t* hi32) {
     Risc0Consts k; host::risc0_consts(k);
     uint32_t h[8], lo[8], hi[8];

@@ -218,3 +218,23 @@ def test_both_kernel_mappings_agree_on_a_2p13_batch(zkv, real_proofs):
     orc = ol.Risc0Oracle(); orc.initialize(H(r['control_root']), H(r['bn254_control_id']))
     ost, _ = orc.verify_batch([x.tobytes() for x in seals[:k]], [x.tobytes() for x in ids[:k]], [x.tobytes() for x in jds[:k]], threads=8)
     assert (out[2][:k] == ost).all()
+
+
+def test_vk_x_batch_matches_oracle(zkv, r0, sp1, real_proofs):
+    """compute_vk_x on the GPU (windowed fixed-base tables built by the set-up kernels) against the oracle's ecMul/ecAdd chain
+    for random and edge-case signals -- the valid proofs of the corpus all share one set of public inputs."""
+    import random
+    import oracle_lib as ol
+    import spec_model as m
+    r = real_proofs['risc0']
+    fixed = [H(x) for x in r['signals']]
+    rng = random.Random(12)
+    pairs = [(0, 0), (1, 0), (0, 1), ((1 << 128) - 1, (1 << 128) - 1), (15, 1 << 124)] + [(rng.randrange(1 << 128), rng.randrange(1 << 128)) for _ in range(120)]
+    got = r0.vk_x_batch([(m.be32(a), m.be32(b)) for a, b in pairs])
+    for (a, b), g in zip(pairs, got):
+        assert g == ol.groth16_vk_x(0, [fixed[0], fixed[1], m.be32(a), m.be32(b), fixed[4]]), (hex(a), hex(b))
+    assert got[len(pairs) - 1] != got[0]
+    pairs = [(0, 0), (1, 1), (m.R - 1, m.R - 1), (m.R - 1, 0), (1 << 252, (1 << 253) - 1)] + [(rng.randrange(m.R), rng.randrange(1 << 253)) for _ in range(120)]
+    got = sp1.vk_x_batch([(m.be32(a), m.be32(b)) for a, b in pairs])
+    for (a, b), g in zip(pairs, got):
+        assert g == ol.groth16_vk_x(1, [m.be32(a), m.be32(b)]), (hex(a), hex(b))

@@ -115,3 +115,26 @@ def test_lane_pair_kernels_on_corpus(hs, hs_pair, verify_corpus, real_proofs):
         assert acc == (1 if c['status'] == 0 else 0), c['name']
         n += 1
     assert n > 40
+
+
+def test_windowed_vk_x_matches_oracle_on_random_signals(hs, real_proofs):
+    """compute_vk_x (groth16.rs:51-58): the fixed-base window tables and the window walk of k_msm against the oracle's
+    ecMul/ecAdd chain for random and edge-case per-proof signals, both verification keys."""
+    import oracle_lib as ol
+    r = real_proofs['risc0']
+    cr, cid = H(r['control_root']), H(r['bn254_control_id'])
+    fixed = [H(x) for x in r['signals']]
+    rng = random.Random(11)
+    cases = [(0, 0), (1, 0), (0, 1), ((1 << 128) - 1, (1 << 128) - 1), (15, 1 << 124), (0x1111111111111111, 0xf0f0f0f0f0f0f0f0)]
+    cases += [(rng.randrange(1 << 128), rng.randrange(1 << 128)) for _ in range(20)]
+    for a, b in cases:
+        out = C.create_string_buffer(64)
+        hs.hs_vk_x(0, cr, cid, m.be32(a), m.be32(b), out)
+        sig = [fixed[0], fixed[1], m.be32(a), m.be32(b), fixed[4]]
+        assert out.raw == ol.groth16_vk_x(0, sig), (hex(a), hex(b))
+    cases = [(0, 0), (1, 1), (m.R - 1, m.R - 1), (m.R - 1, 0), (1 << 252, (1 << 253) - 1)]
+    cases += [(rng.randrange(m.R), rng.randrange(1 << 253)) for _ in range(20)]
+    for a, b in cases:
+        out = C.create_string_buffer(64)
+        hs.hs_vk_x(1, None, None, m.be32(a), m.be32(b), out)
+        assert out.raw == ol.groth16_vk_x(1, [m.be32(a), m.be32(b)]), (hex(a), hex(b))
