@@ -118,6 +118,18 @@ int zkv_bn254_ecmul_batch(zkv_ctx* ctx, size_t n, const uint8_t* in, uint8_t* ou
  * of the k pairings is 1 (the precompile's 32-byte output word), meaningful when ok[i] = 1. */
 int zkv_bn254_pairing_batch(zkv_ctx* ctx, size_t n, size_t k, const uint8_t* in, uint8_t* result, uint8_t* ok);
 
+/* ------------------------------------------------------------------ Groth16 core, arbitrary verification key
+ * Groth16Verifier::verify_proof_with_key(vm_type, &vk, a, b, c, &signals) -> bool (common/groth16.rs:23-49) is generic over the
+ * key; this context takes any key.  vk_words: alpha1.x alpha1.y | beta2.x[0] x[1] y[0] y[1] | gamma2 (4) | delta2 (4) |
+ * ic[0].x ic[0].y ... ic[n_ic-1] -- 32-byte big-endian words in the layout of `VerificationKey` (common/types.rs:17-23; G2 words
+ * are (imaginary, real)), 1 <= n_ic <= 6.  vm_type: ZKV_VM_RISC0 negates A, ZKV_VM_SP1 does not (groth16.rs:96-103).
+ * A key holding a point the precompiles would reject makes every proof fail, as in the reference. */
+#define ZKV_VM_GROTH16 3
+zkv_ctx* zkv_groth16_ctx_create(const uint8_t* vk_words, size_t n_ic, int vm_type, int device);
+/* proofs: n x 256 bytes (a.x a.y b.x[0] b.x[1] b.y[0] b.y[1] c.x c.y); signals: n x (n_ic - 1) x 32 bytes big-endian;
+ * verified[i] = 1 / 0 is the function's return value (signal >= R, malformed point, pairing product != 1 -> 0). */
+int zkv_groth16_verify_batch(zkv_ctx* ctx, size_t n, const uint8_t* proofs, const uint8_t* signals, uint8_t* verified);
+
 /* ------------------------------------------------------------------ Groth16 core pieces
  * Groth16Verifier::compute_vk_x (common/groth16.rs:51-58) for a batch: vk_x = IC[0] + sum s_i IC[i+1] with the context's
  * fixed signals (RISC Zero: control root halves and bn254 control id) and the two per-proof signals given here as

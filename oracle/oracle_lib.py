@@ -46,6 +46,7 @@ def lib():
         L.zkvo_sp1_verifier_hash.argtypes = [C.c_char_p]
         L.zkvo_sp1_version.restype = C.c_char_p
         L.zkvo_groth16_vk_x.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_char_p]
+        L.zkvo_groth16_verify_vk.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
         L.zkvo_status_abi_encode.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
         L.zkvo_count_enable.argtypes = [C.c_int]
         L.zkvo_count_read.restype = C.c_uint64
@@ -162,6 +163,11 @@ def groth16_vk_x(vm, signals):
     o = _buf(64)
     ok = lib().zkvo_groth16_vk_x(vm, b''.join(signals), len(signals), o)
     return o.raw if ok else None
+
+
+def groth16_verify_vk(vm, vk_words, n_ic, proof_words, signals):
+    """verify_proof_with_key for an arbitrary key: vk_words bytes, proof_words 256 bytes, signals list of 32-byte values."""
+    return bool(lib().zkvo_groth16_verify_vk(vm, bytes(vk_words), n_ic, bytes(proof_words), b''.join(signals) + b'\0', len(signals)))
 
 
 def status_abi_encode(vm, status, recv, exp):

@@ -515,3 +515,53 @@ def rerandomize(a, b, c, delta2, r1, r2):
 def seal_bytes(selector, a, b, c):
     (bxr, bxi), (byr, byi) = b
     return selector + b''.join(be32(v) for v in (a[0], a[1], bxi, bxr, byi, byr, c[0], c[1]))
+
+
+# ---------------------------------------------------------------- trapdoor keys: valid proofs for ARBITRARY public inputs (tests only)
+G1_GEN = (1, 2)
+G2_GEN = vk_g2_point(RISC0_VK['gamma2'])           # the canonical BN254 G2 generator
+
+
+def g2_words(pt):
+    """affine ((re,im),(re,im)) or None -> the reference's G2Point words (x_im, x_re), (y_im, y_re)."""
+    if pt is None:
+        return ((0, 0), (0, 0))
+    (xr, xi), (yr, yi) = pt
+    return ((xi, xr), (yi, yr))
+
+
+def trapdoor_vk(rng, n_ic):
+    """A verification key whose discrete logs are known: returns (vk dict in the reference's layout, trapdoor)."""
+    td = dict(alpha=rng.randrange(1, R), beta=rng.randrange(1, R), gamma=rng.randrange(1, R), delta=rng.randrange(1, R),
+              ic=[rng.randrange(1, R) for _ in range(n_ic)])
+    vk = dict(alpha1=g1_mul(G1_GEN, td['alpha']), beta2=g2_words(g2_mul(G2_GEN, td['beta'])),
+              gamma2=g2_words(g2_mul(G2_GEN, td['gamma'])), delta2=g2_words(g2_mul(G2_GEN, td['delta'])),
+              ic=[g1_mul(G1_GEN, k) for k in td['ic']])
+    return vk, td
+
+
+def trapdoor_prove(rng, td, signals, vm_type):
+    """(a, b, c) in the seal's word layout satisfying the pairing equation of groth16.rs:86-107 for `signals`."""
+    ell = (td['ic'][0] + sum(s * k for s, k in zip(signals, td['ic'][1:]))) % R
+    a_s, b_s = rng.randrange(1, R), rng.randrange(1, R)
+    if vm_type == 'risc0':          # e(-A,B) e(alpha,beta) e(L,gamma) e(C,delta) = 1
+        c_s = (a_s * b_s - td['alpha'] * td['beta'] - ell * td['gamma']) * pow(td['delta'], -1, R) % R
+    else:                           # e(A,B) e(alpha,beta) e(L,gamma) e(C,delta) = 1
+        c_s = -(a_s * b_s + td['alpha'] * td['beta'] + ell * td['gamma']) * pow(td['delta'], -1, R) % R
+    A = g1_mul(G1_GEN, a_s); B = g2_words(g2_mul(G2_GEN, b_s)); Cc = g1_mul(G1_GEN, c_s)
+    Cw = Cc if Cc is not None else (0, 0)
+    return A, B, Cw
+
+
+def vk_to_words(vk):
+    """bytes in the order zkv_groth16_ctx_create / zkvo_groth16_verify_vk expect."""
+    out = be32(vk['alpha1'][0]) + be32(vk['alpha1'][1])
+    for q in (vk['beta2'], vk['gamma2'], vk['delta2']):
+        out += be32(q[0][0]) + be32(q[0][1]) + be32(q[1][0]) + be32(q[1][1])
+    for x, y in vk['ic']:
+        out += be32(x) + be32(y)
+    return out
+
+
+def proof_to_words(a, b, c):
+    return b''.join(be32(v) for v in (a[0], a[1], b[0][0], b[0][1], b[1][0], b[1][1], c[0], c[1]))

@@ -652,6 +652,37 @@ static int groth16_verify(int vm, const vk_hex *vk, const uint8_t *proof_words /
     for (int i = 0; i < 32; i++) if (out[i]) return 1;
     return 0;
 }
+/* Groth16Verifier::verify_proof_with_key for an ARBITRARY verification key (groth16.rs:23-49 is generic over `vk`).
+ * vk_words: alpha1.x alpha1.y | beta2 x[0] x[1] y[0] y[1] | gamma2 (4) | delta2 (4) | ic[i].x ic[i].y ..., 32-byte big-endian.
+ * vm: 0 = VMType::Risc0 (A negated), 1 = VMType::Sp1.  Returns the function's bool. */
+ZKVO_API int zkvo_groth16_verify_vk(int vm, const uint8_t *vk_words, int n_ic, const uint8_t *proof_words, const uint8_t *signals, int n_sig) {
+    if (n_sig + 1 != n_ic) return 0;
+    for (int i = 0; i < n_sig; i++) { uint64_t sv[4]; u256_from_be(sv, signals + 32 * i); if (u256_geq(sv, RM)) return 0; }
+    const uint8_t *ic = vk_words + 448;
+    uint8_t vkx[64], buf[128], mul[64];
+    memcpy(vkx, ic, 64);
+    for (int i = 0; i < n_sig; i++) {
+        memcpy(buf, ic + 64 * (i + 1), 64); memcpy(buf + 64, signals + 32 * i, 32);
+        if (!zkvo_ecmul(buf, 96, mul)) return 0;
+        memcpy(buf, vkx, 64); memcpy(buf + 64, mul, 64);
+        if (!zkvo_ecadd(buf, 128, vkx)) return 0;
+    }
+    uint8_t cd[768], a[64];
+    memcpy(a, proof_words, 64);
+    if (vm == 0) {
+        uint64_t x[4], y[4]; u256_from_be(x, a); u256_from_be(y, a + 32);
+        if (!(u256_is_zero(x) && u256_is_zero(y))) { uint64_t ny[4]; u256_sub(ny, PM, y); u256_to_be(a + 32, ny); }
+    }
+    uint8_t *p = cd;
+    memcpy(p, a, 64); memcpy(p + 64, proof_words + 64, 128); p += 192;
+    memcpy(p, vk_words, 64); memcpy(p + 64, vk_words + 64, 128); p += 192;
+    memcpy(p, vkx, 64); memcpy(p + 64, vk_words + 192, 128); p += 192;
+    memcpy(p, proof_words + 192, 64); memcpy(p + 64, vk_words + 320, 128);
+    uint8_t out[32];
+    if (!zkvo_ecpairing(cd, 768, out)) return 0;
+    for (int i = 0; i < 32; i++) if (out[i]) return 1;
+    return 0;
+}
 ZKVO_API int zkvo_groth16_vk_x(int vm, const uint8_t *signals, int n_sig, uint8_t out[64]) {
     const vk_hex *vk = vm == 0 ? &RISC0_VK : &SP1_VK;
     uint8_t buf[128], mul[64];

@@ -8,8 +8,9 @@ from .errors import VerifierError
 from .risc0 import RiscZeroVerifier
 from .sp1 import Sp1Verifier
 from .bn254 import Bn254Precompiles
+from .groth16 import Groth16Verifier
 
-__all__ = ['RiscZeroVerifier', 'Sp1Verifier', 'Bn254Precompiles', 'VerifierError', 'errors', 'device_count']
+__all__ = ['RiscZeroVerifier', 'Sp1Verifier', 'Bn254Precompiles', 'Groth16Verifier', 'VerifierError', 'errors', 'device_count']
 
 
 def device_count():

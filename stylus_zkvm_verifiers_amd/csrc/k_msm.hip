@@ -12,10 +12,10 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_msm(size_t n, const VkTables* __r
     PrepOut in;
     in.ax = ws_ld(ws.prep, ws.cap, 0, i); in.ay = ws_ld(ws.prep, ws.cap, 8, i);
     in.cx = ws_ld(ws.prep, ws.cap, 16, i); in.cy = ws_ld(ws.prep, ws.cap, 24, i);
+#pragma unroll 1
+    for (uint32_t b = 0; b < vk->n_var; b++) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        in.s[0][k] = ws.prep[(size_t)(64 + k) * ws.cap + i];
-        in.s[1][k] = ws.prep[(size_t)(72 + k) * ws.cap + i];
+        for (int k = 0; k < 8; k++) in.s[b][k] = ws.prep[(size_t)(64 + 8 * b + k) * ws.cap + i];
     }
     G1Norm o;
     msm_normalize(*vk, in, flags, o);

@@ -10,9 +10,9 @@ __device__ __forceinline__ void store_prep(const Workspace& ws, size_t i, const 
     ws_st(ws.prep, ws.cap, 32, i, o.bx.c0); ws_st(ws.prep, ws.cap, 40, i, o.bx.c1);
     ws_st(ws.prep, ws.cap, 48, i, o.by.c0); ws_st(ws.prep, ws.cap, 56, i, o.by.c1);
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        ws.prep[(size_t)(64 + k) * ws.cap + i] = o.s[0][k];
-        ws.prep[(size_t)(72 + k) * ws.cap + i] = o.s[1][k];
+    for (int b = 0; b < MAX_VAR; b++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) ws.prep[(size_t)(64 + 8 * b + k) * ws.cap + i] = o.s[b][k];
     }
 }
 
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_prep_risc0(PrepArgs a, Risc0Const
     uint32_t flags = 0;
     if (front_checks(a, i, staged, seal_lds, rd, st)) {
         PrepOut o;
+        for (int b = 2; b < MAX_VAR; b++) for (int k2 = 0; k2 < 8; k2++) o.s[b][k2] = 0;
         uint32_t h[8];
         if (a.in32_b) risc0_claim_digest(k, a.in32_a + 32 * i, a.in32_b + 32 * i, h);
         else {
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_prep_sp1(PrepArgs a, Workspace ws
     uint32_t flags = 0;
     if (front_checks(a, i, staged, seal_lds, rd, st)) {
         PrepOut o;
+        for (int b = 2; b < MAX_VAR; b++) for (int k2 = 0; k2 < 8; k2++) o.s[b][k2] = 0;
         load_be256(o.s[0], a.in32_a + 32 * i);                      // U256::from_be_bytes(program_vkey), sp1/types.rs:24
         const uint8_t* pv; size_t pvl;
         if (a.pv_off) { pv = a.pv_blob + a.pv_off[i]; pvl = (size_t)(a.pv_off[i + 1] - a.pv_off[i]); }
@@ -123,6 +125,36 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_prep_sp1(PrepArgs a, Workspace ws
     a.status[i] = st;
 }
 
+// Groth16Verifier::verify_proof_with_key for an arbitrary key (common/groth16.rs:23-49): 8 proof words + n_sig signals per
+// proof, no selector / hashing.  status 0 <=> the function returns true.
+__global__ __launch_bounds__(ZKV_BLOCK) void k_prep_groth16(PrepArgs a, Workspace ws) {
+    size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    uint32_t flags = 0;
+    if (!a.force_fail) {
+        PrepOut o;
+        bool ok = true;
+#pragma unroll 1
+        for (uint32_t b = 0; b < MAX_VAR; b++) {
+            if (b < a.n_sig) { load_be256(o.s[b], a.in32_a + 32 * ((size_t)a.n_sig * i + b)); ok = ok && raw_lt_r(o.s[b]); }   // groth16.rs:32
+            else for (int k = 0; k < 8; k++) o.s[b][k] = 0;
+        }
+        if (ok) {
+            uint32_t w[8][8];
+            const uint8_t* rec = a.blob + 256 * i;
+#pragma unroll 1
+            for (int j = 0; j < 8; j++) load_be256(w[j], rec + 32 * j);
+            if (prep_points(w, a.negate_a != 0, o)) { flags = o.flags; store_prep(ws, i, o); }
+        }
+    }
+    ws.flags[i] = flags;
+    a.status[i] = ST_VERIFICATION_FAILED;
+}
+
+void launch_prep_groth16(const PrepArgs& a, const Workspace& ws, hipStream_t s) {
+    if (!a.n) return;
+    hipLaunchKernelGGL(k_prep_groth16, dim3((unsigned)((a.n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, a, ws);
+}
 void launch_prep_risc0(const PrepArgs& a, const Risc0Consts& k, const Workspace& ws, hipStream_t s) {
     if (!a.n) return;
     hipLaunchKernelGGL(k_prep_risc0, dim3((unsigned)((a.n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, a, k, ws);

@@ -7,6 +7,10 @@ namespace zkv {
 __global__ __launch_bounds__(64) void k_setup_base(const VkRaw* __restrict__ raw, VkTables* __restrict__ t) {
     if (threadIdx.x == 0) setup_base(*raw, *t);
 }
+// precompile-input validity of every VK point (a generic key may be anything)
+__global__ __launch_bounds__(64) void k_setup_validate(const VkRaw* __restrict__ raw, VkTables* __restrict__ t) {
+    if (threadIdx.x == 0) setup_validate(*raw, *t);
+}
 // gamma / delta slope-line tables for the fixed-Q Miller loops
 __global__ __launch_bounds__(64) void k_setup_lines(const VkRaw* __restrict__ raw, VkTables* __restrict__ t) {
     if (threadIdx.x == 0) setup_lines(raw->gamma, t->lines[0]);
@@ -15,7 +19,7 @@ __global__ __launch_bounds__(64) void k_setup_lines(const VkRaw* __restrict__ ra
 // one lane per (scalar, window) row of the fixed-base MSM table
 __global__ __launch_bounds__(64) void k_setup_msm(const VkRaw* __restrict__ raw, VkTables* __restrict__ t) {
     int b = blockIdx.x, w = threadIdx.x;
-    if (w < (int)raw->var_windows[b]) setup_msm_row(*raw, *t, b, w);
+    if (b < (int)raw->n_var && w < (int)raw->var_windows[b]) setup_msm_row(*raw, *t, b, w);
 }
 // Miller value of (alpha, beta); f and T of the single lane live in LDS like in k_miller
 __global__ __launch_bounds__(64) void k_setup_alpha_beta(const VkRaw* __restrict__ raw, VkTables* __restrict__ t) {
@@ -27,9 +31,10 @@ __global__ __launch_bounds__(64) void k_setup_alpha_beta(const VkRaw* __restrict
 }
 
 void launch_setup(const VkRaw* d_raw, VkTables* d_tab, hipStream_t s) {
+    hipLaunchKernelGGL(k_setup_validate, dim3(1), dim3(64), 0, s, d_raw, d_tab);
     hipLaunchKernelGGL(k_setup_base, dim3(1), dim3(64), 0, s, d_raw, d_tab);
     hipLaunchKernelGGL(k_setup_lines, dim3(1), dim3(64), 0, s, d_raw, d_tab);
-    hipLaunchKernelGGL(k_setup_msm, dim3(2), dim3(64), 0, s, d_raw, d_tab);
+    hipLaunchKernelGGL(k_setup_msm, dim3(MAX_VAR), dim3(64), 0, s, d_raw, d_tab);
     hipLaunchKernelGGL(k_setup_alpha_beta, dim3(1), dim3(64), 0, s, d_raw, d_tab);
 }
 

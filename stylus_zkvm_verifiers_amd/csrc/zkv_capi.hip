@@ -21,6 +21,8 @@ struct zkv_ctx {
     bool initialized = false, id_ge_r = false;
     uint8_t control_root_0[16] = {0}, control_root_1[16] = {0}, control_id[32] = {0}, selector[4] = {0};
     Risc0Consts consts;
+    uint8_t gvk[448 + 64 * MAX_IC] = {0};    // ZKV_VM_GROTH16: the caller's verification key
+    uint32_t g_n_ic = 0; bool g_negate = false, vk_invalid = false;
     // device side (created lazily on the first compute call)
     bool dev_ready = false;
     hipStream_t stream = nullptr;
@@ -87,6 +89,7 @@ static int ctx_device_init(zkv_ctx* c) {
     if (c->vm != ZKV_VM_BN254) {
         VkRaw raw;
         if (c->vm == ZKV_VM_RISC0) host::fill_vk_risc0(raw, c->control_root_0, c->control_root_1, c->control_id);
+        else if (c->vm == ZKV_VM_GROTH16) host::fill_vk_generic(raw, c->gvk, c->g_n_ic);
         else host::fill_vk_sp1(raw);
         if (c->id_ge_r) memset(raw.fixed_scalar[5], 0, 32);      // never used: every proof fails the range check first
         VkRaw* d_raw = nullptr;
@@ -98,6 +101,9 @@ static int ctx_device_init(zkv_ctx* c) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));
         (void)hipFree(d_raw);
+        uint32_t valid = 0;
+        HIP_TRY(hipMemcpy(&valid, &c->d_tab->vk_valid, sizeof valid, hipMemcpyDeviceToHost));
+        c->vk_invalid = valid == 0;
     }
     size_t cap = chunk_capacity();
     c->ws.cap = cap;
@@ -130,7 +136,9 @@ static int grow(uint8_t** p, size_t* cap, size_t need) {
 // Enqueues the five stages for one chunk (all pointers device-resident).
 static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed) {
     if (timed) (void)hipEventRecord(c->ev[0], s);
-    if (c->vm == ZKV_VM_RISC0) launch_prep_risc0(a, c->consts, c->ws, s); else launch_prep_sp1(a, c->ws, s);
+    if (c->vm == ZKV_VM_RISC0) launch_prep_risc0(a, c->consts, c->ws, s);
+    else if (c->vm == ZKV_VM_GROTH16) launch_prep_groth16(a, c->ws, s);
+    else launch_prep_sp1(a, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[1], s);
     launch_msm(a.n, c->d_tab, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[2], s);
@@ -380,6 +388,46 @@ ZKV_EXPORT int zkv_bn254_pairing_batch(zkv_ctx* c, size_t n, size_t k, const uin
     if (k > 64) return ZKV_ERR_INVALID_ARG;
     uint8_t dummy = 0;
     return run_precompile(c, 2, n, k, k ? in : &dummy, result, ok);
+}
+
+// ------------------------------------------------------------------ Groth16 core, arbitrary verification key
+ZKV_EXPORT zkv_ctx* zkv_groth16_ctx_create(const uint8_t* vk_words, size_t n_ic, int vm_type, int device) {
+    if (!vk_words || n_ic < 1 || n_ic > MAX_IC || (vm_type != ZKV_VM_RISC0 && vm_type != ZKV_VM_SP1)) return nullptr;
+    zkv_ctx* c = new (std::nothrow) zkv_ctx();
+    if (!c) return nullptr;
+    c->vm = ZKV_VM_GROTH16; c->device = device; c->initialized = true;
+    memset(&c->consts, 0, sizeof c->consts);
+    memcpy(c->gvk, vk_words, 448 + 64 * n_ic);
+    c->g_n_ic = (uint32_t)n_ic; c->g_negate = vm_type == ZKV_VM_RISC0;
+    return c;
+}
+ZKV_EXPORT int zkv_groth16_verify_batch(zkv_ctx* c, size_t n, const uint8_t* proofs, const uint8_t* signals, uint8_t* verified) {
+    if (!c || c->vm != ZKV_VM_GROTH16) return ZKV_ERR_WRONG_CTX;
+    const uint32_t n_sig = c->g_n_ic - 1;
+    if (n && (!proofs || !verified || (n_sig && !signals))) return ZKV_ERR_INVALID_ARG;
+    if (!n) return ZKV_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ctx_device_init(c);
+    if (rc != ZKV_OK) return rc;
+    const size_t cap = c->ws.cap;
+    for (size_t base = 0; base < n; base += cap) {
+        size_t m = n - base < cap ? n - base : cap;
+        if ((rc = grow(&c->d_blob, &c->blob_cap, m * 256 + 8)) != ZKV_OK) return rc;
+        if ((rc = grow(&c->d_pv, &c->pv_cap, m * 32 * n_sig + 8)) != ZKV_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_blob, proofs + 256 * base, 256 * m, hipMemcpyHostToDevice, c->stream));
+        if (n_sig) HIP_TRY(hipMemcpyAsync(c->d_pv, signals + (size_t)32 * n_sig * base, (size_t)32 * n_sig * m, hipMemcpyHostToDevice, c->stream));
+        PrepArgs a;
+        memset(&a, 0, sizeof a);
+        a.n = m; a.blob = c->d_blob; a.in32_a = c->d_pv; a.n_sig = n_sig; a.negate_a = c->g_negate ? 1u : 0u;
+        a.force_fail = c->vk_invalid ? 1u : 0u;
+        a.status = c->d_status; a.recv = nullptr;
+        enqueue_chunk(c, a, c->stream, true);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(verified + base, c->d_status, m, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < m; i++) verified[base + i] = verified[base + i] == ZKV_STATUS_OK ? 1 : 0;
+    }
+    return ZKV_OK;
 }
 
 // ------------------------------------------------------------------ Groth16 core pieces

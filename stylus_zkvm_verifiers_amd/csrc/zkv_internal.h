@@ -7,7 +7,7 @@ namespace zkv {
 
 // Per-chunk workspace in HBM, struct-of-arrays: word k of proof i lives at base[k * cap + i], so the 64 lanes
 // of a wavefront read/write 256 contiguous bytes per word (coalesced).
-constexpr int WS_PREP_WORDS = 80;   // ax ay cx cy (4x8) | bx.c0 bx.c1 by.c0 by.c1 (4x8) | s0 s1 (2x8)
+constexpr int WS_PREP_WORDS = 64 + 8 * MAX_VAR;   // ax ay cx cy (4x8) | bx.c0 bx.c1 by.c0 by.c1 (4x8) | per-proof scalars (MAX_VAR x 8)
 constexpr int WS_NORM_WORDS = 48;   // axs ays lxs lys cxs cys
 constexpr int WS_F_WORDS = 96;      // Fp12 Miller value (slot F of the final exponentiation)
 constexpr int WS_FE_WORDS = 5 * 96; // cold Fp12 slots E, Y1, Y3, Y4 of the final exponentiation (+1 spare: f/T or acc when not in LDS)
@@ -40,13 +40,16 @@ struct PrepArgs {
     const uint64_t* pv_off;     // sp1: n+1 offsets or nullptr
     uint32_t pv_stride;
     uint32_t selector_be;       // expected selector as big-endian word
-    uint32_t force_fail;        // context-level VerificationFailed (risc0 bn254_control_id >= R)
+    uint32_t force_fail;        // context-level VerificationFailed (risc0 bn254_control_id >= R, invalid generic VK)
+    uint32_t n_sig;             // generic Groth16 batches: signals per proof (in32_a holds n x n_sig x 32 bytes)
+    uint32_t negate_a;          // generic Groth16 batches: VMType::Risc0 negates A
     uint8_t* status; uint8_t* recv;
 };
 
 void launch_setup(const VkRaw* d_raw, VkTables* d_tab, hipStream_t s);
 void launch_prep_risc0(const PrepArgs& a, const Risc0Consts& k, const Workspace& ws, hipStream_t s);
 void launch_prep_sp1(const PrepArgs& a, const Workspace& ws, hipStream_t s);
+void launch_prep_groth16(const PrepArgs& a, const Workspace& ws, hipStream_t s);
 void launch_msm(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
 void launch_vk_x(size_t n, const VkTables* d_tab, const uint8_t* sig, uint8_t* out, hipStream_t s);
 void launch_g2chk(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);

@@ -24,6 +24,7 @@ enum : uint32_t { FL_ALIVE = 1u, FL_A_INF = 2u, FL_B_INF = 4u, FL_C_INF = 8u, FL
 constexpr int N_LINES = 88;          // 65 doublings + 21 NAF additions + 2 Frobenius additions
 constexpr int MSM_MAX_WINDOWS = 64;  // 4-bit windows over a 256-bit scalar
 constexpr int MAX_IC = 6;
+constexpr int MAX_VAR = 5;           // per-proof signals (risc0 and sp1 use 2; a generic key uses all n_ic - 1)
 
 // Raw verification key handed to the set-up kernel: canonical values as 8 x 32-bit little-endian limbs.
 struct VkRaw {
@@ -33,21 +34,24 @@ struct VkRaw {
     uint32_t n_ic;
     uint32_t fixed_scalar[MAX_IC][8];   // for IC index i >= 1: per-context scalar (risc0 control root / id)
     uint32_t is_fixed[MAX_IC];
-    uint32_t var_ic[2];                 // IC indices of the two per-proof scalars
-    uint32_t var_windows[2];            // 4-bit windows per per-proof scalar (32 for 128-bit, 64 for 256-bit)
+    uint32_t n_var;                     // number of per-proof scalars
+    uint32_t var_ic[MAX_VAR];           // their IC indices
+    uint32_t var_windows[MAX_VAR];      // 4-bit windows per per-proof scalar (32 for 128-bit, 64 for 256-bit)
 };
 
 // Device-resident tables derived from the VK at context set-up.
 struct VkTables {
-    G1A base; uint32_t base_inf; uint32_t var_windows[2];
-    G1A msm[2][MSM_MAX_WINDOWS][16];     // msm[b][w][d] = d * 16^w * IC_var[b]   (d = 0 unused)
+    G1A base; uint32_t base_inf; uint32_t n_var; uint32_t var_windows[MAX_VAR];
+    uint32_t vk_valid;                   // every VK point is a valid precompile input (else every proof is rejected)
+    uint32_t skip_fixed[2];              // gamma / delta is the point at infinity: that pair contributes 1
+    G1A msm[MAX_VAR][MSM_MAX_WINDOWS][16];   // msm[b][w][d] = d * 16^w * IC_var[b]   (d = 0 unused)
     LineAffC lines[2][N_LINES];          // gamma, delta: slope-form lines of the fixed-Q Miller loop
     uint32_t f_alpha_beta[96];           // Miller value of (alpha, beta): Fp12 as g0 g1 g2 h0 h1 h2, (c0, c1) each
 };
 
 struct PrepOut {
     Fp ax, ay, cx, cy; Fp2 bx, by;
-    uint32_t s[2][8];
+    uint32_t s[MAX_VAR][8];
     uint32_t flags;
 };
 struct G1Norm { Fp axs, ays, lxs, lys, cxs, cys; };   // x/y and 1/y of A', L = vk_x, C
@@ -150,7 +154,7 @@ ZKV_HD G1J msm_accumulate(const VkTables& vk, const PrepOut& in) {
     if (vk.base_inf) acc = g1j_infinity();
     else { acc.x = vk.base.x; acc.y = vk.base.y; acc.z = fp_one(); }
 #pragma unroll 1
-    for (int b = 0; b < 2; b++) {
+    for (uint32_t b = 0; b < vk.n_var; b++) {
 #pragma unroll 1
         for (uint32_t w = 0; w < vk.var_windows[b]; w++) {
             uint32_t d = (in.s[b][w >> 3] >> ((w & 7) * 4)) & 15u;
@@ -198,7 +202,7 @@ template <class RF, class RT>
 ZKV_HD void miller_loop_m(const VkTables& vk, uint32_t flags, const G1Norm& n, const Fp2& bx, const Fp2& by,
                           bool with_fixed, RF fm, RT tm) {
     bool do_ab = !(flags & (FL_A_INF | FL_B_INF));
-    bool do_l = with_fixed && !(flags & FL_L_INF), do_c = with_fixed && !(flags & FL_C_INF);
+    bool do_l = with_fixed && !(flags & FL_L_INF) && !vk.skip_fixed[0], do_c = with_fixed && !(flags & FL_C_INF) && !vk.skip_fixed[1];
     f12m_set_one(fm);
     m_st_f2(tm, 0, bx); m_st_f2(tm, 1, by); m_st_f2(tm, 2, f2_one());
     Fp2 nby = f2_neg(by);
@@ -294,10 +298,33 @@ template <class RA> ZKV_HD bool final_exp_is_one_m(MRef F, MRef E, MRef Y1, MRef
 
 #if !defined(ZKV_PAIRED)
 // ---------------------------------------------------------------- context set-up (run once per VK on the device)
+ZKV_HD bool raw_g1_is_inf(const uint32_t p[2][8]) { return raw_is_zero(p[0]) && raw_is_zero(p[1]); }
+ZKV_HD bool raw_g1_valid(const uint32_t p[2][8]) {            // EIP-196 input validation
+    if (!raw_lt_p(p[0]) || !raw_lt_p(p[1])) return false;
+    if (raw_g1_is_inf(p)) return true;
+    return g1_on_curve(fp_from_raw(p[0]), fp_from_raw(p[1]));
+}
+ZKV_HD bool raw_g2_is_inf(const uint32_t q[4][8]) { return raw_is_zero(q[0]) && raw_is_zero(q[1]) && raw_is_zero(q[2]) && raw_is_zero(q[3]); }
+ZKV_HD bool raw_g2_valid(const uint32_t q[4][8]) {            // EIP-197: on the twist and in the order-r subgroup
+    for (int k = 0; k < 4; k++) if (!raw_lt_p(q[k])) return false;
+    if (raw_g2_is_inf(q)) return true;
+    Fp2 x, y; x.c0 = fp_from_raw(q[0]); x.c1 = fp_from_raw(q[1]); y.c0 = fp_from_raw(q[2]); y.c1 = fp_from_raw(q[3]);
+    return g2_on_twist(x, y) && g2_in_subgroup(x, y);
+}
+// Every VK point must be an input the precompiles accept, otherwise each ecMul / ecAdd / ecPairing call of the reference
+// fails and verify_proof_with_key returns false for every proof (groth16.rs:36-39, 106).
+ZKV_HD void setup_validate(const VkRaw& vk, VkTables& t) {
+    bool ok = raw_g1_valid(vk.alpha) && raw_g2_valid(vk.beta) && raw_g2_valid(vk.gamma) && raw_g2_valid(vk.delta);
+    for (uint32_t i = 0; i < vk.n_ic; i++) ok = ok && raw_g1_valid(vk.ic[i]);
+    t.vk_valid = ok ? 1u : 0u;
+    t.skip_fixed[0] = raw_g2_is_inf(vk.gamma) ? 1u : 0u;
+    t.skip_fixed[1] = raw_g2_is_inf(vk.delta) ? 1u : 0u;
+}
 ZKV_HD LineAffC line_to_table(const LineAff& l) {
     LineAffC r; r.nl.c0 = l.nl.c0; r.nl.c1 = l.nl.c1; r.c.c0 = l.c.c0; r.c.c1 = l.c.c1; return r;
 }
 ZKV_HD void setup_lines(const uint32_t q[4][8], LineAffC* out) {
+    if (raw_g2_is_inf(q)) return;                // pair skipped (skip_fixed)
     G2A Q, T;
     Q.x.c0 = fp_from_raw(q[0]); Q.x.c1 = fp_from_raw(q[1]); Q.y.c0 = fp_from_raw(q[2]); Q.y.c1 = fp_from_raw(q[3]);
     T = Q;
@@ -331,21 +358,28 @@ ZKV_HD void g1j_to_affine(const G1J& p, G1A& out, uint32_t& inf) {
 }
 // base = IC[0] + sum over fixed signals s_i * IC[i]
 ZKV_HD void setup_base(const VkRaw& vk, VkTables& t) {
-    G1J acc; acc.x = fp_from_raw(vk.ic[0][0]); acc.y = fp_from_raw(vk.ic[0][1]); acc.z = fp_one();
+    G1J acc;
+    if (raw_g1_is_inf(vk.ic[0])) acc = g1j_infinity();
+    else { acc.x = fp_from_raw(vk.ic[0][0]); acc.y = fp_from_raw(vk.ic[0][1]); acc.z = fp_one(); }
 #pragma unroll 1
     for (uint32_t i = 1; i < vk.n_ic; i++) {
-        if (!vk.is_fixed[i]) continue;
+        if (!vk.is_fixed[i] || raw_g1_is_inf(vk.ic[i])) continue;
         G1J m = g1_mul_raw(fp_from_raw(vk.ic[i][0]), fp_from_raw(vk.ic[i][1]), vk.fixed_scalar[i]);
         G1A ma; uint32_t inf;
         g1j_to_affine(m, ma, inf);
         if (!inf) acc = g1j_add_affine(acc, ma.x, ma.y);
     }
     g1j_to_affine(acc, t.base, t.base_inf);
-    t.var_windows[0] = vk.var_windows[0]; t.var_windows[1] = vk.var_windows[1];
+    t.n_var = vk.n_var;
+    for (int b = 0; b < MAX_VAR; b++) t.var_windows[b] = vk.var_windows[b];
 }
 // one (b, w) row of the fixed-base table: d * 16^w * IC_var[b], d = 1..15
 ZKV_HD void setup_msm_row(const VkRaw& vk, VkTables& t, int b, int w) {
     uint32_t ici = vk.var_ic[b];
+    if (raw_g1_is_inf(vk.ic[ici])) {             // s * infinity = infinity: leave the row zero and never read it
+        if (w == 0) t.var_windows[b] = 0;
+        return;
+    }
     G1J p; p.x = fp_from_raw(vk.ic[ici][0]); p.y = fp_from_raw(vk.ic[ici][1]); p.z = fp_one();
 #pragma unroll 1
     for (int i = 0; i < 4 * w; i++) p = g1j_dbl(p);
@@ -363,6 +397,11 @@ ZKV_HD void setup_msm_row(const VkRaw& vk, VkTables& t, int b, int w) {
     }
 }
 ZKV_HD void setup_alpha_beta(const VkRaw& vk, VkTables& t, MRef fm, MRef tm) {
+    if (raw_g1_is_inf(vk.alpha) || raw_g2_is_inf(vk.beta)) {       // e(alpha, beta) contributes 1
+        f12m_set_one(fm);
+        for (int k = 0; k < 96; k++) t.f_alpha_beta[k] = fm.p[(size_t)k * fm.stride];
+        return;
+    }
     Fp ax = fp_from_raw(vk.alpha[0]), ay = fp_from_raw(vk.alpha[1]);
     Fp iy = fp_inv(ay);
     G1Norm n; n.axs = fp_mul(ax, iy); n.ays = iy;

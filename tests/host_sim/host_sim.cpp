@@ -22,7 +22,8 @@ static VkTables* tables(int vm, const uint8_t* cr, const uint8_t* cid) {
     VkTables* t = g_tab[vm] ? g_tab[vm] : (VkTables*)malloc(sizeof(VkTables));
     memset(t, 0, sizeof *t);
     setup_base(raw, *t);
-    for (int b = 0; b < 2; b++) for (uint32_t w = 0; w < raw.var_windows[b]; w++) setup_msm_row(raw, *t, b, (int)w);
+    setup_validate(raw, *t);
+    for (uint32_t b = 0; b < raw.n_var; b++) for (uint32_t w = 0; w < raw.var_windows[b]; w++) setup_msm_row(raw, *t, (int)b, (int)w);
     setup_lines(raw.gamma, t->lines[0]);
     setup_lines(raw.delta, t->lines[1]);
     { uint32_t ab[96 + 48]; MRef fm = m_ref(ab, 1), tm = m_ref(ab + 96, 1); setup_alpha_beta(raw, *t, fm, tm); }
@@ -96,6 +97,34 @@ void hs_vk_x(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* s0, c
         fp_to_raw(r, c ? a.y : a.x);
         for (int i = 0; i < 8; i++) for (int k = 0; k < 4; k++) out64[32 * c + 31 - 4 * i - k] = r[i] >> (8 * k);
     }
+}
+// verify_proof_with_key for an arbitrary key through the kernel stage functions (tables rebuilt per call: test only)
+int hs_groth16_generic(const uint8_t* vk_words, int n_ic, int negate_a, const uint8_t* words, const uint8_t* signals) {
+    static VkTables* t = (VkTables*)malloc(sizeof(VkTables));
+    VkRaw raw; host::fill_vk_generic(raw, vk_words, (uint32_t)n_ic);
+    memset(t, 0, sizeof *t);
+    setup_validate(raw, *t);
+    if (!t->vk_valid) return 0;
+    setup_base(raw, *t);
+    for (uint32_t b = 0; b < raw.n_var; b++) for (uint32_t w = 0; w < raw.var_windows[b]; w++) setup_msm_row(raw, *t, (int)b, (int)w);
+    setup_lines(raw.gamma, t->lines[0]);
+    setup_lines(raw.delta, t->lines[1]);
+    { uint32_t ab[96 + 48]; MRef fm = m_ref(ab, 1), tm = m_ref(ab + 96, 1); setup_alpha_beta(raw, *t, fm, tm); }
+    PrepOut p; memset(&p, 0, sizeof p);
+    for (int b = 0; b + 1 < n_ic; b++) { load_be256(p.s[b], signals + 32 * b); if (!raw_lt_r(p.s[b])) return 0; }
+    uint32_t w[8][8];
+    for (int k = 0; k < 8; k++) load_be256(w[k], words + 32 * k);
+    if (!prep_points(w, negate_a != 0, p)) return 0;
+    if (!(p.flags & FL_B_INF) && !g2_in_subgroup(p.bx, p.by)) return 0;
+    G1Norm n; uint32_t fl = p.flags;
+    msm_normalize(*t, p, fl, n);
+    static thread_local uint32_t buf[96 + 48], slots[5 * 96];
+    MRef fm = m_ref(buf, 1), tm = m_ref(buf + 96, 1);
+    miller_loop_m(*t, fl, n, p.bx, p.by, true, fm, tm);
+    MRef F = m_ref(slots, 1), E = m_ref(slots + 96, 1), Y1 = m_ref(slots + 192, 1), Y3 = m_ref(slots + 288, 1), Y4 = m_ref(slots + 384, 1);
+    for (int k = 0; k < 96; k++) slots[k] = t->f_alpha_beta[k];
+    f12m_mul(F, F, fm);
+    return final_exp_is_one_m(F, E, Y1, Y3, Y4, fm) ? 1 : 0;
 }
 void hs_risc0_scalars(const uint8_t* image_id, const uint8_t* journal, uint8_t* digest32, uint8_t* lo32, uint8_t* hi32) {
     Risc0Consts k; host::risc0_consts(k);

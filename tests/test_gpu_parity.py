@@ -238,3 +238,41 @@ def test_vk_x_batch_matches_oracle(zkv, r0, sp1, real_proofs):
     got = sp1.vk_x_batch([(m.be32(a), m.be32(b)) for a, b in pairs])
     for (a, b), g in zip(pairs, got):
         assert g == ol.groth16_vk_x(1, [m.be32(a), m.be32(b)]), (hex(a), hex(b))
+
+
+def test_generic_groth16_trapdoor_keys_on_gpu(zkv):
+    """zkv_groth16_verify_batch (verify_proof_with_key for an arbitrary key): valid proofs with distinct public inputs for keys with
+    1..6 IC points, wrong / out-of-range signals, the other VM convention, keys with infinity or invalid points -- equal to the
+    spec model and the C oracle."""
+    import random
+    import oracle_lib as ol
+    import spec_model as m
+    from trapdoor_cases import generic_cases
+    rng = random.Random(78)
+    cases = generic_cases(rng)
+    # group by (vm, key) so that each context verifies a small batch
+    groups = {}
+    for name, vm, vk, prf, sig, expect in cases:
+        groups.setdefault((vm, m.vk_to_words(vk), len(vk['ic'])), []).append((name, prf, sig, expect, vk))
+    for (vm, vkb, n_ic), items in groups.items():
+        v = zkv.Groth16Verifier(vkb, n_ic, zkv.errors.VM_RISC0 if vm == 'risc0' else zkv.errors.VM_SP1)
+        got = v.verify_batch([m.proof_to_words(*it[1]) for it in items], [[m.be32(s) for s in it[2]] for it in items])
+        for it, g in zip(items, got):
+            name, prf, sig, expect, vk = it
+            assert bool(g) == expect == ol.groth16_verify_vk(0 if vm == 'risc0' else 1, vkb, n_ic, m.proof_to_words(*prf), [m.be32(s) for s in sig]), name
+        v.close()
+    # a larger batch of distinct public inputs on one key
+    vk, td = m.trapdoor_vk(rng, 6)
+    proofs, sigs, exp = [], [], []
+    for i in range(96):
+        sig = [rng.randrange(m.R) for _ in range(5)]
+        prf = m.trapdoor_prove(rng, td, sig, 'risc0')
+        if i % 5 == 4:
+            sig[i % 5 - 1] ^= 1
+        proofs.append(m.proof_to_words(*prf)); sigs.append([m.be32(s) for s in sig]); exp.append(i % 5 != 4)
+    v = zkv.Groth16Verifier(m.vk_to_words(vk), 6, zkv.errors.VM_RISC0)
+    assert list(v.verify_batch(proofs, sigs)) == exp
+    A, B, Cc = m.trapdoor_prove(rng, td, [1, 2, 3, 4, 5], 'risc0')
+    assert v.verify_proof_with_key(A, B, Cc, [1, 2, 3, 4, 5]) is True
+    assert v.verify_proof_with_key(A, B, Cc, [1, 2, 3, 4]) is False          # length mismatch, groth16.rs:32
+    v.close()

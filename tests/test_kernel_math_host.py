@@ -138,3 +138,21 @@ def test_windowed_vk_x_matches_oracle_on_random_signals(hs, real_proofs):
         out = C.create_string_buffer(64)
         hs.hs_vk_x(1, None, None, m.be32(a), m.be32(b), out)
         assert out.raw == ol.groth16_vk_x(1, [m.be32(a), m.be32(b)]), (hex(a), hex(b))
+
+
+from trapdoor_cases import generic_cases as _generic_cases  # noqa: E402
+
+
+def test_generic_groth16_with_trapdoor_keys(hs):
+    """verify_proof_with_key for arbitrary keys (groth16.rs:23-49): trapdoor keys give VALID proofs with arbitrary, distinct
+    public inputs (1 to 6 IC points), so the vk_x / pairing stages are exercised beyond the two fixed real-proof inputs."""
+    import oracle_lib as ol
+    rng = random.Random(77)
+    for name, vm, vk, prf, sig, expect in _generic_cases(rng):
+        words = m.proof_to_words(*prf)
+        vkb = m.vk_to_words(vk)
+        sigb = [m.be32(s) for s in sig]
+        assert m.groth16_verify(vm, vk, prf[0], prf[1], prf[2], sig) == expect, name
+        assert ol.groth16_verify_vk(0 if vm == 'risc0' else 1, vkb, len(vk['ic']), words, sigb) == expect, name
+        got = hs.hs_groth16_generic(vkb, len(vk['ic']), 1 if vm == 'risc0' else 0, words, b''.join(sigb) + b'\0')
+        assert bool(got) == expect, name
