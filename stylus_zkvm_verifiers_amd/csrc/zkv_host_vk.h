@@ -95,12 +95,12 @@ inline void fill_vk_risc0(VkRaw& r, const uint8_t cr0[16], const uint8_t cr1[16]
     memset(w, 0, 32); memcpy(w + 16, cr1, 16); be_to_limbs(r.fixed_scalar[2], w);
     be_to_limbs(r.fixed_scalar[5], control_id);
     r.is_fixed[1] = r.is_fixed[2] = r.is_fixed[5] = 1;
-    r.n_var = 2; r.var_ic[0] = 3; r.var_ic[1] = 4; r.var_windows[0] = 32; r.var_windows[1] = 32;
+    r.n_var = 2; r.var_ic[0] = 3; r.var_ic[1] = 4; r.var_windows[0] = 16; r.var_windows[1] = 16;
 }
 // sp1: signals [program_vkey, hash(public_values)] both per proof (sp1/verifier.rs:85-86)
 inline void fill_vk_sp1(VkRaw& r) {
     fill_vk_common(r, SP1_VK);
-    r.n_var = 2; r.var_ic[0] = 1; r.var_ic[1] = 2; r.var_windows[0] = 64; r.var_windows[1] = 64;
+    r.n_var = 2; r.var_ic[0] = 1; r.var_ic[1] = 2; r.var_windows[0] = 32; r.var_windows[1] = 32;
 }
 
 // Arbitrary verification key (Groth16Verifier::verify_proof_with_key is generic over `vk`, common/groth16.rs:23-31):
@@ -118,7 +118,7 @@ inline void fill_vk_generic(VkRaw& r, const uint8_t* words, uint32_t n_ic) {
     r.n_ic = n_ic;
     for (uint32_t i = 0; i < n_ic; i++) { be_to_limbs(r.ic[i][0], words + 448 + 64 * i); be_to_limbs(r.ic[i][1], words + 480 + 64 * i); }
     r.n_var = n_ic - 1;
-    for (uint32_t b = 0; b + 1 < n_ic; b++) { r.var_ic[b] = b + 1; r.var_windows[b] = 64; }
+    for (uint32_t b = 0; b + 1 < n_ic; b++) { r.var_ic[b] = b + 1; r.var_windows[b] = 32; }
 }
 
 // ---- risc0 digest chain (crypto.rs:95-195, verifier.rs:128-144)

@@ -22,7 +22,8 @@ enum : uint8_t {
 enum : uint32_t { FL_ALIVE = 1u, FL_A_INF = 2u, FL_B_INF = 4u, FL_C_INF = 8u, FL_L_INF = 16u };
 
 constexpr int N_LINES = 88;          // 65 doublings + 21 NAF additions + 2 Frobenius additions
-constexpr int MSM_MAX_WINDOWS = 64;  // 4-bit windows over a 256-bit scalar
+constexpr int MSM_MAX_WINDOWS = 32;  // 8-bit windows over a 256-bit scalar
+constexpr int MSM_DIGITS = 256;
 constexpr int MAX_IC = 6;
 constexpr int MAX_VAR = 5;           // per-proof signals (risc0 and sp1 use 2; a generic key uses all n_ic - 1)
 
@@ -36,7 +37,7 @@ struct VkRaw {
     uint32_t is_fixed[MAX_IC];
     uint32_t n_var;                     // number of per-proof scalars
     uint32_t var_ic[MAX_VAR];           // their IC indices
-    uint32_t var_windows[MAX_VAR];      // 4-bit windows per per-proof scalar (32 for 128-bit, 64 for 256-bit)
+    uint32_t var_windows[MAX_VAR];      // 8-bit windows per per-proof scalar (16 for 128-bit, 32 for 256-bit)
 };
 
 // Device-resident tables derived from the VK at context set-up.
@@ -44,7 +45,7 @@ struct VkTables {
     G1A base; uint32_t base_inf; uint32_t n_var; uint32_t var_windows[MAX_VAR];
     uint32_t vk_valid;                   // every VK point is a valid precompile input (else every proof is rejected)
     uint32_t skip_fixed[2];              // gamma / delta is the point at infinity: that pair contributes 1
-    G1A msm[MAX_VAR][MSM_MAX_WINDOWS][16];   // msm[b][w][d] = d * 16^w * IC_var[b]   (d = 0 unused)
+    G1A msm[MAX_VAR][MSM_MAX_WINDOWS][MSM_DIGITS];   // msm[b][w][d] = d * 256^w * IC_var[b]   (d = 0 unused); 2.6 MB, L2-resident rows
     LineAffC lines[2][N_LINES];          // gamma, delta: slope-form lines of the fixed-Q Miller loop
     uint32_t f_alpha_beta[96];           // Miller value of (alpha, beta): Fp12 as g0 g1 g2 h0 h1 h2, (c0, c1) each
 };
@@ -157,7 +158,7 @@ ZKV_HD G1J msm_accumulate(const VkTables& vk, const PrepOut& in) {
     for (uint32_t b = 0; b < vk.n_var; b++) {
 #pragma unroll 1
         for (uint32_t w = 0; w < vk.var_windows[b]; w++) {
-            uint32_t d = (in.s[b][w >> 3] >> ((w & 7) * 4)) & 15u;
+            uint32_t d = (in.s[b][w >> 2] >> ((w & 3) * 8)) & 255u;
             if (d) {
                 const G1A& e = vk.msm[b][w][d];
                 acc = g1j_add_affine(acc, e.x, e.y);
@@ -373,7 +374,9 @@ ZKV_HD void setup_base(const VkRaw& vk, VkTables& t) {
     t.n_var = vk.n_var;
     for (int b = 0; b < MAX_VAR; b++) t.var_windows[b] = vk.var_windows[b];
 }
-// one (b, w) row of the fixed-base table: d * 16^w * IC_var[b], d = 1..15
+// one (b, w) row of the fixed-base table: d * 256^w * IC_var[b], d = 1..255, all affine.
+// The row is built by doubling levels (1 | 2 3 | 4..7 | ... | 128..255): level m adds mP to the known multiples 1..m-1 and doubles
+// mP; the m slopes of a level share ONE field inversion (prefix products parked in the y slots that are about to be written).
 ZKV_HD void setup_msm_row(const VkRaw& vk, VkTables& t, int b, int w) {
     uint32_t ici = vk.var_ic[b];
     if (raw_g1_is_inf(vk.ic[ici])) {             // s * infinity = infinity: leave the row zero and never read it
@@ -382,18 +385,35 @@ ZKV_HD void setup_msm_row(const VkRaw& vk, VkTables& t, int b, int w) {
     }
     G1J p; p.x = fp_from_raw(vk.ic[ici][0]); p.y = fp_from_raw(vk.ic[ici][1]); p.z = fp_one();
 #pragma unroll 1
-    for (int i = 0; i < 4 * w; i++) p = g1j_dbl(p);
+    for (int i = 0; i < 8 * w; i++) p = g1j_dbl(p);
     Fp zi = fp_inv(p.z), zi2 = fp_sqr(zi);
-    Fp px = fp_mul(p.x, zi2), py = fp_mul(p.y, fp_mul(zi2, zi));
-    G1J acc; acc.x = px; acc.y = py; acc.z = fp_one();
     G1A* row = t.msm[b][w];
     row[0].x = fp_zero(); row[0].y = fp_zero();
-    row[1].x = px; row[1].y = py;
+    row[1].x = fp_mul(p.x, zi2); row[1].y = fp_mul(p.y, fp_mul(zi2, zi));
 #pragma unroll 1
-    for (int d = 2; d < 16; d++) {
-        acc = g1j_add_affine(acc, px, py);
-        Fp ai = fp_inv(acc.z), ai2 = fp_sqr(ai);
-        row[d].x = fp_mul(acc.x, ai2); row[d].y = fp_mul(acc.y, fp_mul(ai2, ai));
+    for (int m = 1; m < MSM_DIGITS; m *= 2) {
+        const Fp xm = row[m].x, ym = row[m].y;
+        const int cnt = (2 * m < MSM_DIGITS) ? m : m - 1;       // the last level stops at 255
+        Fp prod = fp_one();
+#pragma unroll 1
+        for (int j = 1; j <= cnt; j++) {
+            Fp den = (j < m) ? fp_sub(row[j].x, xm) : fp_dbl(ym);
+            row[m + j].y = prod;
+            prod = fp_mul(prod, den);
+        }
+        Fp inv = fp_inv(prod);
+#pragma unroll 1
+        for (int j = cnt; j >= 1; j--) {
+            Fp den = (j < m) ? fp_sub(row[j].x, xm) : fp_dbl(ym);
+            Fp dinv = fp_mul(inv, row[m + j].y);
+            inv = fp_mul(inv, den);
+            Fp xj = (j < m) ? row[j].x : xm;
+            Fp num = (j < m) ? fp_sub(row[j].y, ym) : fp_add(fp_dbl(fp_sqr(xm)), fp_sqr(xm));
+            Fp lam = fp_mul(num, dinv);
+            Fp x3 = fp_sub(fp_sub(fp_sqr(lam), xm), xj);
+            row[m + j].x = x3;
+            row[m + j].y = fp_sub(fp_mul(lam, fp_sub(xm, x3)), ym);
+        }
     }
 }
 ZKV_HD void setup_alpha_beta(const VkRaw& vk, VkTables& t, MRef fm, MRef tm) {
