@@ -103,6 +103,45 @@ int zkv_sp1_verify_proof(zkv_ctx* ctx, const uint8_t program_vkey[32], const uin
 int zkv_sp1_verify_batch_dev(zkv_ctx* ctx, size_t n, const uint8_t* d_program_vkeys, const uint8_t* d_public_values, size_t pv_len,
                              const uint8_t* d_proofs, uint8_t* d_status, uint8_t* d_recv_selector, void* stream);
 
+/* ------------------------------------------------------------------ on-chain wire layer: eth_call batches
+ * What a client of the deployed example shells sends: calldata for the Solidity view of the two traits
+ * (examples/risc0-verifier/examples/interact.rs:31-43, examples/sp1-verifier/examples/interact.rs:11-19; the shells are
+ * examples/{risc0,sp1}-verifier/src/lib.rs).  Stylus exports `Vec<u8>` as `uint8[]`, so every seal byte travels as one
+ * 32-byte word: `verify(uint8[],bytes32,bytes32)`, `verifyIntegrity(uint8[],bytes32)`, `verifyProof(bytes32,uint8[],uint8[])`.
+ * Calldata is decoded on the device.  UNPINNED (the Stylus router is not part of the reference tree): calldata must be the
+ * canonical ABI encoding of its arguments (alloy-sol-types 0.8.20 `abi_decode_params(.., validate = true)`); anything else,
+ * and any unknown function selector, reverts with empty return data and reports ZKV_STATUS_BAD_CALLDATA. */
+#define ZKV_STATUS_BAD_CALLDATA 6           /* wire layer only: the contract's router cannot decode the call */
+#define ZKV_RETURNDATA_STRIDE 96            /* longest return / revert data of any method (SP1 `version()`)   */
+/* first 4 bytes of keccak-256(signature), e.g. "verify(uint8[],bytes32,bytes32)" */
+int zkv_abi_function_selector(const char* signature, uint8_t out[4]);
+/* Canonical calldata of one call.  Returns the length needed; writes only when out != NULL and cap is large enough. */
+size_t zkv_risc0_encode_verify_call(const uint8_t* seal, size_t seal_len, const uint8_t image_id[32],
+                                    const uint8_t journal_digest[32], uint8_t* out, size_t cap);
+size_t zkv_risc0_encode_verify_integrity_call(const uint8_t* seal, size_t seal_len, const uint8_t claim_digest[32], uint8_t* out, size_t cap);
+size_t zkv_sp1_encode_verify_proof_call(const uint8_t program_vkey[32], const uint8_t* public_values, size_t pv_len,
+                                        const uint8_t* proof, size_t proof_len, uint8_t* out, size_t cap);
+/* n eth_calls against one verifier instance: request i = calldata_blob[calldata_off[i] .. calldata_off[i+1]).
+ * reverted[i] = 0 / 1; returndata (n x ZKV_RETURNDATA_STRIDE) + returndata_len[n] hold the ABI-encoded return value
+ * (`true` word for verify / verifyIntegrity, nothing for verifyProof, the getters' values) or the revert bytes
+ * (common/errors.rs:18-27, risc0/errors.rs:21-32, sp1/errors.rs:21-32).  status (may be NULL) receives ZKV_STATUS_* of
+ * verify-class calls and ZKV_STATUS_BAD_CALLDATA for everything the device did not verify (getters, `initialize`, which
+ * is simulated without storing anything, and undecodable calldata). */
+int zkv_risc0_eth_call_batch(zkv_ctx* ctx, size_t n, const uint8_t* calldata_blob, const uint64_t* calldata_off, uint8_t* reverted,
+                             uint8_t* returndata, uint32_t* returndata_len, uint8_t* status);
+int zkv_sp1_eth_call_batch(zkv_ctx* ctx, size_t n, const uint8_t* calldata_blob, const uint64_t* calldata_off, uint8_t* reverted,
+                           uint8_t* returndata, uint32_t* returndata_len, uint8_t* status);
+/* Fast path: calldata blob (calldata_bytes long) and its n+1 offsets ALREADY RESIDENT IN HBM; handles the verify-class
+ * calls of the context's verifier (anything else gets ZKV_STATUS_BAD_CALLDATA -- resolve those on the host).
+ * Asynchronous on `stream` (NULL = the context's stream). */
+int zkv_eth_call_batch_dev(zkv_ctx* ctx, size_t n, const uint8_t* d_calldata, const uint64_t* d_calldata_off, uint64_t calldata_bytes,
+                           uint8_t* d_status, uint8_t* d_recv_selector, void* stream);
+/* return / revert data of one verify-class call from its status byte (companion of the device fast path) */
+int zkv_eth_call_returndata(const zkv_ctx* ctx, uint8_t status, const uint8_t recv_selector[4], uint8_t out[ZKV_RETURNDATA_STRIDE],
+                            uint32_t* out_len, uint8_t* reverted);
+/* HIP-event duration (ms) of the calldata-decode kernel of the most recent eth_call chunk. */
+int zkv_ctx_last_wire_ms(zkv_ctx* ctx, float* out_ms);
+
 /* ------------------------------------------------------------------ precompile-level batches (the inner seam)
  * The three EVM precompiles the reference STATICCALLs (common/groth16.rs:12-14): ecAdd 0x06 (call site :55),
  * ecMul 0x07 (:54), ecPairing 0x08 (:121-125), with EIP-196/197 semantics.  ok[i] = 1 when call i succeeds, 0 when

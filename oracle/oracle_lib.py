@@ -55,6 +55,13 @@ def lib():
                                               C.c_void_p, C.c_void_p, C.c_int]
         L.zkvo_sp1_verify_batch.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_int]
+        L.zkvo_keccak256.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+        L.zkvo_risc0_encode_call.restype = C.c_size_t
+        L.zkvo_risc0_encode_call.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p]
+        L.zkvo_sp1_encode_call.restype = C.c_size_t
+        L.zkvo_sp1_encode_call.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p]
+        L.zkvo_risc0_eth_call.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.zkvo_sp1_eth_call.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -96,6 +103,12 @@ class Risc0Oracle:
 
     def is_initialized(self):
         return bool(lib().zkvo_risc0_is_initialized(self._h))
+
+    def eth_call(self, calldata):
+        """One eth_call against the RISC Zero shell: (reverted, returndata, status or None)."""
+        ret = _buf(96); n = C.c_size_t(0); st = C.c_int(0)
+        rev = lib().zkvo_risc0_eth_call(self._h, bytes(calldata), len(calldata), ret, C.byref(n), C.byref(st))
+        return bool(rev), ret.raw[:n.value], (None if st.value < 0 else st.value)
 
     def verify_batch(self, seals, image_ids, journal_digests, threads=1):
         """seals: list of bytes; image_ids/journal_digests: list of 32-byte values. Returns (status bytes, recv bytes)."""
@@ -178,3 +191,26 @@ def status_abi_encode(vm, status, recv, exp):
 
 def fp_mulmod(a, b):
     o = _buf(32); lib().zkvo_fp_mulmod(bytes(a), bytes(b), o); return o.raw
+
+
+def keccak256(b):
+    o = _buf(32); lib().zkvo_keccak256(bytes(b), len(b), o); return o.raw
+
+
+def risc0_encode_call(seal, a, b=None):
+    """Canonical calldata of verify(seal, a, b) or, with b None, verifyIntegrity(seal, a)."""
+    n = lib().zkvo_risc0_encode_call(int(b is None), bytes(seal), len(seal), bytes(a), bytes(b or bytes(32)), None)
+    o = _buf(n); lib().zkvo_risc0_encode_call(int(b is None), bytes(seal), len(seal), bytes(a), bytes(b or bytes(32)), o)
+    return o.raw
+
+
+def sp1_encode_call(vkey, pv, proof):
+    n = lib().zkvo_sp1_encode_call(bytes(vkey), bytes(pv), len(pv), bytes(proof), len(proof), None)
+    o = _buf(n); lib().zkvo_sp1_encode_call(bytes(vkey), bytes(pv), len(pv), bytes(proof), len(proof), o)
+    return o.raw
+
+
+def sp1_eth_call(calldata):
+    ret = _buf(96); n = C.c_size_t(0); st = C.c_int(0)
+    rev = lib().zkvo_sp1_eth_call(bytes(calldata), len(calldata), ret, C.byref(n), C.byref(st))
+    return bool(rev), ret.raw[:n.value], (None if st.value < 0 else st.value)

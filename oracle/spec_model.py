@@ -34,6 +34,7 @@ B1 = 3
 
 # status codes of the C ABI (include/zkv.h) -- order of evaluation is the reference's
 OK, VERIFICATION_FAILED, INVALID_INITIALIZATION, ALREADY_INITIALIZED, INVALID_PROOF_DATA, SELECTOR_MISMATCH = range(6)
+BAD_CALLDATA = 6     # wire layer only: calldata the contract's router cannot decode (reverts with empty data)
 
 
 # ---------------------------------------------------------------- Fp2 (for curve arithmetic on the twist)
@@ -565,3 +566,147 @@ def vk_to_words(vk):
 
 def proof_to_words(a, b, c):
     return b''.join(be32(v) for v in (a[0], a[1], b[0][0], b[0][1], b[1][0], b[1][1], c[0], c[1]))
+
+
+# ---------------------------------------------------------------- on-chain wire layer
+# What a client of the deployed Stylus contracts sends and receives: `eth_call` calldata for the methods the
+# example shells export (examples/risc0-verifier/src/lib.rs, examples/risc0-verifier/examples/interact.rs:31-43,
+# examples/sp1-verifier/examples/interact.rs:11-19).  Stylus maps `Vec<u8>` to `uint8[]` (one 32-byte word per
+# byte) and snake_case method names to camelCase.  UNPINNED: the Stylus router (stylus-sdk 0.9.0) is not in the
+# container; modelled as "decode with alloy-sol-types 0.8.20 abi_decode_params(validate = true)", i.e. calldata
+# must equal the canonical ABI encoding of what it decodes to, and any decode failure or unknown function
+# selector reverts with empty data.
+
+_KECCAK_RC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808A, 0x8000000080008000, 0x000000000000808B,
+              0x0000000080000001, 0x8000000080008081, 0x8000000000008009, 0x000000000000008A, 0x0000000000000088,
+              0x0000000080008009, 0x000000008000000A, 0x000000008000808B, 0x800000000000008B, 0x8000000000008089,
+              0x8000000000008003, 0x8000000000008002, 0x8000000000000080, 0x000000000000800A, 0x800000008000000A,
+              0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+_KECCAK_ROT = [[0, 36, 3, 41, 18], [1, 44, 10, 45, 2], [62, 6, 43, 15, 61], [28, 55, 25, 21, 56], [27, 20, 39, 8, 14]]
+_M64 = (1 << 64) - 1
+
+def _rol64(x, n): return ((x << n) | (x >> (64 - n))) & _M64 if n else x
+
+def _keccak_f(s):
+    for rc in _KECCAK_RC:
+        c = [s[x][0] ^ s[x][1] ^ s[x][2] ^ s[x][3] ^ s[x][4] for x in range(5)]
+        d = [c[(x - 1) % 5] ^ _rol64(c[(x + 1) % 5], 1) for x in range(5)]
+        s = [[s[x][y] ^ d[x] for y in range(5)] for x in range(5)]
+        b = [[0] * 5 for _ in range(5)]
+        for x in range(5):
+            for y in range(5):
+                b[y][(2 * x + 3 * y) % 5] = _rol64(s[x][y], _KECCAK_ROT[x][y])
+        s = [[b[x][y] ^ ((~b[(x + 1) % 5][y]) & b[(x + 2) % 5][y]) for y in range(5)] for x in range(5)]
+        s[0][0] ^= rc
+    return s
+
+def keccak256(data):
+    """Keccak-256 (original padding 0x01, as used by Ethereum), rate 136."""
+    rate = 136
+    msg = bytearray(data) + b'\x01' + bytes((-len(data) - 2) % rate) + b'\x80' if (len(data) + 1) % rate else bytearray(data) + b'\x81'
+    s = [[0] * 5 for _ in range(5)]
+    for off in range(0, len(msg), rate):
+        for i in range(rate // 8):
+            s[i % 5][i // 5] ^= int.from_bytes(msg[off + 8 * i:off + 8 * i + 8], 'little')
+        s = _keccak_f(s)
+    return b''.join(s[i % 5][i // 5].to_bytes(8, 'little') for i in range(4))
+
+def fn_selector(signature): return keccak256(signature.encode())[:4]
+
+RISC0_FUNCTIONS = ['initialize(bytes32,bytes32)', 'verify(uint8[],bytes32,bytes32)', 'verifyIntegrity(uint8[],bytes32)',
+                   'isInitialized()', 'getSelector()', 'getControlRoot()', 'getBn254ControlId()', 'getVerifierKeyDigest()']
+SP1_FUNCTIONS = ['verifyProof(bytes32,uint8[],uint8[])', 'verifierHash()', 'version()']
+
+def _u8_array_words(b): return be32(len(b)) + b''.join(be32(x) for x in b)
+
+def encode_risc0_verify(seal, image_id, journal_digest):
+    return fn_selector(RISC0_FUNCTIONS[1]) + be32(0x60) + image_id + journal_digest + _u8_array_words(seal)
+
+def encode_risc0_verify_integrity(seal, claim_digest):
+    return fn_selector(RISC0_FUNCTIONS[2]) + be32(0x40) + claim_digest + _u8_array_words(seal)
+
+def encode_risc0_initialize(control_root, bn254_control_id):
+    return fn_selector(RISC0_FUNCTIONS[0]) + control_root + bn254_control_id
+
+def encode_sp1_verify_proof(program_vkey, public_values, proof_bytes):
+    return (fn_selector(SP1_FUNCTIONS[0]) + program_vkey + be32(0x60) + be32(0x60 + 32 + 32 * len(public_values)) +
+            _u8_array_words(public_values) + _u8_array_words(proof_bytes))
+
+def _decode_u8_array(args, head_word):
+    """Lenient structural decode of one uint8[]; canonical form is enforced by the caller through re-encoding."""
+    off = int.from_bytes(args[32 * head_word:32 * head_word + 32], 'big')
+    if off + 32 > len(args):
+        return None
+    n = int.from_bytes(args[off:off + 32], 'big')
+    if off + 32 + 32 * n > len(args):
+        return None
+    out = bytearray()
+    for i in range(n):
+        w = int.from_bytes(args[off + 32 + 32 * i:off + 64 + 32 * i], 'big')
+        if w > 255:
+            return None
+        out.append(w)
+    return bytes(out)
+
+def _left(b): return bytes(b).ljust(32, b'\0')
+
+def risc0_eth_call(verifier, calldata):
+    """One eth_call against the RISC Zero shell: returns (reverted, returndata, status) with status = the verifier's
+    status for verify / verifyIntegrity calls, BAD_CALLDATA for undecodable calldata, None for other methods."""
+    if len(calldata) < 4:
+        return True, b'', BAD_CALLDATA
+    sel, args = bytes(calldata[:4]), bytes(calldata[4:])
+    sels = [fn_selector(s) for s in RISC0_FUNCTIONS]
+    if sel not in sels:
+        return True, b'', BAD_CALLDATA
+    k = sels.index(sel)
+    if k in (1, 2):
+        nhead = 3 if k == 1 else 2
+        seal = _decode_u8_array(args, 0) if len(args) >= 32 * nhead else None
+        if seal is None:
+            return True, b'', BAD_CALLDATA
+        a, b = args[32:64], args[64:96]
+        canon = encode_risc0_verify(seal, a, b) if k == 1 else encode_risc0_verify_integrity(seal, a)
+        if canon != bytes(calldata):
+            return True, b'', BAD_CALLDATA
+        st, recv = verifier.verify(seal, a, b) if k == 1 else verifier.verify_integrity(seal, a)
+        if st == OK:
+            return False, be32(1), st
+        return True, revert_bytes('risc0', st, recv, verifier.selector), st
+    if k == 0:
+        if len(args) != 64:
+            return True, b'', BAD_CALLDATA
+        if verifier.initialized:
+            return True, revert_bytes('risc0', ALREADY_INITIALIZED), None
+        return False, b'', None                      # eth_call simulates; state is not kept
+    if len(args) != 0:
+        return True, b'', BAD_CALLDATA
+    if k == 3: return False, be32(1 if verifier.initialized else 0), None
+    if k == 4: return False, _left(verifier.selector), None
+    if k == 5: return False, _left(verifier.control_root_0) + _left(verifier.control_root_1), None
+    if k == 6: return False, bytes(verifier.bn254_control_id), None
+    return False, risc0_vk_digest(), None
+
+def sp1_eth_call(calldata):
+    if len(calldata) < 4:
+        return True, b'', BAD_CALLDATA
+    sel, args = bytes(calldata[:4]), bytes(calldata[4:])
+    sels = [fn_selector(s) for s in SP1_FUNCTIONS]
+    if sel not in sels:
+        return True, b'', BAD_CALLDATA
+    k = sels.index(sel)
+    if k == 0:
+        if len(args) < 96:
+            return True, b'', BAD_CALLDATA
+        pv, proof = _decode_u8_array(args, 1), _decode_u8_array(args, 2)
+        if pv is None or proof is None or encode_sp1_verify_proof(args[:32], pv, proof) != bytes(calldata):
+            return True, b'', BAD_CALLDATA
+        st, recv = sp1_verify_proof(args[:32], pv, proof)
+        if st == OK:
+            return False, b'', st
+        return True, revert_bytes('sp1', st, recv, SP1_VERIFIER_HASH[:4]), st
+    if len(args) != 0:
+        return True, b'', BAD_CALLDATA
+    if k == 1: return False, SP1_VERIFIER_HASH, None
+    v = SP1_VERSION.encode()
+    return False, be32(0x20) + be32(len(v)) + v.ljust(32, b'\0'), None

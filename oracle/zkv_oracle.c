@@ -833,6 +833,175 @@ ZKVO_API int zkvo_status_abi_encode(int vm, int status, const uint8_t recv[4], c
     memcpy(out, sel[status], 4); return 4;
 }
 
+/* ------------------------------------------------------------------ on-chain wire layer
+ * eth_call calldata of the example shells (examples/risc0-verifier/src/lib.rs, examples/risc0-verifier/examples/interact.rs:31-43,
+ * examples/sp1-verifier/examples/interact.rs:11-19): Vec<u8> travels as uint8[] (one 32-byte word per byte).  UNPINNED: the Stylus
+ * router is not in the container; modelled as alloy-sol-types 0.8.20 abi_decode_params(validate = true) -- decode, re-encode, require
+ * byte equality -- with decode failures and unknown function selectors reverting with empty data. */
+#define ST_BAD_CALLDATA 6
+static const uint64_t KECCAK_RC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL, 0x000000000000808BULL, 0x0000000080000001ULL,
+    0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008AULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000AULL,
+    0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL, 0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL,
+    0x000000000000800AULL, 0x800000008000000AULL, 0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+static void keccak_f(uint64_t a[25]) {
+    static const int rot[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    for (int r = 0; r < 24; r++) {
+        uint64_t c[5], b[25];
+        for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+        for (int x = 0; x < 5; x++) {
+            uint64_t t = c[(x + 1) % 5], d = c[(x + 4) % 5] ^ ((t << 1) | (t >> 63));
+            for (int y = 0; y < 25; y += 5) a[x + y] ^= d;
+        }
+        for (int x = 0; x < 5; x++) for (int y = 0; y < 5; y++) {
+            uint64_t v = a[x + 5 * y]; int n = rot[x + 5 * y];
+            b[y + 5 * ((2 * x + 3 * y) % 5)] = n ? (v << n) | (v >> (64 - n)) : v;
+        }
+        for (int x = 0; x < 5; x++) for (int y = 0; y < 25; y += 5) a[x + y] = b[x + y] ^ (~b[(x + 1) % 5 + y] & b[(x + 2) % 5 + y]);
+        a[0] ^= KECCAK_RC[r];
+    }
+}
+ZKVO_API void zkvo_keccak256(const uint8_t *msg, size_t len, uint8_t out[32]) {
+    uint64_t a[25]; uint8_t blk[136];
+    memset(a, 0, sizeof a);
+    for (;;) {
+        size_t take = len < 136 ? len : 136;
+        memset(blk, 0, 136); memcpy(blk, msg, take);
+        int last = take < 136;
+        if (last) { blk[take] ^= 0x01; blk[135] ^= 0x80; }
+        for (int i = 0; i < 17; i++) { uint64_t w = 0; for (int k = 7; k >= 0; k--) w = (w << 8) | blk[8 * i + k]; a[i] ^= w; }
+        keccak_f(a);
+        if (last) break;
+        msg += take; len -= take;
+    }
+    for (int i = 0; i < 4; i++) for (int k = 0; k < 8; k++) out[8 * i + k] = (uint8_t)(a[i] >> (8 * k));
+}
+static void fn_selector(const char *sig, uint8_t out[4]) { uint8_t h[32]; zkvo_keccak256((const uint8_t *)sig, strlen(sig), h); memcpy(out, h, 4); }
+/* big-endian word -> size_t, or (size_t)-1 when it does not fit 32 bits */
+static size_t word_small(const uint8_t *w) {
+    for (int i = 0; i < 28; i++) if (w[i]) return (size_t)-1;
+    return ((size_t)w[28] << 24) | ((size_t)w[29] << 16) | ((size_t)w[30] << 8) | w[31];
+}
+/* decode the uint8[] whose offset sits in head word `hw`; returns a malloc'd byte string or NULL */
+static uint8_t *decode_u8_array(const uint8_t *args, size_t alen, int hw, size_t *n_out) {
+    size_t off = word_small(args + 32 * hw);
+    if (off == (size_t)-1 || off + 32 > alen) return NULL;
+    size_t n = word_small(args + off);
+    if (n == (size_t)-1 || (alen - off - 32) / 32 < n) return NULL;
+    uint8_t *out = (uint8_t *)malloc(n + 1);
+    for (size_t i = 0; i < n; i++) {
+        size_t v = word_small(args + off + 32 + 32 * i);
+        if (v > 255) { free(out); return NULL; }
+        out[i] = (uint8_t)v;
+    }
+    *n_out = n;
+    return out;
+}
+static void put_word(uint8_t *p, size_t v) { memset(p, 0, 32); p[28] = (uint8_t)(v >> 24); p[29] = (uint8_t)(v >> 16); p[30] = (uint8_t)(v >> 8); p[31] = (uint8_t)v; }
+static size_t put_u8_array(uint8_t *p, const uint8_t *b, size_t n) {
+    put_word(p, n);
+    for (size_t i = 0; i < n; i++) put_word(p + 32 + 32 * i, b[i]);
+    return 32 + 32 * n;
+}
+/* canonical calldata of verify (integrity = 0) / verifyIntegrity (1); out == NULL only returns the length */
+ZKVO_API size_t zkvo_risc0_encode_call(int integrity, const uint8_t *seal, size_t seal_len, const uint8_t a[32], const uint8_t b[32], uint8_t *out) {
+    size_t nh = integrity ? 2 : 3, len = 4 + 32 * nh + 32 + 32 * seal_len;
+    if (!out) return len;
+    fn_selector(integrity ? "verifyIntegrity(uint8[],bytes32)" : "verify(uint8[],bytes32,bytes32)", out);
+    put_word(out + 4, 32 * nh); memcpy(out + 36, a, 32);
+    if (!integrity) memcpy(out + 68, b, 32);
+    put_u8_array(out + 4 + 32 * nh, seal, seal_len);
+    return len;
+}
+ZKVO_API size_t zkvo_sp1_encode_call(const uint8_t vkey[32], const uint8_t *pv, size_t pv_len, const uint8_t *proof, size_t proof_len, uint8_t *out) {
+    size_t len = 4 + 96 + 32 + 32 * pv_len + 32 + 32 * proof_len;
+    if (!out) return len;
+    fn_selector("verifyProof(bytes32,uint8[],uint8[])", out);
+    memcpy(out + 4, vkey, 32); put_word(out + 36, 0x60); put_word(out + 68, 0x60 + 32 + 32 * pv_len);
+    size_t k = put_u8_array(out + 100, pv, pv_len);
+    put_u8_array(out + 100 + k, proof, proof_len);
+    return len;
+}
+static void left32(uint8_t *out, const uint8_t *b, size_t n) { memset(out, 0, 32); memcpy(out, b, n); }
+/* One eth_call against the RISC Zero shell.  ret (>= 96 bytes) receives the return / revert data; *status the verifier status
+ * (ST_BAD_CALLDATA for undecodable calldata, -1 for non-verify methods).  Returns 1 when the call reverts. */
+ZKVO_API int zkvo_risc0_eth_call(const zkvo_risc0 *v, const uint8_t *cd, size_t len, uint8_t *ret, size_t *ret_len, int *status) {
+    static const char *sigs[8] = {"initialize(bytes32,bytes32)", "verify(uint8[],bytes32,bytes32)", "verifyIntegrity(uint8[],bytes32)", "isInitialized()",
+                                  "getSelector()", "getControlRoot()", "getBn254ControlId()", "getVerifierKeyDigest()"};
+    *ret_len = 0; *status = ST_BAD_CALLDATA;
+    if (len < 4) return 1;
+    int k = -1;
+    for (int i = 0; i < 8; i++) { uint8_t s[4]; fn_selector(sigs[i], s); if (!memcmp(s, cd, 4)) k = i; }
+    if (k < 0) return 1;
+    const uint8_t *args = cd + 4; size_t alen = len - 4;
+    if (k == 1 || k == 2) {
+        size_t nh = k == 1 ? 3 : 2, n = 0;
+        if (alen < 32 * nh) return 1;
+        uint8_t *seal = decode_u8_array(args, alen, 0, &n);
+        if (!seal) return 1;
+        size_t clen = zkvo_risc0_encode_call(k == 2, seal, n, args + 32, args + 64, NULL);
+        int same = 0;
+        if (clen == len) { uint8_t *canon = (uint8_t *)malloc(clen); zkvo_risc0_encode_call(k == 2, seal, n, args + 32, args + 64, canon); same = !memcmp(canon, cd, len); free(canon); }
+        if (!same) { free(seal); return 1; }
+        uint8_t recv[4] = {0, 0, 0, 0};
+        int st = k == 1 ? zkvo_risc0_verify(v, seal, n, args + 32, args + 64, recv) : zkvo_risc0_verify_integrity(v, seal, n, args + 32, recv);
+        free(seal);
+        *status = st;
+        if (st == ST_OK) { put_word(ret, 1); *ret_len = 32; return 0; }
+        *ret_len = (size_t)zkvo_status_abi_encode(0, st, recv, v->selector, ret);
+        return 1;
+    }
+    *status = -1;
+    if (k == 0) {
+        if (alen != 64) { *status = ST_BAD_CALLDATA; return 1; }
+        if (v->initialized) { *ret_len = (size_t)zkvo_status_abi_encode(0, ST_ALREADY_INITIALIZED, NULL, NULL, ret); return 1; }
+        return 0;
+    }
+    if (alen != 0) { *status = ST_BAD_CALLDATA; return 1; }
+    *ret_len = 32;
+    if (k == 3) put_word(ret, v->initialized ? 1 : 0);
+    else if (k == 4) left32(ret, v->selector, 4);
+    else if (k == 5) { left32(ret, v->control_root_0, 16); left32(ret + 32, v->control_root_1, 16); *ret_len = 64; }
+    else if (k == 6) memcpy(ret, v->bn254_control_id, 32);
+    else zkvo_risc0_vk_digest(ret);
+    return 0;
+}
+ZKVO_API int zkvo_sp1_eth_call(const uint8_t *cd, size_t len, uint8_t *ret, size_t *ret_len, int *status) {
+    static const char *sigs[3] = {"verifyProof(bytes32,uint8[],uint8[])", "verifierHash()", "version()"};
+    *ret_len = 0; *status = ST_BAD_CALLDATA;
+    if (len < 4) return 1;
+    int k = -1;
+    for (int i = 0; i < 3; i++) { uint8_t s[4]; fn_selector(sigs[i], s); if (!memcmp(s, cd, 4)) k = i; }
+    if (k < 0) return 1;
+    const uint8_t *args = cd + 4; size_t alen = len - 4;
+    if (k == 0) {
+        size_t npv = 0, npr = 0;
+        if (alen < 96) return 1;
+        uint8_t *pv = decode_u8_array(args, alen, 1, &npv);
+        if (!pv) return 1;
+        uint8_t *proof = decode_u8_array(args, alen, 2, &npr);
+        if (!proof) { free(pv); return 1; }
+        int same = 0;
+        if (zkvo_sp1_encode_call(args, pv, npv, proof, npr, NULL) == len) {
+            uint8_t *canon = (uint8_t *)malloc(len); zkvo_sp1_encode_call(args, pv, npv, proof, npr, canon); same = !memcmp(canon, cd, len); free(canon);
+        }
+        int st = ST_BAD_CALLDATA; uint8_t recv[4] = {0, 0, 0, 0};
+        if (same) st = zkvo_sp1_verify_proof(args, pv, npv, proof, npr, recv);
+        free(pv); free(proof);
+        if (!same) return 1;
+        *status = st;
+        if (st == ST_OK) return 0;
+        *ret_len = (size_t)zkvo_status_abi_encode(1, st, recv, SP1_VERIFIER_HASH, ret);
+        return 1;
+    }
+    *status = -1;
+    if (alen != 0) { *status = ST_BAD_CALLDATA; return 1; }
+    if (k == 1) { memcpy(ret, SP1_VERIFIER_HASH, 32); *ret_len = 32; return 0; }
+    const char *ver = zkvo_sp1_version();
+    put_word(ret, 0x20); put_word(ret + 32, strlen(ver)); memset(ret + 64, 0, 32); memcpy(ret + 64, ver, strlen(ver)); *ret_len = 96;
+    return 0;
+}
+
 /* ------------------------------------------------------------------ batch drivers (timed CPU baseline; OpenMP over proofs) */
 ZKVO_API int zkvo_risc0_verify_batch(const zkvo_risc0 *v, size_t n, const uint8_t *seals, const uint64_t *seal_off,
                                      const uint8_t *image_ids, const uint8_t *journal_digests, uint8_t *status, uint8_t *recv, int threads) {

@@ -9,8 +9,9 @@ from .risc0 import RiscZeroVerifier
 from .sp1 import Sp1Verifier
 from .bn254 import Bn254Precompiles
 from .groth16 import Groth16Verifier
+from . import wire
 
-__all__ = ['RiscZeroVerifier', 'Sp1Verifier', 'Bn254Precompiles', 'Groth16Verifier', 'VerifierError', 'errors', 'device_count']
+__all__ = ['RiscZeroVerifier', 'Sp1Verifier', 'Bn254Precompiles', 'Groth16Verifier', 'VerifierError', 'errors', 'wire', 'device_count']
 
 
 def device_count():

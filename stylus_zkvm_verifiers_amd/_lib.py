@@ -47,6 +47,15 @@ SYMBOLS = {
     'zkv_ctx_synchronize': (_i, [_vp]),
     'zkv_ctx_last_stage_ms': (_i, [_vp, C.POINTER(C.c_float)]),
     'zkv_status_abi_encode': (_i, [_i, C.c_uint8, _cp, _cp, _cp]),
+    'zkv_abi_function_selector': (_i, [_cp, _cp]),
+    'zkv_risc0_encode_verify_call': (_sz, [_cp, _sz, _cp, _cp, _cp, _sz]),
+    'zkv_risc0_encode_verify_integrity_call': (_sz, [_cp, _sz, _cp, _cp, _sz]),
+    'zkv_sp1_encode_verify_proof_call': (_sz, [_cp, _cp, _sz, _cp, _sz, _cp, _sz]),
+    'zkv_risc0_eth_call_batch': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'zkv_sp1_eth_call_batch': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'zkv_eth_call_batch_dev': (_i, [_vp, _sz, _vp, _vp, C.c_uint64, _vp, _vp, _vp]),
+    'zkv_eth_call_returndata': (_i, [_vp, C.c_uint8, _cp, _cp, C.POINTER(C.c_uint32), _u8p]),
+    'zkv_ctx_last_wire_ms': (_i, [_vp, C.POINTER(C.c_float)]),
 }
 
 

@@ -49,12 +49,14 @@ __device__ __forceinline__ bool front_checks(const PrepArgs& a, size_t i, bool s
     rd.lds_row = nullptr;
     if (a.off) { rd.rec = a.blob + a.off[i]; len = (size_t)(a.off[i + 1] - a.off[i]); }
     else {
-        rd.rec = a.blob + i * (size_t)a.stride; len = a.stride;
+        rd.rec = a.blob + i * (size_t)a.stride; len = a.len ? a.len[i] : a.stride;
         if (staged) rd.lds_row = lds + threadIdx.x * 65u;
     }
     uint32_t rv = 0;
     bool go = false;
-    if (len < 4) st = ST_INVALID_PROOF_DATA;                       // verifier.rs:151 / sp1 verifier.rs:64
+    if (a.len && len == 0xFFFFFFFFu) st = ST_BAD_CALLDATA;         // wire layer: the router could not decode the call
+    else if (a.not_initialized) st = ST_INVALID_INITIALIZATION;     // risc0/verifier.rs:84-86, 99-101
+    else if (len < 4) st = ST_INVALID_PROOF_DATA;                       // verifier.rs:151 / sp1 verifier.rs:64
     else {
         uint32_t sel = rd.word(0);
         if (sel != a.selector_be) { st = ST_SELECTOR_MISMATCH; rv = sel; }        // :155-165 / :68-78
@@ -80,7 +82,8 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_prep_risc0(PrepArgs a, Risc0Const
         PrepOut o;
         for (int b = 2; b < MAX_VAR; b++) for (int k2 = 0; k2 < 8; k2++) o.s[b][k2] = 0;
         uint32_t h[8];
-        if (a.in32_b) risc0_claim_digest(k, a.in32_a + 32 * i, a.in32_b + 32 * i, h);
+        const bool integrity = a.kind ? a.kind[i] != 0 : a.in32_b == nullptr;
+        if (!integrity) risc0_claim_digest(k, a.in32_a + 32 * i, a.in32_b + 32 * i, h);
         else {
 #pragma unroll 1
             for (int j = 0; j < 8; j++) h[j] = load_be32(a.in32_a + 32 * i + 4 * j);
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_prep_sp1(PrepArgs a, Workspace ws
         for (int b = 2; b < MAX_VAR; b++) for (int k2 = 0; k2 < 8; k2++) o.s[b][k2] = 0;
         load_be256(o.s[0], a.in32_a + 32 * i);                      // U256::from_be_bytes(program_vkey), sp1/types.rs:24
         const uint8_t* pv; size_t pvl;
-        if (a.pv_off) { pv = a.pv_blob + a.pv_off[i]; pvl = (size_t)(a.pv_off[i + 1] - a.pv_off[i]); }
+        if (a.pv_len) { pv = a.pv_blob + a.pv_off[i]; pvl = a.pv_len[i]; }
+        else if (a.pv_off) { pv = a.pv_blob + a.pv_off[i]; pvl = (size_t)(a.pv_off[i + 1] - a.pv_off[i]); }
         else { pv = a.pv_blob + i * (size_t)a.pv_stride; pvl = a.pv_stride; }
         uint32_t h[8];
         sha256_bytes(pv, pvl, h);

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/zkv.h"
+#include "zkv_host_abi.h"
 #include "zkv_host_vk.h"
 #include "zkv_internal.h"
 
@@ -31,7 +32,13 @@ struct zkv_ctx {
     uint8_t *d_blob = nullptr, *d_a = nullptr, *d_b = nullptr, *d_pv = nullptr, *d_status = nullptr, *d_recv = nullptr;
     uint64_t *d_off = nullptr, *d_pvoff = nullptr;
     size_t blob_cap = 0, pv_cap = 0;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // wire layer (eth_call batches): calldata blob, its offsets, decoded lengths / methods
+    uint8_t *d_cd = nullptr, *d_kind = nullptr;
+    uint64_t* d_cdoff = nullptr;
+    uint32_t *d_len = nullptr, *d_pvlen = nullptr;
+    size_t cd_cap = 0;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ev_wire[2] = {nullptr, nullptr};
+    bool wire_timed = false;
     std::mutex mu;
 };
 
@@ -70,9 +77,10 @@ static void ctx_free_device(zkv_ctx* c) {
     if (!c->dev_ready && !c->stream) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_tab, c->ws.prep, c->ws.norm, c->ws.f, c->ws.fe, c->ws.flags, c->d_blob, c->d_a, c->d_b, c->d_pv,
-                    c->d_status, c->d_recv, c->d_off, c->d_pvoff};
+                    c->d_status, c->d_recv, c->d_off, c->d_pvoff, c->d_cd, c->d_kind, c->d_cdoff, c->d_len, c->d_pvlen};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_wire) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     c->dev_ready = false; c->stream = nullptr;
 }
@@ -86,6 +94,7 @@ static int ctx_device_init(zkv_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto& e : c->ev_wire) HIP_TRY(hipEventCreate(&e));
     if (c->vm != ZKV_VM_BN254) {
         VkRaw raw;
         if (c->vm == ZKV_VM_RISC0) host::fill_vk_risc0(raw, c->control_root_0, c->control_root_1, c->control_id);
@@ -348,6 +357,215 @@ ZKV_EXPORT int zkv_sp1_verify_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d_v
     if (!c || c->vm != ZKV_VM_SP1) return ZKV_ERR_WRONG_CTX;
     if (n && !d_pv) return ZKV_ERR_INVALID_ARG;
     return run_dev_batch(c, n, d_proofs, d_vkeys, nullptr, d_pv, pv_len, d_status, d_recv, stream);
+}
+
+// ------------------------------------------------------------------ on-chain wire layer (eth_call batches)
+ZKV_EXPORT int zkv_abi_function_selector(const char* signature, uint8_t out[4]) {
+    if (!signature || !out) return ZKV_ERR_INVALID_ARG;
+    host::fn_selector(signature, out);
+    return ZKV_OK;
+}
+ZKV_EXPORT size_t zkv_risc0_encode_verify_call(const uint8_t* seal, size_t seal_len, const uint8_t image_id[32], const uint8_t journal_digest[32],
+                                               uint8_t* out, size_t cap) {
+    const size_t need = 4 + 96 + 32 * (seal_len + 1);
+    if (!out || cap < need || (seal_len && !seal) || !image_id || !journal_digest) return need;
+    memcpy(out, host::selectors().risc0[host::R0_VERIFY], 4);
+    host::abi_word_u32(out + 4, 0x60); memcpy(out + 36, image_id, 32); memcpy(out + 68, journal_digest, 32);
+    host::abi_u8_array(out + 100, seal, seal_len);
+    return need;
+}
+ZKV_EXPORT size_t zkv_risc0_encode_verify_integrity_call(const uint8_t* seal, size_t seal_len, const uint8_t claim_digest[32], uint8_t* out, size_t cap) {
+    const size_t need = 4 + 64 + 32 * (seal_len + 1);
+    if (!out || cap < need || (seal_len && !seal) || !claim_digest) return need;
+    memcpy(out, host::selectors().risc0[host::R0_VERIFY_INTEGRITY], 4);
+    host::abi_word_u32(out + 4, 0x40); memcpy(out + 36, claim_digest, 32);
+    host::abi_u8_array(out + 68, seal, seal_len);
+    return need;
+}
+ZKV_EXPORT size_t zkv_sp1_encode_verify_proof_call(const uint8_t program_vkey[32], const uint8_t* pv, size_t pv_len, const uint8_t* proof, size_t proof_len,
+                                                   uint8_t* out, size_t cap) {
+    const size_t need = 4 + 96 + 32 * (pv_len + 1) + 32 * (proof_len + 1);
+    if (!out || cap < need || (pv_len && !pv) || (proof_len && !proof) || !program_vkey) return need;
+    memcpy(out, host::selectors().sp1[host::SP1_VERIFY_PROOF], 4);
+    memcpy(out + 4, program_vkey, 32); host::abi_word_u32(out + 36, 0x60); host::abi_word_u32(out + 68, 0x80 + 32 * (uint64_t)pv_len);
+    size_t k = host::abi_u8_array(out + 100, pv, pv_len);
+    host::abi_u8_array(out + 100 + k, proof, proof_len);
+    return need;
+}
+
+// Return / revert data of a verify-class call from its status (success: `true` word for RISC Zero, nothing for SP1).
+static void verify_returndata(const zkv_ctx* c, uint8_t st, const uint8_t* recv, uint8_t* out, uint32_t* out_len, uint8_t* reverted) {
+    if (st == ZKV_STATUS_OK) {
+        *reverted = 0;
+        if (c->vm == ZKV_VM_RISC0) { host::abi_word_u32(out, 1); *out_len = 32; } else *out_len = 0;
+        return;
+    }
+    *reverted = 1;
+    if (st == ZKV_STATUS_BAD_CALLDATA) { *out_len = 0; return; }
+    int k = zkv_status_abi_encode(c->vm, st, recv, c->vm == ZKV_VM_RISC0 ? c->selector : host::SP1_VERIFIER_HASH, out);
+    *out_len = k > 0 ? (uint32_t)k : 0;
+}
+// Calls the device left as BAD_CALLDATA: either one of the constant-size methods (answered here) or really undecodable.
+static void host_method(const zkv_ctx* c, const uint8_t* cd, size_t len, uint8_t* out, uint32_t* out_len, uint8_t* reverted) {
+    *out_len = 0; *reverted = 1;
+    if (len < 4) return;
+    const host::Selectors& S = host::selectors();
+    if (c->vm == ZKV_VM_RISC0) {
+        int k = -1;
+        for (int i = 0; i < host::R0_COUNT; i++) if (!memcmp(S.risc0[i], cd, 4)) k = i;
+        if (k < 0 || k == host::R0_VERIFY || k == host::R0_VERIFY_INTEGRITY) return;
+        if (k == host::R0_INITIALIZE) {                      // eth_call simulates the transaction; nothing is stored
+            if (len != 4 + 64) return;
+            if (c->initialized) *out_len = (uint32_t)zkv_status_abi_encode(ZKV_VM_RISC0, ZKV_STATUS_ALREADY_INITIALIZED, nullptr, nullptr, out);
+            else *reverted = 0;
+            return;
+        }
+        if (len != 4) return;
+        *reverted = 0; *out_len = 32;
+        if (k == host::R0_IS_INITIALIZED) host::abi_word_u32(out, c->initialized ? 1 : 0);
+        else if (k == host::R0_GET_SELECTOR) host::abi_word_left(out, c->selector, 4);
+        else if (k == host::R0_GET_CONTROL_ROOT) { host::abi_word_left(out, c->control_root_0, 16); host::abi_word_left(out + 32, c->control_root_1, 16); *out_len = 64; }
+        else if (k == host::R0_GET_BN254_CONTROL_ID) memcpy(out, c->control_id, 32);
+        else host::risc0_vk_digest(out);
+    } else {
+        int k = -1;
+        for (int i = 0; i < host::SP1_COUNT; i++) if (!memcmp(S.sp1[i], cd, 4)) k = i;
+        if (k <= host::SP1_VERIFY_PROOF || len != 4) return;
+        *reverted = 0;
+        if (k == host::SP1_FN_VERIFIER_HASH) { memcpy(out, host::SP1_VERIFIER_HASH, 32); *out_len = 32; return; }
+        const size_t vl = strlen(host::SP1_VERSION);
+        host::abi_word_u32(out, 0x20); host::abi_word_u32(out + 32, vl); memset(out + 64, 0, 32); memcpy(out + 64, host::SP1_VERSION, vl);
+        *out_len = 96;
+    }
+}
+
+// Decode + verify one chunk whose calldata and offsets are already on the device.
+static int enqueue_wire_chunk(zkv_ctx* c, size_t m, const uint8_t* d_cd, const uint64_t* d_cdoff, uint64_t cd_bytes, uint8_t* d_status, uint8_t* d_recv,
+                              hipStream_t s, bool timed) {
+    int rc;
+    if ((rc = grow(&c->d_blob, &c->blob_cap, m * ZKV_SEAL_BYTES + 8)) != ZKV_OK) return rc;
+    if (c->vm == ZKV_VM_SP1 && (rc = grow(&c->d_pv, &c->pv_cap, (size_t)(cd_bytes / 32) + 64)) != ZKV_OK) return rc;
+    const host::Selectors& S = host::selectors();
+    WireArgs w;
+    memset(&w, 0, sizeof w);
+    w.n = m; w.cd = d_cd; w.off = d_cdoff;
+    w.seals = c->d_blob; w.seal_len = c->d_len; w.in_a = c->d_a; w.in_b = c->d_b; w.kind = c->d_kind;
+    w.pv = c->d_pv; w.pv_off = c->d_pvoff; w.pv_len = c->d_pvlen;
+    if (timed) (void)hipEventRecord(c->ev_wire[0], s);
+    if (c->vm == ZKV_VM_RISC0) {
+        w.sel_a_be = be32_of(S.risc0[host::R0_VERIFY]); w.sel_b_be = be32_of(S.risc0[host::R0_VERIFY_INTEGRITY]);
+        launch_wire_risc0(w, s);
+    } else {
+        w.sel_a_be = be32_of(S.sp1[host::SP1_VERIFY_PROOF]);
+        launch_wire_sp1(w, s);
+    }
+    if (timed) { (void)hipEventRecord(c->ev_wire[1], s); c->wire_timed = true; }
+    PrepArgs a;
+    memset(&a, 0, sizeof a);
+    a.n = m; a.blob = c->d_blob; a.off = nullptr; a.stride = ZKV_SEAL_BYTES; a.len = c->d_len;
+    a.in32_a = c->d_a;
+    if (c->vm == ZKV_VM_RISC0) {
+        a.in32_b = c->d_b; a.kind = c->d_kind;
+        a.selector_be = be32_of(c->selector);
+        a.force_fail = c->id_ge_r ? 1u : 0u;
+        a.not_initialized = c->initialized ? 0u : 1u;
+    } else {
+        a.pv_blob = c->d_pv; a.pv_off = c->d_pvoff; a.pv_len = c->d_pvlen;
+        a.selector_be = be32_of(host::SP1_VERIFIER_HASH);
+    }
+    a.status = d_status; a.recv = d_recv;
+    enqueue_chunk(c, a, s, timed);
+    return ZKV_OK;
+}
+static int wire_buffers(zkv_ctx* c) {
+    if (c->d_len) return ZKV_OK;
+    const size_t cap = c->ws.cap;
+    if (hipMalloc(&c->d_len, sizeof(uint32_t) * cap) != hipSuccess || hipMalloc(&c->d_pvlen, sizeof(uint32_t) * cap) != hipSuccess ||
+        hipMalloc(&c->d_kind, cap) != hipSuccess || hipMalloc(&c->d_cdoff, sizeof(uint64_t) * (cap + 1)) != hipSuccess) {
+        (void)hipGetLastError();
+        return ZKV_ERR_OOM;
+    }
+    return ZKV_OK;
+}
+
+static int run_eth_call_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const uint64_t* off, uint8_t* reverted, uint8_t* returndata,
+                              uint32_t* returndata_len, uint8_t* status) {
+    if (!c || (n && (!blob || !off || !reverted || !returndata || !returndata_len))) return ZKV_ERR_INVALID_ARG;
+    if (!n) return ZKV_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ctx_device_init(c);
+    if (rc != ZKV_OK) return rc;
+    if ((rc = wire_buffers(c)) != ZKV_OK) return rc;
+    const size_t cap = c->ws.cap;
+    std::vector<uint64_t> rel(cap + 1);
+    std::vector<uint8_t> st(cap), rv(4 * cap);
+    for (size_t base = 0; base < n; base += cap) {
+        size_t m = n - base < cap ? n - base : cap;
+        uint64_t b0 = off[base], bytes = off[base + m] - b0;
+        if ((rc = grow(&c->d_cd, &c->cd_cap, (size_t)bytes + 8)) != ZKV_OK) return rc;
+        for (size_t i = 0; i <= m; i++) rel[i] = off[base + i] - b0;
+        HIP_TRY(hipMemcpyAsync(c->d_cdoff, rel.data(), sizeof(uint64_t) * (m + 1), hipMemcpyHostToDevice, c->stream));
+        if (bytes) HIP_TRY(hipMemcpyAsync(c->d_cd, blob + b0, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+        if ((rc = enqueue_wire_chunk(c, m, c->d_cd, c->d_cdoff, bytes, c->d_status, c->d_recv, c->stream, true)) != ZKV_OK) return rc;
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(st.data(), c->d_status, m, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(rv.data(), c->d_recv, 4 * m, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < m; i++) {
+            uint8_t* out = returndata + (base + i) * ZKV_RETURNDATA_STRIDE;
+            if (st[i] == ZKV_STATUS_BAD_CALLDATA)
+                host_method(c, blob + off[base + i], (size_t)(off[base + i + 1] - off[base + i]), out, &returndata_len[base + i], &reverted[base + i]);
+            else verify_returndata(c, st[i], rv.data() + 4 * i, out, &returndata_len[base + i], &reverted[base + i]);
+            if (status) status[base + i] = st[i];
+        }
+    }
+    return ZKV_OK;
+}
+ZKV_EXPORT int zkv_risc0_eth_call_batch(zkv_ctx* c, size_t n, const uint8_t* calldata_blob, const uint64_t* calldata_off, uint8_t* reverted,
+                                        uint8_t* returndata, uint32_t* returndata_len, uint8_t* status) {
+    if (!c || c->vm != ZKV_VM_RISC0) return ZKV_ERR_WRONG_CTX;
+    return run_eth_call_batch(c, n, calldata_blob, calldata_off, reverted, returndata, returndata_len, status);
+}
+ZKV_EXPORT int zkv_sp1_eth_call_batch(zkv_ctx* c, size_t n, const uint8_t* calldata_blob, const uint64_t* calldata_off, uint8_t* reverted,
+                                      uint8_t* returndata, uint32_t* returndata_len, uint8_t* status) {
+    if (!c || c->vm != ZKV_VM_SP1) return ZKV_ERR_WRONG_CTX;
+    return run_eth_call_batch(c, n, calldata_blob, calldata_off, reverted, returndata, returndata_len, status);
+}
+// Device-resident calldata: verify-class calls only, statuses stay on the device.
+ZKV_EXPORT int zkv_eth_call_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d_calldata, const uint64_t* d_calldata_off, uint64_t calldata_bytes,
+                                      uint8_t* d_status, uint8_t* d_recv, void* stream) {
+    if (!c || (c->vm != ZKV_VM_RISC0 && c->vm != ZKV_VM_SP1)) return ZKV_ERR_WRONG_CTX;
+    if (n && (!d_calldata || !d_calldata_off || !d_status)) return ZKV_ERR_INVALID_ARG;
+    if (!n) return ZKV_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ctx_device_init(c);
+    if (rc != ZKV_OK) return rc;
+    if ((rc = wire_buffers(c)) != ZKV_OK) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const size_t cap = c->ws.cap;
+    for (size_t base = 0; base < n; base += cap) {
+        size_t m = n - base < cap ? n - base : cap;
+        // offsets are absolute into d_calldata, so chunks share the blob pointer; the public-values scratch is sized for the whole blob
+        if ((rc = enqueue_wire_chunk(c, m, d_calldata, d_calldata_off + base, calldata_bytes, d_status + base, d_recv ? d_recv + 4 * base : nullptr, s,
+                                     base + cap >= n)) != ZKV_OK) return rc;
+    }
+    HIP_TRY(hipGetLastError());
+    return ZKV_OK;
+}
+ZKV_EXPORT int zkv_eth_call_returndata(const zkv_ctx* c, uint8_t status, const uint8_t recv_selector[4], uint8_t out[ZKV_RETURNDATA_STRIDE],
+                                       uint32_t* out_len, uint8_t* reverted) {
+    static const uint8_t zero[4] = {0, 0, 0, 0};
+    if (!c || !out || !out_len || !reverted || (c->vm != ZKV_VM_RISC0 && c->vm != ZKV_VM_SP1) || status > ZKV_STATUS_BAD_CALLDATA) return ZKV_ERR_INVALID_ARG;
+    verify_returndata(c, status, recv_selector ? recv_selector : zero, out, out_len, reverted);
+    return ZKV_OK;
+}
+ZKV_EXPORT int zkv_ctx_last_wire_ms(zkv_ctx* c, float* out_ms) {
+    if (!c || !out_ms) return ZKV_ERR_INVALID_ARG;
+    if (!c->dev_ready || !c->wire_timed) return ZKV_ERR_NO_DEVICE;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev_wire[1]));
+    HIP_TRY(hipEventElapsedTime(out_ms, c->ev_wire[0], c->ev_wire[1]));
+    return ZKV_OK;
 }
 
 // ------------------------------------------------------------------ precompile-level batches

@@ -43,8 +43,30 @@ struct PrepArgs {
     uint32_t force_fail;        // context-level VerificationFailed (risc0 bn254_control_id >= R, invalid generic VK)
     uint32_t n_sig;             // generic Groth16 batches: signals per proof (in32_a holds n x n_sig x 32 bytes)
     uint32_t negate_a;          // generic Groth16 batches: VMType::Risc0 negates A
+    // wire-layer batches (k_wire.hip decodes calldata into fixed-stride records): per-proof decoded seal length
+    // (0xFFFFFFFF = undecodable calldata), per-proof method (1 = verifyIntegrity: in32_a is the claim digest) and
+    // per-proof public-values length (pv_off then holds n start offsets).
+    const uint32_t* len;
+    const uint8_t* kind;
+    const uint32_t* pv_len;
+    uint32_t not_initialized;   // wire-layer batches on an un-initialised RISC Zero verifier: decodable calls get InvalidInitialization
     uint8_t* status; uint8_t* recv;
 };
+
+// eth_call calldata decode (k_wire.hip): one wavefront per request.
+struct WireArgs {
+    size_t n;
+    const uint8_t* cd;          // calldata blob
+    const uint64_t* off;        // n+1 offsets
+    uint32_t sel_a_be, sel_b_be;    // risc0: verify / verifyIntegrity; sp1: verifyProof / unused
+    uint8_t* seals;             // n x 260: first min(L, 260) decoded seal / proof bytes
+    uint32_t* seal_len;         // n: decoded length L, or 0xFFFFFFFF when the calldata is not a canonical verify call
+    uint8_t* in_a; uint8_t* in_b;   // n x 32 each: risc0 image id (claim digest) / journal digest; sp1 program vkey / unused
+    uint8_t* kind;              // n: risc0 0 = verify, 1 = verifyIntegrity
+    uint8_t* pv; uint64_t* pv_off; uint32_t* pv_len;    // sp1 public values: pv_off[i] = off[i] / 32
+};
+void launch_wire_risc0(const WireArgs& a, hipStream_t s);
+void launch_wire_sp1(const WireArgs& a, hipStream_t s);
 
 void launch_setup(const VkRaw* d_raw, VkTables* d_tab, hipStream_t s);
 void launch_prep_risc0(const PrepArgs& a, const Risc0Consts& k, const Workspace& ws, hipStream_t s);

@@ -17,7 +17,8 @@ namespace zkv {
 
 enum : uint8_t {
     ST_OK = 0, ST_VERIFICATION_FAILED = 1, ST_INVALID_INITIALIZATION = 2, ST_ALREADY_INITIALIZED = 3,
-    ST_INVALID_PROOF_DATA = 4, ST_SELECTOR_MISMATCH = 5
+    ST_INVALID_PROOF_DATA = 4, ST_SELECTOR_MISMATCH = 5,
+    ST_BAD_CALLDATA = 6            // wire layer only: calldata the contract's router cannot decode
 };
 enum : uint32_t { FL_ALIVE = 1u, FL_A_INF = 2u, FL_B_INF = 4u, FL_C_INF = 8u, FL_L_INF = 16u };
 

@@ -13,10 +13,11 @@ STATUS_INVALID_INITIALIZATION = 2
 STATUS_ALREADY_INITIALIZED = 3
 STATUS_INVALID_PROOF_DATA = 4
 STATUS_SELECTOR_MISMATCH = 5
+STATUS_BAD_CALLDATA = 6          # wire layer only (wire.py): calldata the contract's router cannot decode
 
 STATUS_NAMES = {
     0: 'Ok', 1: 'VerificationFailed', 2: 'InvalidInitialization', 3: 'AlreadyInitialized', 4: 'InvalidProofData',
-    5: 'SelectorMismatch',
+    5: 'SelectorMismatch', 6: 'BadCalldata',
 }
 VM_RISC0, VM_SP1 = 0, 1
 

@@ -200,3 +200,39 @@ def make_batch(vm, base_seal, n, seed, pool=16, mutate_every=64, classes=MUTATIO
         st[1] = g2_add(b, st[3])
         st[2] = g1_add(c, st[4])
     return seals, mutated, mclass, flip_input
+
+
+# ---------------------------------------------------------------- eth_call calldata of a batch (wire layer)
+def _u8_array_words(dst, col0, data):
+    """dst[:, col0:] receives the ABI encoding of uint8[] `data` (n x L): length word + one 32-byte word per byte."""
+    n, length = data.shape
+    dst[:, col0 + 28:col0 + 32] = np.frombuffer(int(length).to_bytes(4, 'big'), dtype=np.uint8)
+    dst[:, col0 + 32 + 31:col0 + 32 + 32 * length:32] = data
+    return col0 + 32 + 32 * length
+
+
+def calldata_risc0_verify(seals, image_ids, journal_digests):
+    """Canonical calldata of `verify(uint8[],bytes32,bytes32)` for every row: uint8[n, 8452] for 260-byte seals."""
+    from . import wire
+    n, length = seals.shape
+    out = np.zeros((n, 4 + 96 + 32 * (length + 1)), dtype=np.uint8)
+    out[:, :4] = np.frombuffer(wire.function_selector('verify(uint8[],bytes32,bytes32)'), dtype=np.uint8)
+    out[:, 4 + 31] = 0x60
+    out[:, 36:68] = image_ids
+    out[:, 68:100] = journal_digests
+    _u8_array_words(out, 100, seals)
+    return out
+
+
+def calldata_sp1_verify_proof(program_vkeys, public_values, proofs):
+    """Canonical calldata of `verifyProof(bytes32,uint8[],uint8[])` for every row (fixed public-values length)."""
+    from . import wire
+    n, lpv = public_values.shape
+    out = np.zeros((n, 4 + 96 + 32 * (lpv + 1) + 32 * (proofs.shape[1] + 1)), dtype=np.uint8)
+    out[:, :4] = np.frombuffer(wire.function_selector('verifyProof(bytes32,uint8[],uint8[])'), dtype=np.uint8)
+    out[:, 4:36] = program_vkeys
+    out[:, 36 + 31] = 0x60
+    out[:, 68 + 24:68 + 32] = np.frombuffer(int(0x80 + 32 * lpv).to_bytes(8, 'big'), dtype=np.uint8)
+    k = _u8_array_words(out, 100, public_values)
+    _u8_array_words(out, k, proofs)
+    return out

@@ -37,3 +37,8 @@ def precompile_kats():
 @pytest.fixture(scope='session')
 def revert_vectors():
     return load_golden('revert_bytes.json')
+
+
+@pytest.fixture(scope='session')
+def wire_cases():
+    return load_golden('wire_cases.json')

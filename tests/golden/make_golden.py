@@ -312,6 +312,127 @@ def corpus_fixture(rng, real):
                 cases=cases, ctx_cases=ctx_cases)
 
 
+
+# ---------------------------------------------------------------- on-chain wire layer (UNPINNED: Stylus router behaviour)
+def apply_ops(calldata, ops):
+    b = bytearray(calldata)
+    for op in ops:
+        if op[0] == 'patch':
+            v = bytes.fromhex(op[2]); b[op[1]:op[1] + len(v)] = v
+        elif op[0] == 'truncate':
+            del b[op[1]:]
+        elif op[0] == 'append':
+            b += bytes.fromhex(op[1])
+        elif op[0] == 'insert':
+            b[op[1]:op[1]] = bytes.fromhex(op[2])
+    return bytes(b)
+
+
+def wire_fixture(real, corpus):
+    """Cases are stored as (method, arguments, byte edits of the canonical calldata) so the fixture stays small; the
+    expectations come from spec_model.risc0_eth_call / sp1_eth_call."""
+    H = bytes.fromhex
+    r, s = real['risc0'], real['sp1']
+    v_init = m.Risc0Verifier(); v_init.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    v_new = m.Risc0Verifier()
+    cases = []
+
+    def build(c):
+        if c['method'] == 'verify':
+            cd = m.encode_risc0_verify(H(c['seal']), H(c['a']), H(c['b']))
+        elif c['method'] == 'verify_integrity':
+            cd = m.encode_risc0_verify_integrity(H(c['seal']), H(c['a']))
+        elif c['method'] == 'verify_proof':
+            cd = m.encode_sp1_verify_proof(H(c['a']), H(c['pv']), H(c['seal']))
+        else:
+            cd = H(c['raw'])
+        return apply_ops(cd, c['ops'])
+
+    def add(vm, name, method, ops=(), ctx='init', **kw):
+        c = dict(vm=vm, ctx=ctx, name=name, method=method, ops=[list(o) for o in ops], **kw)
+        cd = build(c)
+        if vm == 'risc0':
+            rev, ret, st = m.risc0_eth_call(v_init if ctx == 'init' else v_new, cd)
+        else:
+            rev, ret, st = m.sp1_eth_call(cd)
+        c.update(calldata_len=len(cd), calldata_keccak=hx(m.keccak256(cd)), reverted=bool(rev), returndata=hx(ret), status=st)
+        cases.append(c)
+
+    seal, iid, jd, claim = r['seal'], r['image_id'], r['journal_digest'], r['claim_digest']
+    R = dict(seal=seal, a=iid, b=jd)
+    add('risc0', 'real proof, verify', 'verify', **R)
+    add('risc0', 'real proof, verifyIntegrity', 'verify_integrity', seal=seal, a=claim)
+    add('risc0', 'verifyIntegrity with the wrong claim', 'verify_integrity', seal=seal, a=jd)
+    for c in corpus['cases']:
+        if c['vm'] == 'risc0' and c['name'] in ('flip bit in C.x', 'wrong selector', 'len 3', 'len 259', 'len 261', 'flip bit in journal_digest',
+                                                                       'B out of subgroup (on twist)', 'A.x += Q', 'rerandomised 0'):
+            add('risc0', 'corpus: ' + c['name'], 'verify', seal=c['seal'], a=c['image_id'], b=c['journal_digest'])
+    add('risc0', 'empty seal', 'verify', seal='', a=iid, b=jd)
+    add('risc0', 'seal of 2 bytes', 'verify', seal=seal[:4], a=iid, b=jd)
+    add('risc0', 'seal of 600 bytes', 'verify', seal=seal + '00' * 340, a=iid, b=jd)
+    add('risc0', 'offset word 0x80 with padding word', 'verify', [('patch', 4 + 31, '80'), ('insert', 100, '00' * 32)], **R)
+    add('risc0', 'offset word 0x40', 'verify', [('patch', 4 + 31, '40')], **R)
+    add('risc0', 'offset word has a high byte', 'verify', [('patch', 4, '01')], **R)
+    add('risc0', '32 trailing bytes', 'verify', [('append', '00' * 32)], **R)
+    add('risc0', '1 trailing byte', 'verify', [('append', '00')], **R)
+    add('risc0', 'truncated by one byte', 'verify', [('truncate', 8451)], **R)
+    add('risc0', 'truncated by one word', 'verify', [('truncate', 8452 - 32)], **R)
+    add('risc0', 'length word one too large', 'verify', [('patch', 100 + 30, '0105')], **R)
+    add('risc0', 'length word one too small', 'verify', [('patch', 100 + 30, '0103')], **R)
+    add('risc0', 'length word 2^255', 'verify', [('patch', 100, '80')], **R)
+    add('risc0', 'element 0 = 256', 'verify', [('patch', 132 + 30, '0100')], **R)
+    add('risc0', 'element 5 has bit 255 set', 'verify', [('patch', 132 + 32 * 5, '80')], **R)
+    add('risc0', 'element 259 has bit 8 set', 'verify', [('patch', 132 + 32 * 259 + 30, '01')], **R)
+    add('risc0', 'element 100 upper half nonzero', 'verify', [('patch', 132 + 32 * 100 + 15, '01')], **R)
+    add('risc0', 'element 100 lower half nonzero', 'verify', [('patch', 132 + 32 * 100 + 16, '01')], **R)
+    add('risc0', 'verify selector with verifyIntegrity layout', 'verify_integrity', [('patch', 0, hx(m.fn_selector(m.RISC0_FUNCTIONS[1])))], seal=seal, a=claim)
+    add('risc0', 'unknown function selector', 'verify', [('patch', 0, 'deadbeef')], **R)
+    add('risc0', 'three bytes of calldata', 'raw', raw='f8b3b6')
+    add('risc0', 'empty calldata', 'raw', raw='')
+    add('risc0', 'verify selector only', 'raw', raw=hx(m.fn_selector(m.RISC0_FUNCTIONS[1])))
+    add('risc0', 'verify head only', 'verify', [('truncate', 100)], **R)
+    for sig in m.RISC0_FUNCTIONS[3:]:
+        add('risc0', sig, 'raw', raw=hx(m.fn_selector(sig)))
+        add('risc0', sig + ' on a new verifier', 'raw', ctx='new', raw=hx(m.fn_selector(sig)))
+    add('risc0', 'getter with an argument word', 'raw', raw=hx(m.fn_selector('getSelector()')) + '00' * 32)
+    add('risc0', 'initialize on an initialised verifier', 'raw', raw=hx(m.encode_risc0_initialize(H(r['control_root']), H(r['bn254_control_id']))))
+    add('risc0', 'initialize on a new verifier (simulated)', 'raw', ctx='new', raw=hx(m.encode_risc0_initialize(H(r['control_root']), H(r['bn254_control_id']))))
+    add('risc0', 'initialize with a short argument', 'raw', ctx='new', raw=hx(m.encode_risc0_initialize(H(r['control_root']), H(r['bn254_control_id']))[:-1]))
+    add('risc0', 'verify on a new verifier', 'verify', ctx='new', **R)
+    add('risc0', 'verifyIntegrity on a new verifier', 'verify_integrity', ctx='new', seal=seal, a=claim)
+    add('risc0', 'bad calldata on a new verifier', 'verify', [('append', '00')], ctx='new', **R)
+
+    S = dict(a=s['vkey'], pv=s['public_values'], seal=s['proof'])
+    add('sp1', 'real proof, verifyProof', 'verify_proof', **S)
+    for c in corpus['cases']:
+        if c['vm'] == 'sp1' and c['name'] in ('flip last public-values byte', 'wrong selector', 'len 259', 'len 2', 'vkey >= R', 'B out of subgroup',
+                                                'rerandomised 1', 'public values 55 bytes'):
+            add('sp1', 'corpus: ' + c['name'], 'verify_proof', a=c['vkey'], pv=c['public_values'], seal=c['proof'])
+    add('sp1', 'empty public values', 'verify_proof', a=s['vkey'], pv='', seal=s['proof'])
+    add('sp1', 'one public-values byte', 'verify_proof', a=s['vkey'], pv='14', seal=s['proof'])
+    add('sp1', '300 public-values bytes', 'verify_proof', a=s['vkey'], pv=s['public_values'] + 'ab' * 204, seal=s['proof'])
+    add('sp1', 'empty proof', 'verify_proof', a=s['vkey'], pv=s['public_values'], seal='')
+    add('sp1', 'first offset 0x80', 'verify_proof', [('patch', 36 + 31, '80')], **S)
+    add('sp1', 'second offset one word short', 'verify_proof', [('patch', 68 + 30, '0c60')], **S)
+    add('sp1', 'second offset aliases the first array', 'verify_proof', [('patch', 68 + 30, '0060')], **S)
+    add('sp1', 'public-values length one too large', 'verify_proof', [('patch', 100 + 31, '61')], **S)
+    add('sp1', 'public-values element = 0x1ff', 'verify_proof', [('patch', 132 + 32 * 95 + 30, '01ff')], **S)
+    add('sp1', 'proof element upper half nonzero', 'verify_proof', [('patch', 132 + 32 * 96 + 32 + 32 * 7 + 3, '01')], **S)
+    add('sp1', 'proof length word one too large', 'verify_proof', [('patch', 132 + 32 * 96 + 30, '0105')], **S)
+    add('sp1', '32 trailing bytes', 'verify_proof', [('append', '00' * 32)], **S)
+    add('sp1', 'truncated by one byte', 'verify_proof', [('truncate', 11555)], **S)
+    add('sp1', 'head only', 'verify_proof', [('truncate', 100)], **S)
+    add('sp1', 'unknown function selector', 'verify_proof', [('patch', 0, '01020304')], **S)
+    add('sp1', 'empty calldata', 'raw', raw='')
+    for sig in m.SP1_FUNCTIONS[1:]:
+        add('sp1', sig, 'raw', raw=hx(m.fn_selector(sig)))
+    add('sp1', 'version() with trailing byte', 'raw', raw=hx(m.fn_selector('version()')) + '00')
+    return dict(risc0_ctx=dict(control_root=r['control_root'], bn254_control_id=r['bn254_control_id']),
+                selectors={sig: hx(m.fn_selector(sig)) for sig in m.RISC0_FUNCTIONS + m.SP1_FUNCTIONS},
+                keccak_kats=[dict(msg=hx(x), digest=hx(m.keccak256(x))) for x in (b'', b'abc', b'a' * 135, b'a' * 136, b'a' * 137, bytes(range(256)) * 2)],
+                cases=cases)
+
+
 def revert_fixture():
     sel_r0 = bytes.fromhex('9f39696c'); sel_sp1 = bytes.fromhex('a4594c59'); got = bytes.fromhex('12345678')
     out = []
@@ -329,8 +450,11 @@ def main():
         json.dump(real, f, indent=1)
     with open(os.path.join(HERE, 'precompile_kats.json'), 'w') as f:
         json.dump(precompile_fixture(rng), f, indent=1)
+    corpus = corpus_fixture(rng, real)
     with open(os.path.join(HERE, 'verify_corpus.json'), 'w') as f:
-        json.dump(corpus_fixture(rng, real), f, indent=1)
+        json.dump(corpus, f, indent=1)
+    with open(os.path.join(HERE, 'wire_cases.json'), 'w') as f:
+        json.dump(wire_fixture(real, corpus), f, indent=1)
     with open(os.path.join(HERE, 'revert_bytes.json'), 'w') as f:
         json.dump(revert_fixture(), f, indent=1)
     print('golden fixtures written to', HERE)

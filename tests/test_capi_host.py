@@ -93,3 +93,19 @@ def test_argument_validation(z):
     sp = z.Sp1Verifier()
     assert L.zkv_risc0_get_selector(sp._h, C.create_string_buffer(4)) == _lib.ERR_WRONG_CTX
     assert L.zkv_status_abi_encode(7, 1, b'\0' * 4, b'\0' * 4, C.create_string_buffer(68)) == _lib.ERR_INVALID_ARG
+
+
+def test_wire_layer_host_side(z, wire_cases):
+    """Function selectors and the calldata encoders run on the host: they must reproduce the golden calldata bytes."""
+    from wire_util import calldata_of
+    import oracle_lib as ol
+    for sig, sel in wire_cases['selectors'].items():
+        assert z.wire.function_selector(sig).hex() == sel
+    for c in wire_cases['cases']:
+        cd = calldata_of(c, z.wire.encode_risc0_verify, z.wire.encode_risc0_verify_integrity, z.wire.encode_sp1_verify_proof)
+        assert ol.keccak256(cd).hex() == c['calldata_keccak'], c['name']
+    if z.device_count() == 0:            # no device: eth_call batches fail loudly as well
+        from stylus_zkvm_verifiers_amd import _lib
+        with pytest.raises(_lib.ZkvRuntimeError) as ei:
+            z.wire.eth_call_batch(z.Sp1Verifier(), [z.wire.function_selector('version()')])
+        assert ei.value.code == _lib.ERR_NO_DEVICE

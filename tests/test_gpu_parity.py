@@ -276,3 +276,86 @@ def test_generic_groth16_trapdoor_keys_on_gpu(zkv):
     assert v.verify_proof_with_key(A, B, Cc, [1, 2, 3, 4, 5]) is True
     assert v.verify_proof_with_key(A, B, Cc, [1, 2, 3, 4]) is False          # length mismatch, groth16.rs:32
     v.close()
+
+
+def test_wire_layer_cases_match_golden_and_oracle(zkv, r0, sp1, wire_cases):
+    """eth_call calldata decoded on the device (csrc/k_wire.hip): return / revert data and status of every golden case equal
+    the fixture (spec model) and the C oracle.  The whole layer is UNPINNED by the reference (the Stylus router is a
+    dependency): it is pinned by the ABI specification and the two real proofs travelling through it."""
+    import oracle_lib as ol
+    from wire_util import calldata_of
+    enc = (zkv.wire.encode_risc0_verify, zkv.wire.encode_risc0_verify_integrity, zkv.wire.encode_sp1_verify_proof)
+    new = zkv.RiscZeroVerifier()
+    ctx = wire_cases['risc0_ctx']
+    o_init = ol.Risc0Oracle(); o_init.initialize(H(ctx['control_root']), H(ctx['bn254_control_id']))
+    o_new = ol.Risc0Oracle()
+    groups = {('risc0', 'init'): (r0, o_init.eth_call), ('risc0', 'new'): (new, o_new.eth_call), ('sp1', 'init'): (sp1, ol.sp1_eth_call)}
+    for key, (ver, oracle_call) in groups.items():
+        cases = [c for c in wire_cases['cases'] if (c['vm'], c['ctx']) == key]
+        cds = [calldata_of(c, *enc) for c in cases]
+        for order in (cds, cds[::-1]):                        # both orders: request offsets get every alignment
+            rev, ret, st = zkv.wire.eth_call_batch(ver, order)
+            cs = cases if order is cds else cases[::-1]
+            for c, cd, rv, rd, s in zip(cs, order, rev, ret, st):
+                assert (bool(rv), rd.hex()) == (c['reverted'], c['returndata']), (key, c['name'])
+                assert int(s) == (6 if c['status'] is None else c['status']), (key, c['name'])
+                orev, oret, ost = oracle_call(cd)
+                assert (bool(rv), rd) == (orev, oret), (key, c['name'])
+    new.close()
+
+
+def test_wire_layer_device_fast_path_2p12(zkv, r0, sp1, real_proofs):
+    """4,096 seeded eth_calls per verifier with calldata resident in HBM: statuses equal the fixed-stride seal path on the
+    same proofs (which the other tests tie to the oracle), calldata-level damage is reported as BAD_CALLDATA, and a sample
+    equals the oracle's eth_call."""
+    import torch
+    import oracle_lib as ol
+    from stylus_zkvm_verifiers_amd import synth
+    dev = torch.device('cuda', 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    r = real_proofs['risc0']
+    n = 1 << 12
+    seals, mut, mclass, flip = synth.make_batch('risc0', H(r['seal']), n, 0x5A4B5631, pool=8, mutate_every=8)
+    ids = np.tile(np.frombuffer(H(r['image_id']), dtype=np.uint8), (n, 1))
+    jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (n, 1)); jds[flip, 0] ^= 1
+    cd = synth.calldata_risc0_verify(seals, ids, jds)
+    bad = np.zeros(n, dtype=bool)
+    bad[5::97] = True
+    cd[5::97, 132 + 32 * 17 + 9] = 0x40                        # element 17 is not a uint8
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(cd.shape[1])
+    d_cd, d_off = torch.from_numpy(cd).to(dev), torch.from_numpy(off.view(np.int64)).to(dev)
+    d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev); d_rv = torch.zeros((n, 4), dtype=torch.uint8, device=dev)
+    zkv.wire.eth_call_batch_dev(r0, n, d_cd.data_ptr(), d_off.data_ptr(), cd.size, d_st.data_ptr(), d_rv.data_ptr(), stream)
+    torch.cuda.synchronize()
+    st = d_st.cpu().numpy()
+    d_seals, d_ids, d_jds = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (seals, ids, jds))
+    d_st2 = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+    r0.verify_batch_dev(n, d_seals.data_ptr(), d_ids.data_ptr(), d_jds.data_ptr(), d_st2.data_ptr(), 0, stream)
+    torch.cuda.synchronize()
+    st2 = d_st2.cpu().numpy()
+    assert (st[bad] == 6).all() and (st[~bad] == st2[~bad]).all()
+    assert ((st == 0) == (~mut & ~bad)).all()
+    assert zkv.wire.last_wire_ms(r0) > 0
+    orc = ol.Risc0Oracle(); orc.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    for i in list(range(0, 24)) + [102, 199]:
+        orev, oret, ost = orc.eth_call(cd[i].tobytes())
+        assert int(st[i]) == ost, i
+    # SP1
+    s = real_proofs['sp1']
+    proofs, mut, mclass, flip = synth.make_batch('sp1', H(s['proof']), n, 0x5A4B5632, pool=8, mutate_every=8)
+    vk = np.tile(np.frombuffer(H(s['vkey']), dtype=np.uint8), (n, 1))
+    pv = np.tile(np.frombuffer(H(s['public_values']), dtype=np.uint8), (n, 1)); pv[flip, -1] ^= 1
+    cd = synth.calldata_sp1_verify_proof(vk, pv, proofs)
+    bad = np.zeros(n, dtype=bool)
+    bad[7::101] = True
+    cd[7::101, 68 + 31] ^= 0x20                                # second offset no longer canonical
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(cd.shape[1])
+    d_cd, d_off = torch.from_numpy(cd).to(dev), torch.from_numpy(off.view(np.int64)).to(dev)
+    d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+    zkv.wire.eth_call_batch_dev(sp1, n, d_cd.data_ptr(), d_off.data_ptr(), cd.size, d_st.data_ptr(), 0, stream)
+    torch.cuda.synchronize()
+    st = d_st.cpu().numpy()
+    assert (st[bad] == 6).all() and ((st == 0) == (~mut & ~bad)).all()
+    for i in list(range(0, 16)) + [108]:
+        orev, oret, ost = ol.sp1_eth_call(cd[i].tobytes())
+        assert int(st[i]) == ost, i

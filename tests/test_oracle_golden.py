@@ -143,3 +143,23 @@ def _ok(m, data):
         return True
     except m.PrecompileError:
         return False
+
+
+def test_wire_layer_cases(wire_cases):
+    """eth_call calldata -> return / revert data (Stylus router behaviour is unpinned): C oracle == golden."""
+    from wire_util import calldata_of
+    for k in wire_cases['keccak_kats']:
+        assert ol.keccak256(H(k['msg'])).hex() == k['digest']
+    for sig, sel in wire_cases['selectors'].items():
+        assert ol.keccak256(sig.encode())[:4].hex() == sel
+    ctx = wire_cases['risc0_ctx']
+    init = ol.Risc0Oracle(); init.initialize(H(ctx['control_root']), H(ctx['bn254_control_id']))
+    new = ol.Risc0Oracle()
+    for c in wire_cases['cases']:
+        cd = calldata_of(c, ol.risc0_encode_call, ol.risc0_encode_call, ol.sp1_encode_call)
+        assert ol.keccak256(cd).hex() == c['calldata_keccak'], c['name']
+        if c['vm'] == 'risc0':
+            rev, ret, st = (init if c['ctx'] == 'init' else new).eth_call(cd)
+        else:
+            rev, ret, st = ol.sp1_eth_call(cd)
+        assert (rev, ret.hex(), st) == (c['reverted'], c['returndata'], c['status']), c['name']
