@@ -128,6 +128,41 @@ def host_boundary_rate(shard, repeats=2):
             'note': 'host buffers in, statuses out: PCIe staging and copies inside the call (pageable memory, synchronous per chunk)'}
 
 
+def wire_leg(shard, dev, stream, steps=3):
+    """The same batch arriving as eth_call calldata already resident in HBM (`verify(uint8[],bytes32,bytes32)` /
+    `verifyProof(bytes32,uint8[],uint8[])`: one 32-byte word per seal byte): decode kernel (HBM-bound, its own roofline line)
+    followed by the usual stages.  Reported next to `value`, never as it."""
+    from stylus_zkvm_verifiers_amd import synth, wire
+    if shard.vm == 'risc0':
+        cd = synth.calldata_risc0_verify(shard.h_seals, shard.h_a, shard.h_b)
+    else:
+        cd = synth.calldata_sp1_verify_proof(shard.h_a, shard.h_b, shard.h_seals)
+    n = shard.n
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(cd.shape[1])
+    d_cd = torch.from_numpy(cd).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+    run = lambda: wire.eth_call_batch_dev(shard.ctx, n, d_cd.data_ptr(), d_off.data_ptr(), cd.size, d_st.data_ptr(), 0, stream)
+    run(); torch.cuda.synchronize()
+    wire_ms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+        wire_ms.append(wire.last_wire_ms(shard.ctx))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    same = bool((d_st.cpu().numpy() == shard.d_status.cpu().numpy()).all())
+    chunk = int(os.environ.get('ZKV_CHUNK', 1 << 17))
+    last = n - (-(-n // chunk) - 1) * chunk                      # the events bracket the last chunk's decode launch
+    ms = float(np.mean(wire_ms))
+    out_bytes = 260 + (64 if shard.vm == 'risc0' else 32 + shard.h_b.shape[1]) + 4 + 1
+    gbs = last * (cd.shape[1] + out_bytes) / (ms * 1e-3) / 1e9
+    default = shard.vm == 'risc0' and n == 1 << 16
+    return {'kernel': 'k_wire_' + shard.vm, 'traffic': pmc_traffic('k_wire_' + shard.vm) if default else None, 'calldata_bytes_per_proof': int(cd.shape[1]), 'decoded_bytes_per_proof': out_bytes,
+            'kernel_ms': ms, 'proofs_per_launch': int(last), 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': gbs / HBM_PEAK_GBS, 'end_to_end_proofs_per_s': n / dt, 'statuses_equal_seal_path': same}
+
+
 def host_cores():
     """CPU threads this process may actually use: affinity mask, capped by the cgroup CPU quota when one is set."""
     try:
@@ -185,6 +220,7 @@ def main():
     ap.add_argument('--proofs', dest='n', type=int, default=0, help='override proofs per GPU')
     ap.add_argument('--mutate-every', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-wire', action='store_true', help='skip the eth_call calldata leg (N=1 only)')
     ap.add_argument('--rehearse-single-gpu', action='store_true',
                     help='multi-process rehearsal on a one-GPU box: every rank uses cuda:0 and the collectives run over gloo on host tensors')
     args = ap.parse_args()
@@ -282,6 +318,8 @@ def main():
         }
         if world == 1:
             out['host_boundary'] = host_boundary_rate(shards[0])
+        if world == 1 and not args.no_wire and shards[0].n * 12000 < (8 << 30):       # calldata blob must fit comfortably
+            out['wire'] = wire_leg(shards[0], dev, stream)
         if world == 1 and not args.no_cpu_baseline:
             base, cst, kk = cpu_baseline(shards[0])
             out['cpu_baseline'] = base

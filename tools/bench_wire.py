@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Times the calldata-decode kernel alone (HIP events around k_wire_*) on a synthetic batch resident in HBM.
+
+    python tools/bench_wire.py [--vm risc0|sp1] [--proofs N] [--reps K]
+
+Only the decode launch is timed; the verification stages that follow it in the same call are not part of the figure."""
+import argparse, json, os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--vm', default='risc0')
+    ap.add_argument('--proofs', type=int, default=1 << 16)
+    ap.add_argument('--reps', type=int, default=5)
+    args = ap.parse_args()
+    from stylus_zkvm_verifiers_amd import RiscZeroVerifier, Sp1Verifier, synth, wire
+    g = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'real_proofs.json')))
+    H = bytes.fromhex
+    n = args.proofs
+    dev = torch.device('cuda', 0)
+    # decode cost does not depend on proof validity: replicate one real proof, with a few damaged requests
+    if args.vm == 'risc0':
+        r = g['risc0']
+        v = RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+        f = lambda h: np.tile(np.frombuffer(H(h), dtype=np.uint8), (n, 1))
+        cd = synth.calldata_risc0_verify(f(r['seal']), f(r['image_id']), f(r['journal_digest']))
+    else:
+        s = g['sp1']
+        v = Sp1Verifier()
+        f = lambda h: np.tile(np.frombuffer(H(h), dtype=np.uint8), (n, 1))
+        cd = synth.calldata_sp1_verify_proof(f(s['vkey']), f(s['public_values']), f(s['proof']))
+    cd[3::1000, 200] = 1
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(cd.shape[1])
+    d_cd = torch.from_numpy(cd).to(dev); d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+    ms = []
+    for _ in range(args.reps + 1):
+        wire.eth_call_batch_dev(v, n, d_cd.data_ptr(), d_off.data_ptr(), cd.size, d_st.data_ptr(), 0, 0)
+        ms.append(wire.last_wire_ms(v))
+    v.synchronize()                     # the call is asynchronous on the context's own stream
+    st = d_st.cpu().numpy()
+    bad = np.zeros(n, dtype=bool); bad[3::1000] = True
+    assert (st[bad] == 6).all() and (st[~bad] == 0).all(), 'unexpected statuses'
+    chunk = int(os.environ.get('ZKV_CHUNK', 1 << 17))
+    last = n - (-(-n // chunk) - 1) * chunk
+    best = min(ms[1:])
+    print(json.dumps({'vm': args.vm, 'proofs': n, 'calldata_bytes_per_proof': int(cd.shape[1]), 'wire_ms': ms[1:], 'best_ms': best,
+                      'read_GBps_best': last * cd.shape[1] / (best * 1e-3) / 1e9, 'blocks_env': os.environ.get('ZKV_WIRE_BLOCKS')}))
+
+
+if __name__ == '__main__':
+    main()

@@ -11,6 +11,7 @@ import collections
 import csv
 import glob
 import json
+import re
 import os
 import shutil
 import sys
@@ -32,7 +33,7 @@ def main(src, tag):
                 k = r['Kernel_Name']
                 if 'zkv::k_' not in k or 'setup' in k:
                     continue
-                k = k.split('(')[0].replace('zkv::', '')
+                k = re.sub(r'<.*?>', '', k.split('(')[0].replace('zkv::', '').replace('void ', '')).strip()
                 data[k][r['Counter_Name']] += float(r['Counter_Value'])
                 calls[k][r['Counter_Name']] += 1
     if not data:
@@ -47,7 +48,8 @@ def main(src, tag):
              '    rocprofv3 --pmc WRITE_SIZE --kernel-trace ...      rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES ... --kernel-trace ...\n',
              'FETCH_SIZE / WRITE_SIZE in KiB per dispatch as rocprofv3 reports them.  The gfx950 x2 FETCH_SIZE correction of',
              'MI355X_MICROARCH.md applies to wide (16 B/lane) streaming reads; these kernels issue 4 B/lane struct-of-arrays and scratch',
-             'accesses, which that guide lists as uncalibrated, so raw values are given.\n',
+             'accesses, which that guide lists as uncalibrated, so raw values are given -- except for k_wire_* (16 B/lane coalesced',
+             'streaming of calldata), whose FETCH_SIZE is doubled in the traffic figure as the guide prescribes.\n',
              '| kernel | ' + ' | '.join(cols) + ' |', '|---|' + '---|' * len(cols)]
     for k in sorted(per):
         lines.append('| %s | ' % k + ' | '.join('%.6g' % per[k].get(c, float('nan')) for c in cols) + ' |')
@@ -55,7 +57,7 @@ def main(src, tag):
     traffic = {}
     for k, d in per.items():
         if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
-            traffic[k] = (d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024.0
+            traffic[k] = ((2.0 if k.startswith('k_wire') else 1.0) * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024.0
         if 'SQ_INSTS_VALU' in d and d.get('SQ_WAVES'):
             lines.append('%s: %.3g VALU instructions per wave, %.3g cycles per wave (SQ_WAVE_CYCLES counts quad-cycles), %.2f wave-cycles per VALU instruction'
                          % (k, d['SQ_INSTS_VALU'] / d['SQ_WAVES'], d['SQ_WAVE_CYCLES'] * 4 / d['SQ_WAVES'], d['SQ_WAVE_CYCLES'] * 4 / d['SQ_INSTS_VALU']))
