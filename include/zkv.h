@@ -11,8 +11,10 @@
  *     a verification outcome.  Verification outcomes are per-proof status bytes (ZKV_STATUS_*), which
  *     reproduce the reference's `Result<_, Vec<u8>>` error classes in the reference's evaluation order.
  *   - There is no CPU fallback: compute entry points return ZKV_ERR_NO_DEVICE when no gfx950 device is usable.
- *   - A context is immutable after initialisation; batch calls on one context are serialised on the
- *     context's HIP stream (use one context per host thread for concurrency).
+ *   - A context is immutable after initialisation.  All calls on one context share its device workspace and are
+ *     therefore executed one after another, also when the *_dev entry points are given different HIP streams (each
+ *     call makes its stream wait for the previous call's last kernel).  Use one context per host thread / per
+ *     concurrent stream for overlap.
  */
 #ifndef ZKV_H
 #define ZKV_H

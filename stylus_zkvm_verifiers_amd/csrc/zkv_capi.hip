@@ -39,6 +39,10 @@ struct zkv_ctx {
     size_t cd_cap = 0;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ev_wire[2] = {nullptr, nullptr};
     bool wire_timed = false;
+    // The workspace is shared by every call on this context, and the *_dev entry points run on caller-chosen streams:
+    // each call first makes its stream wait for the previous call's last kernel (ev_done), then records ev_done again.
+    hipEvent_t ev_done = nullptr;
+    bool has_done = false;
     std::mutex mu;
 };
 
@@ -81,6 +85,8 @@ static void ctx_free_device(zkv_ctx* c) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_wire) if (e) (void)hipEventDestroy(e);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    c->ev_done = nullptr; c->has_done = false;
     if (c->stream) (void)hipStreamDestroy(c->stream);
     c->dev_ready = false; c->stream = nullptr;
 }
@@ -95,6 +101,7 @@ static int ctx_device_init(zkv_ctx* c) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->ev_wire) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
     if (c->vm != ZKV_VM_BN254) {
         VkRaw raw;
         if (c->vm == ZKV_VM_RISC0) host::fill_vk_risc0(raw, c->control_root_0, c->control_root_1, c->control_id);
@@ -142,6 +149,17 @@ static int grow(uint8_t** p, size_t* cap, size_t need) {
     return ZKV_OK;
 }
 
+// Cross-stream ordering of consecutive calls on one context (see zkv_ctx::ev_done).
+static int order_after_previous(zkv_ctx* c, hipStream_t s) {
+    if (c->has_done) HIP_TRY(hipStreamWaitEvent(s, c->ev_done, 0));
+    return ZKV_OK;
+}
+static int mark_done(zkv_ctx* c, hipStream_t s) {
+    HIP_TRY(hipEventRecord(c->ev_done, s));
+    c->has_done = true;
+    return ZKV_OK;
+}
+
 // Enqueues the five stages for one chunk (all pointers device-resident).
 static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed) {
     if (timed) (void)hipEventRecord(c->ev[0], s);
@@ -177,6 +195,7 @@ static int run_host_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const uint6
     if (rc != ZKV_OK) return rc;
     size_t cap = c->ws.cap;
     std::vector<uint64_t> rel(cap + 1);
+    if ((rc = order_after_previous(c, c->stream)) != ZKV_OK) return rc;
     for (size_t base = 0; base < n; base += cap) {
         size_t m = n - base < cap ? n - base : cap;
         uint64_t b0 = off[base], bytes = off[base + m] - b0;
@@ -227,6 +246,7 @@ static int run_dev_batch(zkv_ctx* c, size_t n, const uint8_t* d_blob, const uint
         return ZKV_OK;
     }
     size_t cap = c->ws.cap;
+    if (n && (rc = order_after_previous(c, s)) != ZKV_OK) return rc;
     for (size_t base = 0; base < n; base += cap) {
         size_t m = n - base < cap ? n - base : cap;
         PrepArgs a;
@@ -244,7 +264,7 @@ static int run_dev_batch(zkv_ctx* c, size_t n, const uint8_t* d_blob, const uint
         enqueue_chunk(c, a, s, base + cap >= n);
     }
     HIP_TRY(hipGetLastError());
-    return ZKV_OK;
+    return n ? mark_done(c, s) : ZKV_OK;
 }
 
 // ------------------------------------------------------------------ RISC Zero
@@ -496,6 +516,7 @@ static int run_eth_call_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const u
     int rc = ctx_device_init(c);
     if (rc != ZKV_OK) return rc;
     if ((rc = wire_buffers(c)) != ZKV_OK) return rc;
+    if ((rc = order_after_previous(c, c->stream)) != ZKV_OK) return rc;
     const size_t cap = c->ws.cap;
     std::vector<uint64_t> rel(cap + 1);
     std::vector<uint8_t> st(cap), rv(4 * cap);
@@ -543,6 +564,7 @@ ZKV_EXPORT int zkv_eth_call_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d_cal
     if ((rc = wire_buffers(c)) != ZKV_OK) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const size_t cap = c->ws.cap;
+    if ((rc = order_after_previous(c, s)) != ZKV_OK) return rc;
     for (size_t base = 0; base < n; base += cap) {
         size_t m = n - base < cap ? n - base : cap;
         // offsets are absolute into d_calldata, so chunks share the blob pointer; the public-values scratch is sized for the whole blob
@@ -550,7 +572,7 @@ ZKV_EXPORT int zkv_eth_call_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d_cal
                                      base + cap >= n)) != ZKV_OK) return rc;
     }
     HIP_TRY(hipGetLastError());
-    return ZKV_OK;
+    return mark_done(c, s);
 }
 ZKV_EXPORT int zkv_eth_call_returndata(const zkv_ctx* c, uint8_t status, const uint8_t recv_selector[4], uint8_t out[ZKV_RETURNDATA_STRIDE],
                                        uint32_t* out_len, uint8_t* reverted) {
@@ -585,6 +607,7 @@ static int run_precompile(zkv_ctx* c, int kind, size_t n, size_t k, const uint8_
     int rc = ctx_device_init(c);
     if (rc != ZKV_OK) return rc;
     const size_t in_sz = kind == 0 ? 128 : kind == 1 ? 96 : 192 * k, out_sz = kind == 2 ? 1 : 64, cap = c->ws.cap;
+    if ((rc = order_after_previous(c, c->stream)) != ZKV_OK) return rc;
     for (size_t base = 0; base < n; base += cap) {
         size_t m = n - base < cap ? n - base : cap;
         if ((rc = grow(&c->d_blob, &c->blob_cap, m * in_sz + 8)) != ZKV_OK) return rc;
@@ -628,6 +651,7 @@ ZKV_EXPORT int zkv_groth16_verify_batch(zkv_ctx* c, size_t n, const uint8_t* pro
     int rc = ctx_device_init(c);
     if (rc != ZKV_OK) return rc;
     const size_t cap = c->ws.cap;
+    if ((rc = order_after_previous(c, c->stream)) != ZKV_OK) return rc;
     for (size_t base = 0; base < n; base += cap) {
         size_t m = n - base < cap ? n - base : cap;
         if ((rc = grow(&c->d_blob, &c->blob_cap, m * 256 + 8)) != ZKV_OK) return rc;
@@ -658,6 +682,7 @@ ZKV_EXPORT int zkv_ctx_vk_x_batch(zkv_ctx* c, size_t n, const uint8_t* var_signa
     int rc = ctx_device_init(c);
     if (rc != ZKV_OK) return rc;
     const size_t cap = c->ws.cap;
+    if ((rc = order_after_previous(c, c->stream)) != ZKV_OK) return rc;
     for (size_t base = 0; base < n; base += cap) {
         size_t m = n - base < cap ? n - base : cap;
         if ((rc = grow(&c->d_blob, &c->blob_cap, m * 64 + 8)) != ZKV_OK) return rc;

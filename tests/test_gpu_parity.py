@@ -359,3 +359,29 @@ def test_wire_layer_device_fast_path_2p12(zkv, r0, sp1, real_proofs):
     for i in list(range(0, 16)) + [108]:
         orev, oret, ost = ol.sp1_eth_call(cd[i].tobytes())
         assert int(st[i]) == ost, i
+
+
+def test_dev_calls_on_different_streams_do_not_race(zkv, r0, real_proofs):
+    """Two device-resident batches enqueued back to back on two HIP streams share the context's workspace: the second must
+    wait for the first (event ordering inside the library), so both status vectors are right."""
+    import torch
+    from stylus_zkvm_verifiers_amd import synth
+    dev = torch.device('cuda', 0)
+    r = real_proofs['risc0']
+    n = 1 << 12
+    batches = []
+    for seed, every in ((0x5A4B5641, 3), (0x5A4B5642, 5)):
+        seals, mut, mclass, flip = synth.make_batch('risc0', H(r['seal']), n, seed, pool=4, mutate_every=every)
+        ids = np.tile(np.frombuffer(H(r['image_id']), dtype=np.uint8), (n, 1))
+        jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (n, 1)); jds[flip, 0] ^= 1
+        d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (seals, ids, jds)]
+        batches.append((d, mut, torch.full((n,), 255, dtype=torch.uint8, device=dev)))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    for rep in range(3):
+        for (d, mut, d_st), st in zip(batches, streams):
+            r0.verify_batch_dev(n, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d_st.data_ptr(), 0, st.cuda_stream)
+    torch.cuda.synchronize()
+    for d, mut, d_st in batches:
+        st = d_st.cpu().numpy()
+        assert ((st == 0) == ~mut).all()
