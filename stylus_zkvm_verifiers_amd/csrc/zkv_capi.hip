@@ -33,10 +33,12 @@ struct zkv_ctx {
     uint64_t *d_off = nullptr, *d_pvoff = nullptr;
     size_t blob_cap = 0, pv_cap = 0;
     // wire layer (eth_call batches): calldata blob, its offsets, decoded lengths / methods
-    uint8_t *d_cd = nullptr, *d_kind = nullptr;
-    uint64_t* d_cdoff = nullptr;
+    uint8_t *d_cd[2] = {nullptr, nullptr}, *d_kind = nullptr, *d_st_all = nullptr, *d_rv_all = nullptr;
+    uint64_t* d_cdoff[2] = {nullptr, nullptr};
     uint32_t *d_len = nullptr, *d_pvlen = nullptr;
-    size_t cd_cap = 0;
+    size_t cd_cap[2] = {0, 0}, st_all_cap = 0, rv_all_cap = 0;
+    hipStream_t copy_stream = nullptr;                       // H2D of calldata chunk k+1 overlaps the kernels of chunk k
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_decoded[2] = {nullptr, nullptr};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ev_wire[2] = {nullptr, nullptr};
     bool wire_timed = false;
     // The workspace is shared by every call on this context, and the *_dev entry points run on caller-chosen streams:
@@ -81,12 +83,19 @@ static void ctx_free_device(zkv_ctx* c) {
     if (!c->dev_ready && !c->stream) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_tab, c->ws.prep, c->ws.norm, c->ws.f, c->ws.fe, c->ws.flags, c->d_blob, c->d_a, c->d_b, c->d_pv,
-                    c->d_status, c->d_recv, c->d_off, c->d_pvoff, c->d_cd, c->d_kind, c->d_cdoff, c->d_len, c->d_pvlen};
+                    c->d_status, c->d_recv, c->d_off, c->d_pvoff, c->d_cd[0], c->d_cd[1], c->d_kind, c->d_cdoff[0], c->d_cdoff[1], c->d_len,
+                    c->d_pvlen, c->d_st_all, c->d_rv_all};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_wire) if (e) (void)hipEventDestroy(e);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     c->ev_done = nullptr; c->has_done = false;
+    for (int b = 0; b < 2; b++) {
+        if (c->ev_copied[b]) (void)hipEventDestroy(c->ev_copied[b]);
+        if (c->ev_decoded[b]) (void)hipEventDestroy(c->ev_decoded[b]);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    c->copy_stream = nullptr;
     if (c->stream) (void)hipStreamDestroy(c->stream);
     c->dev_ready = false; c->stream = nullptr;
 }
@@ -461,7 +470,7 @@ static void host_method(const zkv_ctx* c, const uint8_t* cd, size_t len, uint8_t
 
 // Decode + verify one chunk whose calldata and offsets are already on the device.
 static int enqueue_wire_chunk(zkv_ctx* c, size_t m, const uint8_t* d_cd, const uint64_t* d_cdoff, uint64_t cd_bytes, uint8_t* d_status, uint8_t* d_recv,
-                              hipStream_t s, bool timed) {
+                              hipStream_t s, bool timed, hipEvent_t decoded = nullptr) {
     int rc;
     if ((rc = grow(&c->d_blob, &c->blob_cap, m * ZKV_SEAL_BYTES + 8)) != ZKV_OK) return rc;
     if (c->vm == ZKV_VM_SP1 && (rc = grow(&c->d_pv, &c->pv_cap, (size_t)(cd_bytes / 32) + 64)) != ZKV_OK) return rc;
@@ -480,6 +489,7 @@ static int enqueue_wire_chunk(zkv_ctx* c, size_t m, const uint8_t* d_cd, const u
         launch_wire_sp1(w, s);
     }
     if (timed) { (void)hipEventRecord(c->ev_wire[1], s); c->wire_timed = true; }
+    if (decoded) (void)hipEventRecord(decoded, s);           // the calldata buffer may be overwritten from here on
     PrepArgs a;
     memset(&a, 0, sizeof a);
     a.n = m; a.blob = c->d_blob; a.off = nullptr; a.stride = ZKV_SEAL_BYTES; a.len = c->d_len;
@@ -501,13 +511,28 @@ static int wire_buffers(zkv_ctx* c) {
     if (c->d_len) return ZKV_OK;
     const size_t cap = c->ws.cap;
     if (hipMalloc(&c->d_len, sizeof(uint32_t) * cap) != hipSuccess || hipMalloc(&c->d_pvlen, sizeof(uint32_t) * cap) != hipSuccess ||
-        hipMalloc(&c->d_kind, cap) != hipSuccess || hipMalloc(&c->d_cdoff, sizeof(uint64_t) * (cap + 1)) != hipSuccess) {
+        hipMalloc(&c->d_kind, cap) != hipSuccess || hipMalloc(&c->d_cdoff[0], sizeof(uint64_t) * (cap + 1)) != hipSuccess ||
+        hipMalloc(&c->d_cdoff[1], sizeof(uint64_t) * (cap + 1)) != hipSuccess) {
         (void)hipGetLastError();
         return ZKV_ERR_OOM;
+    }
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) {
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_copied[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_decoded[b], hipEventDisableTiming));
     }
     return ZKV_OK;
 }
 
+// Host calldata: 8-12 KB per proof cross PCIe, as much time as the verification itself.  Chunks of at most 2^16 requests
+// (enough lanes to fill the chip) are double-buffered: the H2D copy of chunk k+1 runs on its own stream while chunk k is
+// decoded and verified; statuses stay on the device until the whole batch is done, so the host never waits inside the loop.
+static size_t wire_host_chunk(size_t cap) {
+    const char* e = getenv("ZKV_WIRE_HOST_CHUNK");
+    size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 16;
+    if (v < 1) v = 1;
+    return v < cap ? v : cap;
+}
 static int run_eth_call_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const uint64_t* off, uint8_t* reverted, uint8_t* returndata,
                               uint32_t* returndata_len, uint8_t* status) {
     if (!c || (n && (!blob || !off || !reverted || !returndata || !returndata_len))) return ZKV_ERR_INVALID_ARG;
@@ -517,28 +542,47 @@ static int run_eth_call_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const u
     if (rc != ZKV_OK) return rc;
     if ((rc = wire_buffers(c)) != ZKV_OK) return rc;
     if ((rc = order_after_previous(c, c->stream)) != ZKV_OK) return rc;
-    const size_t cap = c->ws.cap;
-    std::vector<uint64_t> rel(cap + 1);
-    std::vector<uint8_t> st(cap), rv(4 * cap);
-    for (size_t base = 0; base < n; base += cap) {
-        size_t m = n - base < cap ? n - base : cap;
-        uint64_t b0 = off[base], bytes = off[base + m] - b0;
-        if ((rc = grow(&c->d_cd, &c->cd_cap, (size_t)bytes + 8)) != ZKV_OK) return rc;
-        for (size_t i = 0; i <= m; i++) rel[i] = off[base + i] - b0;
-        HIP_TRY(hipMemcpyAsync(c->d_cdoff, rel.data(), sizeof(uint64_t) * (m + 1), hipMemcpyHostToDevice, c->stream));
-        if (bytes) HIP_TRY(hipMemcpyAsync(c->d_cd, blob + b0, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
-        if ((rc = enqueue_wire_chunk(c, m, c->d_cd, c->d_cdoff, bytes, c->d_status, c->d_recv, c->stream, true)) != ZKV_OK) return rc;
+    const size_t chunk = wire_host_chunk(c->ws.cap);
+    if ((rc = grow(&c->d_st_all, &c->st_all_cap, n)) != ZKV_OK || (rc = grow(&c->d_rv_all, &c->rv_all_cap, 4 * n)) != ZKV_OK) return rc;
+    uint64_t max_bytes = 0;
+    for (size_t base = 0; base < n; base += chunk) {
+        size_t m = n - base < chunk ? n - base : chunk;
+        uint64_t bytes = off[base + m] - off[base];
+        if (bytes > max_bytes) max_bytes = bytes;
+    }
+    // all device buffers are sized before the loop: growing one frees it, which synchronises the device
+    for (int b = 0; b < 2; b++)
+        if ((n > chunk || b == 0) && (rc = grow(&c->d_cd[b], &c->cd_cap[b], (size_t)max_bytes + 8)) != ZKV_OK) return rc;
+    if ((rc = grow(&c->d_blob, &c->blob_cap, chunk * ZKV_SEAL_BYTES + 8)) != ZKV_OK) return rc;
+    if (c->vm == ZKV_VM_SP1 && (rc = grow(&c->d_pv, &c->pv_cap, (size_t)(max_bytes / 32) + 64)) != ZKV_OK) return rc;
+    std::vector<uint64_t> rel[2];
+    size_t k = 0;
+    for (size_t base = 0; base < n; base += chunk, k++) {
+        const size_t m = n - base < chunk ? n - base : chunk;
+        const int b = (int)(k & 1);
+        const uint64_t b0 = off[base], bytes = off[base + m] - b0;
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_decoded[b], 0));     // chunk k-2 has been decoded out of this buffer
+        HIP_TRY(hipStreamSynchronize(c->copy_stream));                                    // rel[b] of chunk k-2 is no longer being read
+        rel[b].resize(m + 1);
+        for (size_t i = 0; i <= m; i++) rel[b][i] = off[base + i] - b0;
+        HIP_TRY(hipMemcpyAsync(c->d_cdoff[b], rel[b].data(), sizeof(uint64_t) * (m + 1), hipMemcpyHostToDevice, c->copy_stream));
+        if (bytes) HIP_TRY(hipMemcpyAsync(c->d_cd[b], blob + b0, (size_t)bytes, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(hipEventRecord(c->ev_copied[b], c->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_copied[b], 0));
+        if ((rc = enqueue_wire_chunk(c, m, c->d_cd[b], c->d_cdoff[b], bytes, c->d_st_all + base, c->d_rv_all + 4 * base, c->stream,
+                                     base + chunk >= n, c->ev_decoded[b])) != ZKV_OK) return rc;
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(st.data(), c->d_status, m, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(rv.data(), c->d_recv, 4 * m, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        for (size_t i = 0; i < m; i++) {
-            uint8_t* out = returndata + (base + i) * ZKV_RETURNDATA_STRIDE;
-            if (st[i] == ZKV_STATUS_BAD_CALLDATA)
-                host_method(c, blob + off[base + i], (size_t)(off[base + i + 1] - off[base + i]), out, &returndata_len[base + i], &reverted[base + i]);
-            else verify_returndata(c, st[i], rv.data() + 4 * i, out, &returndata_len[base + i], &reverted[base + i]);
-            if (status) status[base + i] = st[i];
-        }
+    }
+    std::vector<uint8_t> st(n), rv(4 * n);
+    HIP_TRY(hipMemcpyAsync(st.data(), c->d_st_all, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(rv.data(), c->d_rv_all, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->copy_stream));
+    for (size_t i = 0; i < n; i++) {
+        uint8_t* out = returndata + i * ZKV_RETURNDATA_STRIDE;
+        if (st[i] == ZKV_STATUS_BAD_CALLDATA) host_method(c, blob + off[i], (size_t)(off[i + 1] - off[i]), out, &returndata_len[i], &reverted[i]);
+        else verify_returndata(c, st[i], rv.data() + 4 * i, out, &returndata_len[i], &reverted[i]);
+        if (status) status[i] = st[i];
     }
     return ZKV_OK;
 }

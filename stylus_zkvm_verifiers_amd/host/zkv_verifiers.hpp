@@ -8,6 +8,7 @@
 // is the ABI-encoded Solidity custom error; here `Result::err` holds exactly those bytes.  Library/runtime failures
 // (no device, HIP errors) are thrown as zkv::RuntimeError -- they are never verification outcomes.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <stdexcept>
@@ -126,5 +127,46 @@ public:
 private:
     zkv_ctx* ctx_;
 };
+
+
+// ---- on-chain wire layer: eth_call calldata in, return / revert data out (include/zkv.h, "on-chain wire layer";
+// Solidity view of the traits: examples/risc0-verifier/examples/interact.rs:31-43, examples/sp1-verifier/examples/interact.rs:11-19)
+struct CallResult { bool reverted; Bytes data; uint8_t status; };
+
+inline Bytes encode_verify_call(const Bytes& seal, const B256& image_id, const B256& journal_digest) {
+    Bytes out(zkv_risc0_encode_verify_call(seal.data(), seal.size(), image_id.data(), journal_digest.data(), nullptr, 0));
+    zkv_risc0_encode_verify_call(seal.data(), seal.size(), image_id.data(), journal_digest.data(), out.data(), out.size());
+    return out;
+}
+inline Bytes encode_verify_integrity_call(const Bytes& seal, const B256& claim_digest) {
+    Bytes out(zkv_risc0_encode_verify_integrity_call(seal.data(), seal.size(), claim_digest.data(), nullptr, 0));
+    zkv_risc0_encode_verify_integrity_call(seal.data(), seal.size(), claim_digest.data(), out.data(), out.size());
+    return out;
+}
+inline Bytes encode_verify_proof_call(const B256& program_vkey, const Bytes& public_values, const Bytes& proof_bytes) {
+    Bytes out(zkv_sp1_encode_verify_proof_call(program_vkey.data(), public_values.data(), public_values.size(), proof_bytes.data(), proof_bytes.size(), nullptr, 0));
+    zkv_sp1_encode_verify_proof_call(program_vkey.data(), public_values.data(), public_values.size(), proof_bytes.data(), proof_bytes.size(), out.data(),
+                                     out.size());
+    return out;
+}
+// n eth_calls against one verifier (zkv::RiscZeroVerifier or zkv::Sp1Verifier)
+template <class Verifier>
+inline std::vector<CallResult> eth_call_batch(const Verifier& v, const std::vector<Bytes>& calls) {
+    const size_t n = calls.size();
+    std::vector<uint64_t> off(n + 1, 0);
+    for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + calls[i].size();
+    Bytes blob(off[n] + 1);
+    for (size_t i = 0; i < n; i++) std::copy(calls[i].begin(), calls[i].end(), blob.begin() + off[i]);
+    Bytes rev(n), st(n), ret(n * ZKV_RETURNDATA_STRIDE + 1);
+    std::vector<uint32_t> len(n);
+    int rc = zkv_ctx_vm(v.raw()) == ZKV_VM_SP1
+                 ? zkv_sp1_eth_call_batch(v.raw(), n, blob.data(), off.data(), rev.data(), ret.data(), len.data(), st.data())
+                 : zkv_risc0_eth_call_batch(v.raw(), n, blob.data(), off.data(), rev.data(), ret.data(), len.data(), st.data());
+    check(rc, "zkv_eth_call_batch");
+    std::vector<CallResult> out(n);
+    for (size_t i = 0; i < n; i++)
+        out[i] = CallResult{rev[i] != 0, Bytes(ret.begin() + i * ZKV_RETURNDATA_STRIDE, ret.begin() + i * ZKV_RETURNDATA_STRIDE + len[i]), st[i]};
+    return out;
+}
 
 }  // namespace zkv

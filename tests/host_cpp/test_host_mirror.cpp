@@ -23,12 +23,19 @@ int main(int argc, char** argv) {
     auto vkd = v.get_verifier_key_digest(); printf(" vk_digest="); hex(vkd.data(), 32);
     zkv::Sp1Verifier s(0);
     printf(" sp1_version=%s", s.version().c_str());
+    auto cd = zkv::encode_verify_call(unhex(argv[3]), arr<32>(argv[4]), arr<32>(argv[5]));
+    printf(" calldata_len=%zu calldata_head=", cd.size()); hex(cd.data(), 36);
     if (zkv_device_count() > 0) {
         auto ok = v.verify(unhex(argv[3]), arr<32>(argv[4]), arr<32>(argv[5]));
         printf(" verify_ok=%d", (int)ok.ok);
         zkv::Bytes bad = unhex(argv[3]); bad[0] ^= 1;
         auto mm = v.verify(bad, arr<32>(argv[4]), arr<32>(argv[5]));
         printf(" mismatch_status=%d mismatch_err=", (int)mm.status); hex(mm.err.data(), mm.err.size());
+        uint8_t gs[4]; zkv_abi_function_selector("getSelector()", gs);
+        auto calls = zkv::eth_call_batch(v, {cd, zkv::Bytes(gs, gs + 4), zkv::Bytes{1, 2, 3}});
+        printf(" call0_reverted=%d call0_ret=", (int)calls[0].reverted); hex(calls[0].data.data(), calls[0].data.size());
+        printf(" call1_ret="); hex(calls[1].data.data(), calls[1].data.size());
+        printf(" call2_reverted=%d call2_len=%zu call2_status=%d", (int)calls[2].reverted, calls[2].data.size(), (int)calls[2].status);
     } else {
         try { v.verify(unhex(argv[3]), arr<32>(argv[4]), arr<32>(argv[5])); printf(" verify=unexpected"); }
         catch (const zkv::RuntimeError& e) { printf(" verify_runtime_error=%d", e.code); }

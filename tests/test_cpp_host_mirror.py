@@ -28,6 +28,7 @@ def test_cpp_mirror_host_logic(real_proofs):
     assert kv['reinit_status'] == '3' and kv['reinit_err'] == '0dc149f0'
     assert kv['selector'] == r['selector'] and kv['vk_digest'] == r['vk_digest']
     assert kv['sp1_version'] == 'v5.0.0'
+    assert kv['calldata_len'] == '8452' and kv['calldata_head'] == 'f8b3b60b' + '00' * 31 + '60'
     if 'verify_runtime_error' in kv:
         assert kv['verify_runtime_error'] == '-2'       # ZKV_ERR_NO_DEVICE: no CPU fallback
 
@@ -38,3 +39,7 @@ def test_cpp_mirror_verifies_on_gpu(real_proofs):
     assert kv['verify_ok'] == '1'
     assert kv['mismatch_status'] == '5'
     assert kv['mismatch_err'].startswith('b8b38d4c9e39696c')
+    # wire layer through the C++ mirror: verify() call -> true word, getSelector() -> bytes4 word, garbage -> empty revert
+    assert kv['call0_reverted'] == '0' and kv['call0_ret'] == '00' * 31 + '01'
+    assert kv['call1_ret'] == real_proofs['risc0']['selector'] + '00' * 28
+    assert (kv['call2_reverted'], kv['call2_len'], kv['call2_status']) == ('1', '0', '6')

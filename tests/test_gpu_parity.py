@@ -2,6 +2,8 @@
 
 Pinned by the reference: the two real proofs (examples/*/examples/interact.rs) must ACCEPT.
 Everything else is agreement with the oracle / spec model => "parity unpinned" (SURVEY.md 8c)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -293,9 +295,15 @@ def test_wire_layer_cases_match_golden_and_oracle(zkv, r0, sp1, wire_cases):
     for key, (ver, oracle_call) in groups.items():
         cases = [c for c in wire_cases['cases'] if (c['vm'], c['ctx']) == key]
         cds = [calldata_of(c, *enc) for c in cases]
-        for order in (cds, cds[::-1]):                        # both orders: request offsets get every alignment
-            rev, ret, st = zkv.wire.eth_call_batch(ver, order)
-            cs = cases if order is cds else cases[::-1]
+        for order, host_chunk in ((cds, None), (cds[::-1], None), (cds, '7')):
+            # both orders: request offsets get every alignment; 7-request chunks: the double-buffered H2D pipeline rotates
+            if host_chunk:
+                os.environ['ZKV_WIRE_HOST_CHUNK'] = host_chunk
+            try:
+                rev, ret, st = zkv.wire.eth_call_batch(ver, order)
+            finally:
+                os.environ.pop('ZKV_WIRE_HOST_CHUNK', None)
+            cs = cases[::-1] if order is not cds else cases
             for c, cd, rv, rd, s in zip(cs, order, rev, ret, st):
                 assert (bool(rv), rd.hex()) == (c['reverted'], c['returndata']), (key, c['name'])
                 assert int(s) == (6 if c['status'] is None else c['status']), (key, c['name'])
@@ -385,3 +393,53 @@ def test_dev_calls_on_different_streams_do_not_race(zkv, r0, real_proofs):
     for d, mut, d_st in batches:
         st = d_st.cpu().numpy()
         assert ((st == 0) == ~mut).all()
+
+
+def test_full_size_configs_through_properties(zkv, r0, sp1, real_proofs):
+    """BASELINE.json's single-GPU sizes (2^16 RISC Zero proofs, 2^20 SP1 proofs -- eight 2^17-proof chunks) checked through
+    size-independent properties: accept <=> not mutated by construction for every proof, permutation equivariance (the batch
+    is a seeded shuffle of copies of a 2^12 base batch whose statuses the oracle-pinned tests cover: status[i] must equal
+    base_status[source[i]]), and idempotence (a second run returns the same bytes)."""
+    import torch
+    from stylus_zkvm_verifiers_amd import synth
+    dev = torch.device('cuda', 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    nb = 1 << 12
+
+    def run_r0(seals, ids, jds):
+        d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (seals, ids, jds)]
+        d_st = torch.full((len(seals),), 255, dtype=torch.uint8, device=dev)
+        r0.verify_batch_dev(len(seals), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d_st.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        return d_st.cpu().numpy()
+
+    r = real_proofs['risc0']
+    seals, mut, mclass, flip = synth.make_batch('risc0', H(r['seal']), nb, 0x5A4B5651, pool=8, mutate_every=16)
+    ids = np.tile(np.frombuffer(H(r['image_id']), dtype=np.uint8), (nb, 1))
+    jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (nb, 1)); jds[flip, 0] ^= 1
+    base = run_r0(seals, ids, jds)
+    assert ((base == 0) == ~mut).all()
+    n = 1 << 16
+    src = np.random.default_rng(0x5A4B5652).permutation(n) % nb
+    st = run_r0(seals[src], ids[src], jds[src])
+    assert (st == base[src]).all() and int((st == 0).sum()) == int((~mut[src]).sum())
+    assert (run_r0(seals[src], ids[src], jds[src]) == st).all()
+
+    s = real_proofs['sp1']
+    proofs, mut, mclass, flip = synth.make_batch('sp1', H(s['proof']), nb, 0x5A4B5653, pool=8, mutate_every=16)
+    vk = np.tile(np.frombuffer(H(s['vkey']), dtype=np.uint8), (nb, 1))
+    pv = np.tile(np.frombuffer(H(s['public_values']), dtype=np.uint8), (nb, 1)); pv[flip, -1] ^= 1
+
+    def run_sp1(proofs, vk, pv):
+        d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (vk, pv, proofs)]
+        d_st = torch.full((len(proofs),), 255, dtype=torch.uint8, device=dev)
+        sp1.verify_batch_dev(len(proofs), d[0].data_ptr(), d[1].data_ptr(), pv.shape[1], d[2].data_ptr(), d_st.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        return d_st.cpu().numpy()
+
+    base = run_sp1(proofs, vk, pv)
+    assert ((base == 0) == ~mut).all()
+    n = 1 << 20
+    src = np.random.default_rng(0x5A4B5654).permutation(n) % nb
+    st = run_sp1(proofs[src], vk[src], pv[src])
+    assert (st == base[src]).all() and int((st == 0).sum()) == int((~mut[src]).sum())
