@@ -200,6 +200,24 @@ def precompile_fixture(rng):
     ]
     for name, d in pcases:
         out['pairing'].append(dict(name=name, input=hx(d), output=try_call(m.ecpairing, d)))
+    # Publicly known alt_bn128 values, hard-coded (NOT derived from the spec model, which is asserted to agree):
+    # 2*G1 for G1 = (1, 2), and the canonical G2 generator of EIP-197 (equal to the reference's RISC Zero gamma2,
+    # risc0/crypto.rs:32-41).  They pin ecAdd / ecMul / the pairing's input validation to values outside this repository.
+    two_g = (0x030644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd3, 0x15ed738c0e0a7c92e7845f96b2ae9c0a68a6a449e3538fc7ff3ebf7a5a18a2c4)
+    g2gen = ((0x1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed, 0x198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c2),
+             (0x12c85ea5db8c6deb4aab71808dcb408fe3d1e7690c43d37b4ce6cc0166fa7daa, 0x090689d0585ff075ec9e99ad690c3395bc4b313370b38ef355acdadcd122975b))
+    d = enc(G1) + enc(G1)
+    assert m.ecadd(d) == enc(two_g)
+    out['ecadd'].append(dict(name='public: G + G = 2G', input=hx(d), output=hx(enc(two_g))))
+    d = enc(G1) + m.be32(2)
+    assert m.ecmul(d) == enc(two_g)
+    out['ecmul'].append(dict(name='public: 2 * G = 2G', input=hx(d), output=hx(enc(two_g))))
+    d = enc(G1) + g2enc(g2gen) + enc((1, m.P - 2)) + g2enc(g2gen)
+    assert m.ecpairing(d) == m.be32(1)
+    out['pairing'].append(dict(name='public: e(G1, G2) e(-G1, G2) = 1 on the canonical generators', input=hx(d), output=hx(m.be32(1))))
+    d = enc(two_g) + g2enc(g2gen) + enc((1, m.P - 2)) + g2enc(g2gen)
+    assert m.ecpairing(d) == m.be32(0)
+    out['pairing'].append(dict(name='public: e(2G1, G2) e(-G1, G2) != 1', input=hx(d), output=hx(m.be32(0))))
     return out
 
 
