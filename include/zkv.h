@@ -90,6 +90,28 @@ int zkv_risc0_verify_integrity(zkv_ctx* ctx, const uint8_t* seal, size_t seal_le
 int zkv_risc0_verify_batch_dev(zkv_ctx* ctx, size_t n, const uint8_t* d_seals, const uint8_t* d_image_ids,
                                const uint8_t* d_journal_digests, uint8_t* d_status, uint8_t* d_recv_selector, void* stream);
 
+/* ------------------------------------------------------------------ RISC Zero verifier sets
+ * Many `RiscZeroVerifier` instances -- one per (control_root, bn254_control_id), i.e. per zkVM release -- resident on one
+ * device: they share the verification key (risc0/crypto.rs:16-89), hence the line tables, the e(alpha, beta) value, the
+ * window tables and the workspace; per instance the device keeps only what `initialize` derives (risc0/verifier.rs:58-76,
+ * 128-144): the selector (its SHA-256 chain runs in the set-up kernel), the control-id range flag and the instance's
+ * share of vk_x.  Every proof of a batch names its instance; its outcome is exactly that instance's `verify` outcome.
+ * An index >= the set size behaves like an un-initialised verifier (ZKV_STATUS_INVALID_INITIALIZATION). */
+#define ZKV_VM_RISC0_SET 4
+zkv_ctx* zkv_risc0_set_create(size_t n_instances, const uint8_t* control_roots /* n x 32 */, const uint8_t* bn254_control_ids /* n x 32 */,
+                              int device);
+size_t zkv_risc0_set_size(const zkv_ctx* ctx);
+/* get_selector of one instance (derived on the device: needs a gfx950 device) */
+int zkv_risc0_set_get_selector(zkv_ctx* ctx, size_t instance, uint8_t out[4]);
+/* IRiscZeroVerifier::verify over a batch, proof i against instance[i] */
+int zkv_risc0_set_verify_batch(zkv_ctx* ctx, size_t n, const uint32_t* instance, const uint8_t* seal_blob, const uint64_t* seal_off,
+                               const uint8_t* image_ids, const uint8_t* journal_digests, uint8_t* status, uint8_t* recv_selector);
+/* fixed-stride 260-byte seals, everything (including the instance indices) resident in HBM; asynchronous on `stream` */
+int zkv_risc0_set_verify_batch_dev(zkv_ctx* ctx, size_t n, const uint32_t* d_instance, const uint8_t* d_seals, const uint8_t* d_image_ids,
+                                   const uint8_t* d_journal_digests, uint8_t* d_status, uint8_t* d_recv_selector, void* stream);
+/* compute_vk_x (common/groth16.rs:51-58) of (instance[i], claim digest halves i): var_signals n x 2 x 32 bytes, out n x 64 */
+int zkv_risc0_set_vk_x_batch(zkv_ctx* ctx, size_t n, const uint32_t* instance, const uint8_t* var_signals, uint8_t* out);
+
 /* ------------------------------------------------------------------ SP1 verifier
  * Replaces `Sp1Verifier` + `ISp1Verifier` (sp1/verifier.rs:16-56). */
 zkv_ctx* zkv_sp1_ctx_create(int device);
@@ -179,7 +201,7 @@ int zkv_groth16_verify_batch(zkv_ctx* ctx, size_t n, const uint8_t* proofs, cons
 int zkv_ctx_vk_x_batch(zkv_ctx* ctx, size_t n, const uint8_t* var_signals, uint8_t* out);
 
 /* ------------------------------------------------------------------ shared */
-int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_RISC0 / ZKV_VM_SP1 */
+int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_* */
 /* Tuning knob (no reference counterpart): kernel mapping of the G2 / Miller / final-exponentiation stages.
  * 2 = one proof per pair of lanes (default, two wavefronts per SIMD), 1 = one proof per lane, 0 = library default
  * (environment ZKV_LANES_PER_PROOF).  Results are identical. */

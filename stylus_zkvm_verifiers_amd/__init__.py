@@ -5,13 +5,13 @@ Drop-in for the verify path of gnosisguild/stylus-zkvm-verifiers: `RiscZeroVerif
 (libzkv_mi355x.so, C ABI in include/zkv.h).  There is no CPU fallback."""
 from . import errors
 from .errors import VerifierError
-from .risc0 import RiscZeroVerifier
+from .risc0 import RiscZeroVerifier, RiscZeroVerifierSet
 from .sp1 import Sp1Verifier
 from .bn254 import Bn254Precompiles
 from .groth16 import Groth16Verifier
 from . import wire
 
-__all__ = ['RiscZeroVerifier', 'Sp1Verifier', 'Bn254Precompiles', 'Groth16Verifier', 'VerifierError', 'errors', 'wire', 'device_count']
+__all__ = ['RiscZeroVerifier', 'RiscZeroVerifierSet', 'Sp1Verifier', 'Bn254Precompiles', 'Groth16Verifier', 'VerifierError', 'errors', 'wire', 'device_count']
 
 
 def device_count():

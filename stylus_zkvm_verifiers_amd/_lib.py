@@ -29,6 +29,12 @@ SYMBOLS = {
     'zkv_risc0_verify': (_i, [_vp, _cp, _sz, _cp, _cp, _u8p, _cp]),
     'zkv_risc0_verify_integrity': (_i, [_vp, _cp, _sz, _cp, _u8p, _cp]),
     'zkv_risc0_verify_batch_dev': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'zkv_risc0_set_create': (_vp, [_sz, _cp, _cp, _i]),
+    'zkv_risc0_set_size': (_sz, [_vp]),
+    'zkv_risc0_set_get_selector': (_i, [_vp, _sz, _cp]),
+    'zkv_risc0_set_verify_batch': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'zkv_risc0_set_verify_batch_dev': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'zkv_risc0_set_vk_x_batch': (_i, [_vp, _sz, _vp, _vp, _vp]),
     'zkv_sp1_ctx_create': (_vp, [_i]),
     'zkv_sp1_verifier_hash': (_i, [_cp]),
     'zkv_sp1_version': (_cp, []),

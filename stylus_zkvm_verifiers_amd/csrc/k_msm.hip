@@ -4,7 +4,7 @@
 
 namespace zkv {
 
-__global__ __launch_bounds__(ZKV_BLOCK) void k_msm(size_t n, const VkTables* __restrict__ vk, Workspace ws) {
+__global__ __launch_bounds__(ZKV_BLOCK) void k_msm(size_t n, const VkTables* __restrict__ vk, const InstTab* __restrict__ inst_tab, Workspace ws) {
     size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t flags = ws.flags[i];
@@ -18,7 +18,11 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_msm(size_t n, const VkTables* __r
         for (int k = 0; k < 8; k++) in.s[b][k] = ws.prep[(size_t)(64 + 8 * b + k) * ws.cap + i];
     }
     G1Norm o;
-    msm_normalize(*vk, in, flags, o);
+    if (inst_tab) {                          // verifier set: the instance index rides in the upper bits of the flags word
+        const InstTab& t = inst_tab[flags >> 8];
+        flags &= 0xFFu;
+        msm_normalize(*vk, in, flags, o, t.base, t.base_inf);
+    } else msm_normalize(*vk, in, flags, o);
     ws_st(ws.norm, ws.cap, 0, i, o.axs); ws_st(ws.norm, ws.cap, 8, i, o.ays);
     ws_st(ws.norm, ws.cap, 16, i, o.lxs); ws_st(ws.norm, ws.cap, 24, i, o.lys);
     ws_st(ws.norm, ws.cap, 32, i, o.cxs); ws_st(ws.norm, ws.cap, 40, i, o.cys);
@@ -26,12 +30,13 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_msm(size_t n, const VkTables* __r
 }
 
 // compute_vk_x alone (zkv_ctx_vk_x_batch): same tables and window walk as k_msm, affine result as 64 big-endian bytes.
-__global__ __launch_bounds__(ZKV_BLOCK) void k_vk_x(size_t n, const VkTables* __restrict__ vk, const uint8_t* __restrict__ sig, uint8_t* __restrict__ out) {
+__global__ __launch_bounds__(ZKV_BLOCK) void k_vk_x(size_t n, const VkTables* __restrict__ vk, const InstTab* __restrict__ inst_tab,
+                                                     const uint32_t* __restrict__ inst, const uint8_t* __restrict__ sig, uint8_t* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (i >= n) return;
     PrepOut in;
     load_be256(in.s[0], sig + 64 * i); load_be256(in.s[1], sig + 64 * i + 32);
-    G1J acc = msm_accumulate(*vk, in);
+    G1J acc = inst_tab ? msm_accumulate(*vk, in, inst_tab[inst[i]].base, inst_tab[inst[i]].base_inf) : msm_accumulate(*vk, in);
     G1A a; uint32_t inf;
     g1j_to_affine(acc, a, inf);
     uint32_t r[8];
@@ -47,14 +52,14 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_vk_x(size_t n, const VkTables* __
         }
     }
 }
-void launch_vk_x(size_t n, const VkTables* d_tab, const uint8_t* sig, uint8_t* out, hipStream_t s) {
+void launch_vk_x(size_t n, const VkTables* d_tab, const InstTab* inst_tab, const uint32_t* inst, const uint8_t* sig, uint8_t* out, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_vk_x, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, d_tab, sig, out);
+    hipLaunchKernelGGL(k_vk_x, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, d_tab, inst_tab, inst, sig, out);
 }
 
-void launch_msm(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s) {
+void launch_msm(size_t n, const VkTables* d_tab, const InstTab* inst_tab, const Workspace& ws, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_msm, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, d_tab, ws);
+    hipLaunchKernelGGL(k_msm, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, d_tab, inst_tab, ws);
 }
 
 }  // namespace zkv

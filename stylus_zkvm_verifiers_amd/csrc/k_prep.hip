@@ -44,7 +44,8 @@ __device__ __forceinline__ bool stage_seals(const PrepArgs& a, uint32_t* lds) {
 
 // shared front: locate the record, run the reference's ordered checks (len < 4, selector, strict decode).
 // Returns true when the 8 words should be parsed; otherwise *st holds the final status.
-__device__ __forceinline__ bool front_checks(const PrepArgs& a, size_t i, bool staged, const uint32_t* lds, SealReader& rd, uint8_t& st) {
+__device__ __forceinline__ bool front_checks(const PrepArgs& a, size_t i, bool staged, const uint32_t* lds, SealReader& rd, uint8_t& st,
+                                             uint32_t& inst_bits) {
     size_t len;
     rd.lds_row = nullptr;
     if (a.off) { rd.rec = a.blob + a.off[i]; len = (size_t)(a.off[i + 1] - a.off[i]); }
@@ -52,16 +53,22 @@ __device__ __forceinline__ bool front_checks(const PrepArgs& a, size_t i, bool s
         rd.rec = a.blob + i * (size_t)a.stride; len = a.len ? a.len[i] : a.stride;
         if (staged) rd.lds_row = lds + threadIdx.x * 65u;
     }
-    uint32_t rv = 0;
-    bool go = false;
+    uint32_t rv = 0, expect = a.selector_be, ctx_fail = a.force_fail;
+    bool go = false, known = true;
+    inst_bits = 0;
+    if (a.inst) {                                                   // verifier set: this proof's instance
+        const uint32_t idx = a.inst[i];
+        known = idx < a.n_inst;                                     // an unregistered instance is an un-initialised verifier
+        if (known) { expect = a.inst_tab[idx].selector_be; ctx_fail = a.inst_tab[idx].fail; inst_bits = idx << 8; }
+    }
     if (a.len && len == 0xFFFFFFFFu) st = ST_BAD_CALLDATA;         // wire layer: the router could not decode the call
-    else if (a.not_initialized) st = ST_INVALID_INITIALIZATION;     // risc0/verifier.rs:84-86, 99-101
+    else if (a.not_initialized || !known) st = ST_INVALID_INITIALIZATION;     // risc0/verifier.rs:84-86, 99-101
     else if (len < 4) st = ST_INVALID_PROOF_DATA;                       // verifier.rs:151 / sp1 verifier.rs:64
     else {
         uint32_t sel = rd.word(0);
-        if (sel != a.selector_be) { st = ST_SELECTOR_MISMATCH; rv = sel; }        // :155-165 / :68-78
+        if (sel != expect) { st = ST_SELECTOR_MISMATCH; rv = sel; }        // :155-165 / :68-78
         else if (len != 260) st = ST_INVALID_PROOF_DATA;            // strict abi_decode of 8 static words
-        else if (a.force_fail) st = ST_VERIFICATION_FAILED;
+        else if (ctx_fail) st = ST_VERIFICATION_FAILED;
         else { st = ST_VERIFICATION_FAILED; go = true; }
     }
     if (a.recv) {
@@ -77,8 +84,8 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_prep_risc0(PrepArgs a, Risc0Const
     size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (i >= a.n) return;
     SealReader rd; uint8_t st;
-    uint32_t flags = 0;
-    if (front_checks(a, i, staged, seal_lds, rd, st)) {
+    uint32_t flags = 0, inst_bits;
+    if (front_checks(a, i, staged, seal_lds, rd, st, inst_bits)) {
         PrepOut o;
         for (int b = 2; b < MAX_VAR; b++) for (int k2 = 0; k2 < 8; k2++) o.s[b][k2] = 0;
         uint32_t h[8];
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_prep_risc0(PrepArgs a, Risc0Const
         uint32_t w[8][8];
 #pragma unroll 1
         for (int j = 0; j < 8; j++) rd.u256(w[j], 1 + 8 * j);
-        if (prep_points(w, true, o)) { flags = o.flags; store_prep(ws, i, o); }
+        if (prep_points(w, true, o)) { flags = o.flags | inst_bits; store_prep(ws, i, o); }
     }
     ws.flags[i] = flags;
     a.status[i] = st;
@@ -104,8 +111,8 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_prep_sp1(PrepArgs a, Workspace ws
     size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (i >= a.n) return;
     SealReader rd; uint8_t st;
-    uint32_t flags = 0;
-    if (front_checks(a, i, staged, seal_lds, rd, st)) {
+    uint32_t flags = 0, inst_bits;
+    if (front_checks(a, i, staged, seal_lds, rd, st, inst_bits)) {
         PrepOut o;
         for (int b = 2; b < MAX_VAR; b++) for (int k2 = 0; k2 < 8; k2++) o.s[b][k2] = 0;
         load_be256(o.s[0], a.in32_a + 32 * i);                      // U256::from_be_bytes(program_vkey), sp1/types.rs:24

@@ -30,6 +30,17 @@ __global__ __launch_bounds__(64) void k_setup_alpha_beta(const VkRaw* __restrict
     setup_alpha_beta(*raw, *t, fm, tm);
 }
 
+// one lane per instance of a verifier set: selector (SHA-256 on the device), control-id range check, per-instance part of vk_x
+__global__ __launch_bounds__(64) void k_setup_instances(const VkRaw* __restrict__ raw, InstConsts k, const InstRaw* __restrict__ in, InstTab* __restrict__ out,
+                                                        uint32_t n_inst) {
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n_inst) setup_instance(*raw, k, in[i], out[i]);
+}
+void launch_setup_instances(const VkRaw* d_raw, const InstConsts& k, const InstRaw* d_in, InstTab* d_out, uint32_t n_inst, hipStream_t s) {
+    if (!n_inst) return;
+    hipLaunchKernelGGL(k_setup_instances, dim3((n_inst + 63) / 64), dim3(64), 0, s, d_raw, k, d_in, d_out, n_inst);
+}
+
 void launch_setup(const VkRaw* d_raw, VkTables* d_tab, hipStream_t s) {
     hipLaunchKernelGGL(k_setup_validate, dim3(1), dim3(64), 0, s, d_raw, d_tab);
     hipLaunchKernelGGL(k_setup_base, dim3(1), dim3(64), 0, s, d_raw, d_tab);

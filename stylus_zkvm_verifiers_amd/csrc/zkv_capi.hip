@@ -22,6 +22,11 @@ struct zkv_ctx {
     bool initialized = false, id_ge_r = false;
     uint8_t control_root_0[16] = {0}, control_root_1[16] = {0}, control_id[32] = {0}, selector[4] = {0};
     Risc0Consts consts;
+    // ZKV_VM_RISC0_SET: n_inst verifier instances sharing the VK tables and the workspace
+    std::vector<InstRaw> inst_raw;
+    std::vector<InstTab> inst_host;          // copy of the device table (selectors derived on the device) for the getters
+    InstTab* d_inst = nullptr;
+    uint32_t* d_inst_idx = nullptr;
     uint8_t gvk[448 + 64 * MAX_IC] = {0};    // ZKV_VM_GROTH16: the caller's verification key
     uint32_t g_n_ic = 0; bool g_negate = false, vk_invalid = false;
     // device side (created lazily on the first compute call)
@@ -84,7 +89,7 @@ static void ctx_free_device(zkv_ctx* c) {
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_tab, c->ws.prep, c->ws.norm, c->ws.f, c->ws.fe, c->ws.flags, c->d_blob, c->d_a, c->d_b, c->d_pv,
                     c->d_status, c->d_recv, c->d_off, c->d_pvoff, c->d_cd[0], c->d_cd[1], c->d_kind, c->d_cdoff[0], c->d_cdoff[1], c->d_len,
-                    c->d_pvlen, c->d_st_all, c->d_rv_all};
+                    c->d_pvlen, c->d_st_all, c->d_rv_all, c->d_inst, c->d_inst_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_wire) if (e) (void)hipEventDestroy(e);
@@ -113,7 +118,7 @@ static int ctx_device_init(zkv_ctx* c) {
     HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
     if (c->vm != ZKV_VM_BN254) {
         VkRaw raw;
-        if (c->vm == ZKV_VM_RISC0) host::fill_vk_risc0(raw, c->control_root_0, c->control_root_1, c->control_id);
+        if (c->vm == ZKV_VM_RISC0 || c->vm == ZKV_VM_RISC0_SET) host::fill_vk_risc0(raw, c->control_root_0, c->control_root_1, c->control_id);
         else if (c->vm == ZKV_VM_GROTH16) host::fill_vk_generic(raw, c->gvk, c->g_n_ic);
         else host::fill_vk_sp1(raw);
         if (c->id_ge_r) memset(raw.fixed_scalar[5], 0, 32);      // never used: every proof fails the range check first
@@ -124,6 +129,22 @@ static int ctx_device_init(zkv_ctx* c) {
         HIP_TRY(hipMemcpyAsync(d_raw, &raw, sizeof raw, hipMemcpyHostToDevice, c->stream));
         launch_setup(d_raw, c->d_tab, c->stream);
         HIP_TRY(hipGetLastError());
+        if (c->vm == ZKV_VM_RISC0_SET) {
+            const size_t k = c->inst_raw.size();
+            InstRaw* d_in = nullptr;
+            InstConsts ic;
+            host::sha256_host((const uint8_t*)"risc0.Groth16ReceiptVerifierParameters", 38, ic.tag);
+            host::risc0_vk_digest(ic.vk_digest);
+            HIP_TRY(hipMalloc(&d_in, sizeof(InstRaw) * k));
+            HIP_TRY(hipMalloc(&c->d_inst, sizeof(InstTab) * k));
+            HIP_TRY(hipMemcpyAsync(d_in, c->inst_raw.data(), sizeof(InstRaw) * k, hipMemcpyHostToDevice, c->stream));
+            launch_setup_instances(d_raw, ic, d_in, c->d_inst, (uint32_t)k, c->stream);
+            HIP_TRY(hipGetLastError());
+            c->inst_host.resize(k);
+            HIP_TRY(hipMemcpyAsync(c->inst_host.data(), c->d_inst, sizeof(InstTab) * k, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            (void)hipFree(d_in);
+        }
         HIP_TRY(hipStreamSynchronize(c->stream));
         (void)hipFree(d_raw);
         uint32_t valid = 0;
@@ -140,7 +161,8 @@ static int ctx_device_init(zkv_ctx* c) {
         hipMalloc(&c->d_a, 32 * cap) != hipSuccess || hipMalloc(&c->d_b, 32 * cap) != hipSuccess ||
         hipMalloc(&c->d_status, cap) != hipSuccess || hipMalloc(&c->d_recv, 4 * cap) != hipSuccess ||
         hipMalloc(&c->d_off, sizeof(uint64_t) * (cap + 1)) != hipSuccess ||
-        hipMalloc(&c->d_pvoff, sizeof(uint64_t) * (cap + 1)) != hipSuccess) {
+        hipMalloc(&c->d_pvoff, sizeof(uint64_t) * (cap + 1)) != hipSuccess ||
+        (c->vm == ZKV_VM_RISC0_SET && hipMalloc(&c->d_inst_idx, sizeof(uint32_t) * cap) != hipSuccess)) {
         (void)hipGetLastError();
         return ZKV_ERR_OOM;
     }
@@ -172,11 +194,11 @@ static int mark_done(zkv_ctx* c, hipStream_t s) {
 // Enqueues the five stages for one chunk (all pointers device-resident).
 static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed) {
     if (timed) (void)hipEventRecord(c->ev[0], s);
-    if (c->vm == ZKV_VM_RISC0) launch_prep_risc0(a, c->consts, c->ws, s);
+    if (c->vm == ZKV_VM_RISC0 || c->vm == ZKV_VM_RISC0_SET) launch_prep_risc0(a, c->consts, c->ws, s);
     else if (c->vm == ZKV_VM_GROTH16) launch_prep_groth16(a, c->ws, s);
     else launch_prep_sp1(a, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[1], s);
-    launch_msm(a.n, c->d_tab, c->ws, s);
+    launch_msm(a.n, c->d_tab, a.inst ? c->d_inst : nullptr, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[2], s);
     const bool pair = (c->lanes ? c->lanes : lanes_per_proof()) == 2;
     if (pair) launch_g2chk2(a.n, c->ws, a.status, s); else launch_g2chk(a.n, c->ws, a.status, s);
@@ -357,6 +379,109 @@ ZKV_EXPORT int zkv_risc0_verify_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d
     if (!c || c->vm != ZKV_VM_RISC0) return ZKV_ERR_WRONG_CTX;
     if (n && !d_journal_digests) return ZKV_ERR_INVALID_ARG;
     return run_dev_batch(c, n, d_seals, d_image_ids, d_journal_digests, nullptr, 0, d_status, d_recv, stream);
+}
+
+// ------------------------------------------------------------------ RISC Zero verifier sets (many instances, one VK)
+ZKV_EXPORT zkv_ctx* zkv_risc0_set_create(size_t n_instances, const uint8_t* control_roots, const uint8_t* bn254_control_ids, int device) {
+    if (!n_instances || n_instances > ((size_t)1 << 24) || !control_roots || !bn254_control_ids) return nullptr;
+    zkv_ctx* c = new (std::nothrow) zkv_ctx();
+    if (!c) return nullptr;
+    c->vm = ZKV_VM_RISC0_SET; c->device = device; c->initialized = true;
+    host::risc0_consts(c->consts);
+    c->inst_raw.resize(n_instances);
+    for (size_t i = 0; i < n_instances; i++) {
+        memcpy(c->inst_raw[i].control_root, control_roots + 32 * i, 32);
+        memcpy(c->inst_raw[i].control_id, bn254_control_ids + 32 * i, 32);
+    }
+    return c;
+}
+ZKV_EXPORT size_t zkv_risc0_set_size(const zkv_ctx* c) { return c && c->vm == ZKV_VM_RISC0_SET ? c->inst_raw.size() : 0; }
+ZKV_EXPORT int zkv_risc0_set_get_selector(zkv_ctx* c, size_t instance, uint8_t out[4]) {
+    if (!c || c->vm != ZKV_VM_RISC0_SET) return ZKV_ERR_WRONG_CTX;
+    if (!out || instance >= c->inst_raw.size()) return ZKV_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ctx_device_init(c);                        // selectors are derived by the set-up kernel
+    if (rc != ZKV_OK) return rc;
+    const uint32_t s = c->inst_host[instance].selector_be;
+    out[0] = (uint8_t)(s >> 24); out[1] = (uint8_t)(s >> 16); out[2] = (uint8_t)(s >> 8); out[3] = (uint8_t)s;
+    return ZKV_OK;
+}
+// shared driver: host pointers when `dev` is false (one chunk at a time, synchronous), device pointers otherwise (asynchronous)
+static int run_set_batch(zkv_ctx* c, size_t n, const uint32_t* inst, const uint8_t* blob, const uint64_t* off, const uint8_t* ids, const uint8_t* jds,
+                         uint8_t* status, uint8_t* recv, bool dev, void* stream) {
+    if (!c || c->vm != ZKV_VM_RISC0_SET) return ZKV_ERR_WRONG_CTX;
+    if (n && (!inst || !blob || (!dev && !off) || !ids || !jds || !status)) return ZKV_ERR_INVALID_ARG;
+    if (!n) return ZKV_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ctx_device_init(c);
+    if (rc != ZKV_OK) return rc;
+    hipStream_t s = dev && stream ? (hipStream_t)stream : c->stream;
+    if ((rc = order_after_previous(c, s)) != ZKV_OK) return rc;
+    const size_t cap = c->ws.cap;
+    std::vector<uint64_t> rel(dev ? 0 : cap + 1);
+    for (size_t base = 0; base < n; base += cap) {
+        const size_t m = n - base < cap ? n - base : cap;
+        PrepArgs a;
+        memset(&a, 0, sizeof a);
+        a.n = m; a.inst_tab = c->d_inst; a.n_inst = (uint32_t)c->inst_raw.size();
+        if (dev) {
+            a.blob = blob + base * ZKV_SEAL_BYTES; a.stride = ZKV_SEAL_BYTES; a.inst = inst + base;
+            a.in32_a = ids + 32 * base; a.in32_b = jds + 32 * base; a.status = status + base; a.recv = recv ? recv + 4 * base : nullptr;
+        } else {
+            const uint64_t b0 = off[base], bytes = off[base + m] - b0;
+            if ((rc = grow(&c->d_blob, &c->blob_cap, (size_t)bytes + 8)) != ZKV_OK) return rc;
+            for (size_t i = 0; i <= m; i++) rel[i] = off[base + i] - b0;
+            HIP_TRY(hipMemcpyAsync(c->d_off, rel.data(), sizeof(uint64_t) * (m + 1), hipMemcpyHostToDevice, s));
+            if (bytes) HIP_TRY(hipMemcpyAsync(c->d_blob, blob + b0, (size_t)bytes, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(c->d_inst_idx, inst + base, sizeof(uint32_t) * m, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(c->d_a, ids + 32 * base, 32 * m, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(c->d_b, jds + 32 * base, 32 * m, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));               // rel[] is reused by the next chunk
+            a.blob = c->d_blob; a.off = c->d_off; a.inst = c->d_inst_idx; a.in32_a = c->d_a; a.in32_b = c->d_b;
+            a.status = c->d_status; a.recv = c->d_recv;
+        }
+        enqueue_chunk(c, a, s, base + cap >= n);
+        HIP_TRY(hipGetLastError());
+        if (!dev) {
+            HIP_TRY(hipMemcpyAsync(status + base, c->d_status, m, hipMemcpyDeviceToHost, s));
+            if (recv) HIP_TRY(hipMemcpyAsync(recv + 4 * base, c->d_recv, 4 * m, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+    }
+    return dev ? mark_done(c, s) : ZKV_OK;
+}
+ZKV_EXPORT int zkv_risc0_set_verify_batch(zkv_ctx* c, size_t n, const uint32_t* instance, const uint8_t* seal_blob, const uint64_t* seal_off,
+                                          const uint8_t* image_ids, const uint8_t* journal_digests, uint8_t* status, uint8_t* recv) {
+    if (recv && n) memset(recv, 0, 4 * n);
+    return run_set_batch(c, n, instance, seal_blob, seal_off, image_ids, journal_digests, status, recv, false, nullptr);
+}
+ZKV_EXPORT int zkv_risc0_set_verify_batch_dev(zkv_ctx* c, size_t n, const uint32_t* d_instance, const uint8_t* d_seals, const uint8_t* d_image_ids,
+                                              const uint8_t* d_journal_digests, uint8_t* d_status, uint8_t* d_recv, void* stream) {
+    return run_set_batch(c, n, d_instance, d_seals, nullptr, d_image_ids, d_journal_digests, d_status, d_recv, true, stream);
+}
+// compute_vk_x for (instance, claim halves): the per-instance signals come from the device table
+ZKV_EXPORT int zkv_risc0_set_vk_x_batch(zkv_ctx* c, size_t n, const uint32_t* instance, const uint8_t* var_signals, uint8_t* out) {
+    if (!c || c->vm != ZKV_VM_RISC0_SET) return ZKV_ERR_WRONG_CTX;
+    if (n && (!instance || !var_signals || !out)) return ZKV_ERR_INVALID_ARG;
+    if (!n) return ZKV_OK;
+    for (size_t i = 0; i < n; i++) if (instance[i] >= c->inst_raw.size()) return ZKV_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ctx_device_init(c);
+    if (rc != ZKV_OK) return rc;
+    if ((rc = order_after_previous(c, c->stream)) != ZKV_OK) return rc;
+    const size_t cap = c->ws.cap;
+    for (size_t base = 0; base < n; base += cap) {
+        size_t m = n - base < cap ? n - base : cap;
+        if ((rc = grow(&c->d_blob, &c->blob_cap, m * 64 + 8)) != ZKV_OK) return rc;
+        if ((rc = grow(&c->d_pv, &c->pv_cap, m * 64 + 8)) != ZKV_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_blob, var_signals + 64 * base, 64 * m, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_inst_idx, instance + base, sizeof(uint32_t) * m, hipMemcpyHostToDevice, c->stream));
+        launch_vk_x(m, c->d_tab, c->d_inst, c->d_inst_idx, c->d_blob, c->d_pv, c->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out + 64 * base, c->d_pv, 64 * m, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return ZKV_OK;
 }
 
 // ------------------------------------------------------------------ SP1
@@ -718,7 +843,7 @@ ZKV_EXPORT int zkv_groth16_verify_batch(zkv_ctx* c, size_t n, const uint8_t* pro
 
 // ------------------------------------------------------------------ Groth16 core pieces
 ZKV_EXPORT int zkv_ctx_vk_x_batch(zkv_ctx* c, size_t n, const uint8_t* var_signals, uint8_t* out) {
-    if (!c || c->vm == ZKV_VM_BN254) return ZKV_ERR_WRONG_CTX;
+    if (!c || c->vm == ZKV_VM_BN254 || c->vm == ZKV_VM_RISC0_SET) return ZKV_ERR_WRONG_CTX;
     if (c->vm == ZKV_VM_RISC0 && !c->initialized) return ZKV_ERR_INVALID_ARG;
     if (n && (!var_signals || !out)) return ZKV_ERR_INVALID_ARG;
     if (!n) return ZKV_OK;
@@ -732,7 +857,7 @@ ZKV_EXPORT int zkv_ctx_vk_x_batch(zkv_ctx* c, size_t n, const uint8_t* var_signa
         if ((rc = grow(&c->d_blob, &c->blob_cap, m * 64 + 8)) != ZKV_OK) return rc;
         if ((rc = grow(&c->d_pv, &c->pv_cap, m * 64 + 8)) != ZKV_OK) return rc;
         HIP_TRY(hipMemcpyAsync(c->d_blob, var_signals + 64 * base, 64 * m, hipMemcpyHostToDevice, c->stream));
-        launch_vk_x(m, c->d_tab, c->d_blob, c->d_pv, c->stream);
+        launch_vk_x(m, c->d_tab, nullptr, nullptr, c->d_blob, c->d_pv, c->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(out + 64 * base, c->d_pv, 64 * m, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));

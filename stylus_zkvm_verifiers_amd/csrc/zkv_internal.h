@@ -49,6 +49,8 @@ struct PrepArgs {
     const uint32_t* len;
     const uint8_t* kind;
     const uint32_t* pv_len;
+    // verifier sets (zkv_risc0_set_*): per-proof instance index; selector and context-level failure come from the table
+    const uint32_t* inst; const InstTab* inst_tab; uint32_t n_inst;
     uint32_t not_initialized;   // wire-layer batches on an un-initialised RISC Zero verifier: decodable calls get InvalidInitialization
     uint8_t* status; uint8_t* recv;
 };
@@ -72,8 +74,9 @@ void launch_setup(const VkRaw* d_raw, VkTables* d_tab, hipStream_t s);
 void launch_prep_risc0(const PrepArgs& a, const Risc0Consts& k, const Workspace& ws, hipStream_t s);
 void launch_prep_sp1(const PrepArgs& a, const Workspace& ws, hipStream_t s);
 void launch_prep_groth16(const PrepArgs& a, const Workspace& ws, hipStream_t s);
-void launch_msm(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
-void launch_vk_x(size_t n, const VkTables* d_tab, const uint8_t* sig, uint8_t* out, hipStream_t s);
+void launch_msm(size_t n, const VkTables* d_tab, const InstTab* inst_tab, const Workspace& ws, hipStream_t s);
+void launch_setup_instances(const VkRaw* d_raw, const InstConsts& k, const InstRaw* d_in, InstTab* d_out, uint32_t n_inst, hipStream_t s);
+void launch_vk_x(size_t n, const VkTables* d_tab, const InstTab* inst_tab, const uint32_t* inst, const uint8_t* sig, uint8_t* out, hipStream_t s);
 void launch_g2chk(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
 void launch_miller(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
 void launch_finalexp(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);

@@ -51,6 +51,11 @@ struct VkTables {
     uint32_t f_alpha_beta[96];           // Miller value of (alpha, beta): Fp12 as g0 g1 g2 h0 h1 h2, (c0, c1) each
 };
 
+// Verifier sets: raw parameters, set-up constants and the per-instance device table (see setup_instance).
+struct InstRaw { uint8_t control_root[32]; uint8_t control_id[32]; };
+struct InstConsts { uint8_t tag[32]; uint8_t vk_digest[32]; };   // sha256("risc0.Groth16ReceiptVerifierParameters"), VK digest
+struct InstTab { G1A base; uint32_t base_inf, selector_be, fail, pad; };
+
 struct PrepOut {
     Fp ax, ay, cx, cy; Fp2 bx, by;
     uint32_t s[MAX_VAR][8];
@@ -151,10 +156,11 @@ ZKV_HD void risc0_split_digest(const uint32_t h[8], uint32_t lo[8], uint32_t hi[
 
 // ---------------------------------------------------------------- stage MSM + G1 normalisation
 // vk_x = base + sum_b s_b * IC_var[b] (groth16.rs:51-58), then x/y and 1/y of A', L, C with one inversion.
-ZKV_HD G1J msm_accumulate(const VkTables& vk, const PrepOut& in) {
+// `base` = IC[0] + the per-verifier-instance signals: the context's own (vk.base) or, for a verifier set, the instance's.
+ZKV_HD G1J msm_accumulate(const VkTables& vk, const PrepOut& in, const G1A& base, uint32_t base_inf) {
     G1J acc;
-    if (vk.base_inf) acc = g1j_infinity();
-    else { acc.x = vk.base.x; acc.y = vk.base.y; acc.z = fp_one(); }
+    if (base_inf) acc = g1j_infinity();
+    else { acc.x = base.x; acc.y = base.y; acc.z = fp_one(); }
 #pragma unroll 1
     for (uint32_t b = 0; b < vk.n_var; b++) {
 #pragma unroll 1
@@ -168,8 +174,9 @@ ZKV_HD G1J msm_accumulate(const VkTables& vk, const PrepOut& in) {
     }
     return acc;
 }
-ZKV_HD void msm_normalize(const VkTables& vk, const PrepOut& in, uint32_t& flags, G1Norm& out) {
-    G1J acc = msm_accumulate(vk, in);
+ZKV_HD G1J msm_accumulate(const VkTables& vk, const PrepOut& in) { return msm_accumulate(vk, in, vk.base, vk.base_inf); }
+ZKV_HD void msm_normalize(const VkTables& vk, const PrepOut& in, uint32_t& flags, G1Norm& out, const G1A& base, uint32_t base_inf) {
+    G1J acc = msm_accumulate(vk, in, base, base_inf);
     Fp one = fp_one();
     bool linf = fp_is_zero(acc.z), ainf = (flags & FL_A_INF) != 0, cinf = (flags & FL_C_INF) != 0;
     if (linf) flags |= FL_L_INF;
@@ -185,6 +192,7 @@ ZKV_HD void msm_normalize(const VkTables& vk, const PrepOut& in, uint32_t& flags
     out.lxs = fp_mul(fp_mul(acc.x, acc.z), iyl);         // (X/Z^2) / (Y/Z^3) = X Z / Y
     out.lys = fp_mul(fp_mul(z2, acc.z), iyl);            // Z^3 / Y
 }
+ZKV_HD void msm_normalize(const VkTables& vk, const PrepOut& in, uint32_t& flags, G1Norm& out) { msm_normalize(vk, in, flags, out, vk.base, vk.base_inf); }
 
 #endif  // !ZKV_PAIRED (PREP and MSM run one proof per lane)
 
@@ -359,19 +367,22 @@ ZKV_HD void g1j_to_affine(const G1J& p, G1A& out, uint32_t& inf) {
     out.x = fp_mul(p.x, zi2); out.y = fp_mul(p.y, fp_mul(zi2, zi)); inf = 0;
 }
 // base = IC[0] + sum over fixed signals s_i * IC[i]
-ZKV_HD void setup_base(const VkRaw& vk, VkTables& t) {
+ZKV_HD void fixed_signal_base(const VkRaw& vk, const uint32_t scalar[MAX_IC][8], G1A& base, uint32_t& base_inf) {
     G1J acc;
     if (raw_g1_is_inf(vk.ic[0])) acc = g1j_infinity();
     else { acc.x = fp_from_raw(vk.ic[0][0]); acc.y = fp_from_raw(vk.ic[0][1]); acc.z = fp_one(); }
 #pragma unroll 1
     for (uint32_t i = 1; i < vk.n_ic; i++) {
         if (!vk.is_fixed[i] || raw_g1_is_inf(vk.ic[i])) continue;
-        G1J m = g1_mul_raw(fp_from_raw(vk.ic[i][0]), fp_from_raw(vk.ic[i][1]), vk.fixed_scalar[i]);
+        G1J m = g1_mul_raw(fp_from_raw(vk.ic[i][0]), fp_from_raw(vk.ic[i][1]), scalar[i]);
         G1A ma; uint32_t inf;
         g1j_to_affine(m, ma, inf);
         if (!inf) acc = g1j_add_affine(acc, ma.x, ma.y);
     }
-    g1j_to_affine(acc, t.base, t.base_inf);
+    g1j_to_affine(acc, base, base_inf);
+}
+ZKV_HD void setup_base(const VkRaw& vk, VkTables& t) {
+    fixed_signal_base(vk, vk.fixed_scalar, t.base, t.base_inf);
     t.n_var = vk.n_var;
     for (int b = 0; b < MAX_VAR; b++) t.var_windows[b] = vk.var_windows[b];
 }
@@ -416,6 +427,29 @@ ZKV_HD void setup_msm_row(const VkRaw& vk, VkTables& t, int b, int w) {
             row[m + j].y = fp_sub(fp_mul(lam, fp_sub(xm, x3)), ym);
         }
     }
+}
+// One instance of a RISC Zero verifier set: what `initialize` derives from (control_root, bn254_control_id)
+// (risc0/verifier.rs:58-76) -- the selector (verifier.rs:128-144: tagged SHA-256 over control root, byte-reversed control
+// id and the VK digest), the split control root (crypto.rs:95-110) -- plus this library's per-instance part of vk_x.
+ZKV_HD void setup_instance(const VkRaw& vk, const InstConsts& k, const InstRaw& in, InstTab& out) {
+    uint8_t buf[130];
+    for (int i = 0; i < 32; i++) { buf[i] = k.tag[i]; buf[32 + i] = in.control_root[i]; buf[64 + i] = in.control_id[31 - i]; buf[96 + i] = k.vk_digest[i]; }
+    buf[128] = 3; buf[129] = 0;
+    uint32_t h[8];
+    sha256_bytes(buf, 130, h);
+    out.selector_be = h[0];
+    uint32_t sc[MAX_IC][8];
+    for (int i = 0; i < MAX_IC; i++) for (int j = 0; j < 8; j++) sc[i][j] = 0;
+    // split_digest: byte-reverse the root; low = rev[16..32], high = rev[0..16], each read big-endian as a 128-bit scalar
+    for (int j = 0; j < 4; j++) {
+        sc[1][j] = __builtin_bswap32(load_be32(in.control_root + 4 * j));            // control_root_0
+        sc[2][j] = __builtin_bswap32(load_be32(in.control_root + 16 + 4 * j));       // control_root_1
+    }
+    load_be256(sc[5], in.control_id);
+    out.fail = raw_lt_r(sc[5]) ? 0u : 1u;              // a control id >= R fails every proof at groth16.rs:32
+    if (out.fail) for (int j = 0; j < 8; j++) sc[5][j] = 0;
+    fixed_signal_base(vk, sc, out.base, out.base_inf);
+    out.pad = 0;
 }
 ZKV_HD void setup_alpha_beta(const VkRaw& vk, VkTables& t, MRef fm, MRef tm) {
     if (raw_g1_is_inf(vk.alpha) || raw_g2_is_inf(vk.beta)) {       // e(alpha, beta) contributes 1

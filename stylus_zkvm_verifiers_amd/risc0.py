@@ -130,3 +130,56 @@ class RiscZeroVerifier:
         out = (C.c_float * 5)()
         _lib.check(self._L.zkv_ctx_last_stage_ms(self._h, out), 'zkv_ctx_last_stage_ms')
         return list(out)
+
+
+class RiscZeroVerifierSet:
+    """Many `RiscZeroVerifier` instances (one per (control_root, bn254_control_id)) resident on one device and sharing the
+    verification-key tables; every proof of a batch names its instance (include/zkv.h, "RISC Zero verifier sets")."""
+
+    def __init__(self, control_roots, bn254_control_ids, device=0):
+        assert len(control_roots) == len(bn254_control_ids) and len(control_roots) > 0
+        self._L = _lib.lib()
+        self._h = self._L.zkv_risc0_set_create(len(control_roots), _cat32(control_roots, 'control_root'),
+                                               _cat32(bn254_control_ids, 'bn254_control_id'), device)
+        if not self._h:
+            raise MemoryError('zkv_risc0_set_create')
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._L.zkv_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __len__(self):
+        return self._L.zkv_risc0_set_size(self._h)
+
+    def get_selector(self, instance):
+        o = C.create_string_buffer(4)
+        _lib.check(self._L.zkv_risc0_set_get_selector(self._h, instance, o), 'zkv_risc0_set_get_selector')
+        return o.raw
+
+    def verify_batch(self, instances, seals, image_ids, journal_digests):
+        n = len(seals)
+        blob, off = _blob(seals)
+        idx = np.ascontiguousarray(instances, dtype=np.uint32)
+        st = np.zeros(n, dtype=np.uint8); rv = np.zeros((n, 4), dtype=np.uint8)
+        _lib.check(self._L.zkv_risc0_set_verify_batch(self._h, n, idx.ctypes.data, blob, off.ctypes.data, _cat32(image_ids, 'image_id'),
+                                                      _cat32(journal_digests, 'journal_digest'), st.ctypes.data, rv.ctypes.data),
+                   'zkv_risc0_set_verify_batch')
+        return st, rv
+
+    def verify_batch_dev(self, n, d_instances, d_seals, d_image_ids, d_journal_digests, d_status, d_recv=0, stream=0):
+        _lib.check(self._L.zkv_risc0_set_verify_batch_dev(self._h, n, d_instances, d_seals, d_image_ids, d_journal_digests, d_status,
+                                                          d_recv or None, stream or None), 'zkv_risc0_set_verify_batch_dev')
+
+    def vk_x_batch(self, instances, var_signals):
+        n = len(var_signals)
+        idx = np.ascontiguousarray(instances, dtype=np.uint32)
+        blob = b''.join(bytes(a) + bytes(b) for a, b in var_signals) + b'\0'
+        out = np.zeros(max(64 * n, 1), dtype=np.uint8)
+        _lib.check(self._L.zkv_risc0_set_vk_x_batch(self._h, n, idx.ctypes.data, blob, out.ctypes.data), 'zkv_risc0_set_vk_x_batch')
+        return [out[64 * i:64 * i + 64].tobytes() for i in range(n)]
+
+    def synchronize(self):
+        _lib.check(self._L.zkv_ctx_synchronize(self._h), 'zkv_ctx_synchronize')

@@ -156,6 +156,31 @@ int hs_cyclo_sqr_check(const uint8_t* seed384) {
     for (int k = 0; k < 96; k++) if (buf[192 + k] != buf[288 + k]) return 0;
     return f12m_is_one(A) ? -1 : 1;
 }
+// One instance of a verifier set through setup_instance (the code of k_setup_instances): selector, control-id range flag and
+// the instance's vk_x for the given claim halves (64 bytes x, y; all-zero = infinity) through the windowed MSM.
+int hs_set_instance(const uint8_t* cr, const uint8_t* cid, const uint8_t* s0, const uint8_t* s1, uint8_t* sel4, uint8_t* vkx64) {
+    const uint8_t zero[32] = {0};
+    VkTables* t = tables(0, zero, zero);            // VK-level tables; the context's own fixed signals are not used
+    VkRaw raw; { uint8_t lo[16] = {0}, hi[16] = {0}; host::fill_vk_risc0(raw, lo, hi, zero); }
+    InstConsts k;
+    host::sha256_host((const uint8_t*)"risc0.Groth16ReceiptVerifierParameters", 38, k.tag);
+    host::risc0_vk_digest(k.vk_digest);
+    InstRaw in; memcpy(in.control_root, cr, 32); memcpy(in.control_id, cid, 32);
+    InstTab tab;
+    setup_instance(raw, k, in, tab);
+    for (int b = 0; b < 4; b++) sel4[b] = (uint8_t)(tab.selector_be >> (24 - 8 * b));
+    PrepOut p; memset(&p, 0, sizeof p);
+    load_be256(p.s[0], s0); load_be256(p.s[1], s1);
+    G1J acc = msm_accumulate(*t, p, tab.base, tab.base_inf);
+    G1A a; uint32_t inf;
+    g1j_to_affine(acc, a, inf);
+    uint32_t r[8];
+    for (int c = 0; c < 2; c++) {
+        fp_to_raw(r, c ? a.y : a.x);
+        for (int i = 0; i < 8; i++) for (int b = 0; b < 4; b++) vkx64[32 * c + 31 - 4 * i - b] = (uint8_t)(r[i] >> (8 * b));
+    }
+    return (int)tab.fail;
+}
 int hs_g2_in_subgroup(const uint8_t* q128) {     // EIP-197 order: x_im x_re y_im y_re; must be on twist
     uint32_t w[4][8];
     for (int k = 0; k < 4; k++) load_be256(w[k], q128 + 32 * k);

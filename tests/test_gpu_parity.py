@@ -443,3 +443,61 @@ def test_full_size_configs_through_properties(zkv, r0, sp1, real_proofs):
     src = np.random.default_rng(0x5A4B5654).permutation(n) % nb
     st = run_sp1(proofs[src], vk[src], pv[src])
     assert (st == base[src]).all() and int((st == 0).sum()) == int((~mut[src]).sum())
+
+
+def test_verifier_set_matches_per_instance_oracles(zkv, real_proofs):
+    """A RiscZeroVerifierSet (many instances resident on the device, selectors derived by the set-up kernel):
+    every proof's status equals what the oracle's verifier for ITS instance returns -- the real instance accepts the valid
+    proofs, the others answer SelectorMismatch or (with their own selector spliced in) VerificationFailed, an instance
+    with bn254_control_id >= R fails everything, an unknown index is an un-initialised verifier."""
+    import random
+    import torch
+    import oracle_lib as ol
+    from stylus_zkvm_verifiers_amd import synth
+    rng = random.Random(0x5A4B5671)
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    r = real_proofs['risc0']
+    roots = [H(r['control_root'])] + [rng.randbytes(32) for _ in range(3)] + [rng.randbytes(32), H(r['control_root'])]
+    ids = [H(r['bn254_control_id'])] + [rng.randrange(R).to_bytes(32, 'big') for _ in range(3)] + [(R + 5).to_bytes(32, 'big'), H(r['bn254_control_id'])]
+    vs = zkv.RiscZeroVerifierSet(roots, ids)
+    oracles = []
+    for cr, cid in zip(roots, ids):
+        o = ol.Risc0Oracle(); o.initialize(cr, cid); oracles.append(o)
+    assert len(vs) == 6
+    for k, o in enumerate(oracles):
+        assert vs.get_selector(k) == o.get_selector()
+    n = 600
+    seals, mut, mclass, flip = synth.make_batch('risc0', H(r['seal']), n, 0x5A4B5672, pool=4, mutate_every=7)
+    iid = np.tile(np.frombuffer(H(r['image_id']), dtype=np.uint8), (n, 1))
+    jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (n, 1)); jds[flip, 0] ^= 1
+    inst = np.array([(i * 5 + i // 6) % 6 for i in range(n)], dtype=np.uint32)
+    for i in range(0, n, 11):                                   # splice the instance's own selector in: reaches the pairing
+        seals[i, :4] = np.frombuffer(oracles[inst[i]].get_selector(), dtype=np.uint8)
+    inst[17] = 6; inst[300] = 0xFFFFFFFF                        # unknown instances
+    st, rv = vs.verify_batch(inst, [x.tobytes() for x in seals], [x.tobytes() for x in iid], [x.tobytes() for x in jds])
+    want_st, want_rv = [], []
+    for i in range(n):
+        if inst[i] >= 6:
+            want_st.append(2); want_rv.append(bytes(4)); continue
+        s, rcv = oracles[inst[i]].verify(seals[i].tobytes(), iid[i].tobytes(), jds[i].tobytes())
+        want_st.append(s); want_rv.append(rcv or bytes(4))
+    assert list(st) == want_st
+    assert [bytes(x) for x in rv] == want_rv
+    assert {0, 1, 2, 5} <= set(want_st)
+    # device-resident entry point
+    dev = torch.device('cuda', 0)
+    d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (seals, iid, jds)]
+    d_inst = torch.from_numpy(inst.view(np.int32)).to(dev)
+    d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+    vs.verify_batch_dev(n, d_inst.data_ptr(), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d_st.data_ptr(), 0,
+                        torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert list(d_st.cpu().numpy()) == want_st
+    # compute_vk_x per instance
+    sig = [(rng.randrange(1 << 128).to_bytes(32, 'big'), rng.randrange(1 << 128).to_bytes(32, 'big')) for _ in range(24)]
+    which = [k % 4 for k in range(24)]
+    got = vs.vk_x_batch(which, sig)
+    for k, (a, b) in zip(which, sig):
+        lo, hi = oracles[k].get_control_root()
+        assert got.pop(0) == ol.groth16_vk_x(0, [lo.rjust(32, b'\0'), hi.rjust(32, b'\0'), a, b, ids[k]])
+    vs.close()

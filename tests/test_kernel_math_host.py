@@ -156,3 +156,28 @@ def test_generic_groth16_with_trapdoor_keys(hs):
         assert ol.groth16_verify_vk(0 if vm == 'risc0' else 1, vkb, len(vk['ic']), words, sigb) == expect, name
         got = hs.hs_groth16_generic(vkb, len(vk['ic']), 1 if vm == 'risc0' else 0, words, b''.join(sigb) + b'\0')
         assert bool(got) == expect, name
+
+
+def test_verifier_set_instance_setup_matches_oracle(hs, real_proofs):
+    """setup_instance (the body of k_setup_instances: selector via SHA-256, control-id range flag, per-instance share of vk_x)
+    against the oracle's initialize / compute_vk_x for several (control_root, bn254_control_id) pairs."""
+    import random
+    import oracle_lib as ol
+    rng = random.Random(0x5A4B5661)
+    r = real_proofs['risc0']
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    pairs = [(H(r['control_root']), H(r['bn254_control_id']))]
+    pairs += [(rng.randbytes(32), rng.randrange(R).to_bytes(32, 'big')) for _ in range(4)]
+    pairs += [(bytes(32), bytes(32)), (b'\xff' * 32, (R - 1).to_bytes(32, 'big')), (rng.randbytes(32), R.to_bytes(32, 'big')),
+              (rng.randbytes(32), b'\xff' * 32)]
+    for cr, cid in pairs:
+        s0, s1 = rng.randrange(1 << 128).to_bytes(32, 'big'), rng.randrange(1 << 128).to_bytes(32, 'big')
+        sel = C.create_string_buffer(4); vkx = C.create_string_buffer(64)
+        fail = hs.hs_set_instance(cr, cid, s0, s1, sel, vkx)
+        o = ol.Risc0Oracle(); o.initialize(cr, cid)
+        assert sel.raw == o.get_selector()
+        assert bool(fail) == (int.from_bytes(cid, 'big') >= R)
+        if not fail:
+            lo, hi = o.get_control_root()
+            want = ol.groth16_vk_x(0, [lo.rjust(32, b'\0'), hi.rjust(32, b'\0'), s0, s1, cid])
+            assert vkx.raw == want
