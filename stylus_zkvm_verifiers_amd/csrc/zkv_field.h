@@ -65,18 +65,18 @@ ZKV_HD uint32_t subb(uint32_t a, uint32_t b, uint32_t& borrow) {
 }
 
 // ---------------------------------------------------------------- Fp
-// Canonical residues (< p) in Montgomery form with R = 2^261, stored as 8 x 32-bit limbs.
+// Residues in Montgomery form with R = 2^261, stored as 8 x 32-bit limbs, kept in the LOOSE range [0, 2p): every value
+// has two representations (x and x + p).  The multipliers then need no final conditional subtraction (their result is
+// < V / 2^261 + p < 2p for every column value V < p * 2^261), additions and subtractions reduce against 2p instead of p at
+// the same cost, and only comparisons (fp_is_zero, fp_eq) and the conversion out of Montgomery form (fp_to_raw) look at
+// both representations.  Constants are canonical, which is a special case.
 ZKV_HD Fp fp_zero() { Fp r; for (int i = 0; i < 8; i++) r.v[i] = 0; return r; }
 ZKV_HD Fp fp_one() { Fp r = ZKV_FP_ONE; return r; }
-ZKV_HD bool fp_is_zero(const Fp& a) {
-    uint32_t o = 0;
-    for (int i = 0; i < 8; i++) o |= a.v[i];
-    return o == 0;
-}
-ZKV_HD bool fp_eq(const Fp& a, const Fp& b) {
-    uint32_t o = 0;
-    for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i];
-    return o == 0;
+ZKV_HD bool fp_is_zero(const Fp& a) {          // a in {0, p}
+    const uint32_t P[8] = ZKV_FP_P_LIMBS;
+    uint32_t o = 0, q = 0;
+    for (int i = 0; i < 8; i++) { o |= a.v[i]; q |= a.v[i] ^ P[i]; }
+    return o == 0 || q == 0;
 }
 // raw 256-bit compare a >= m (m given as limbs)
 ZKV_HD bool u256_geq(const uint32_t* a, const uint32_t* m) {
@@ -85,10 +85,10 @@ ZKV_HD bool u256_geq(const uint32_t* a, const uint32_t* m) {
     return br == 0;
 }
 ZKV_HD Fp fp_add(const Fp& a, const Fp& b) {
-    const uint32_t P[8] = ZKV_FP_P_LIMBS;
+    const uint32_t P[8] = ZKV_FP_2P_LIMBS;
     Fp t, s; uint32_t c = 0, br = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) t.v[i] = addc(a.v[i], b.v[i], c);      // < 2p < 2^255, no carry out
+    for (int i = 0; i < 8; i++) t.v[i] = addc(a.v[i], b.v[i], c);      // < 4p < 2^256, no carry out
 #pragma unroll
     for (int i = 0; i < 8; i++) s.v[i] = subb(t.v[i], P[i], br);
 #pragma unroll
@@ -96,7 +96,7 @@ ZKV_HD Fp fp_add(const Fp& a, const Fp& b) {
     return t;
 }
 ZKV_HD Fp fp_sub(const Fp& a, const Fp& b) {
-    const uint32_t P[8] = ZKV_FP_P_LIMBS;
+    const uint32_t P[8] = ZKV_FP_2P_LIMBS;
     Fp t; uint32_t br = 0, c = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) t.v[i] = subb(a.v[i], b.v[i], br);
@@ -105,10 +105,11 @@ ZKV_HD Fp fp_sub(const Fp& a, const Fp& b) {
     for (int i = 0; i < 8; i++) t.v[i] = addc(t.v[i], P[i] & mask, c);
     return t;
 }
+ZKV_HD bool fp_eq(const Fp& a, const Fp& b) { return fp_is_zero(fp_sub(a, b)); }      // a - b in {0, p} after the loose subtraction
 ZKV_HD Fp fp_neg(const Fp& a) { return fp_sub(fp_zero(), a); }
 ZKV_HD Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
-// a + b without the modular reduction: for sums that only feed fp_mul (which accepts any 256-bit operand and
-// returns a canonical result).  Caller guarantees a + b < 2^256 (at most four canonical values summed: 4p < 2^256).
+// a + b without the modular reduction: for sums that only feed a multiplier (which accepts any 256-bit operand).
+// At most TWO loose values may be summed this way: 4p < 2^256 and every product bound in this file assumes operands < 4p.
 ZKV_HD Fp fp_add_nr(const Fp& a, const Fp& b) {
     Fp t; uint32_t c = 0;
 #pragma unroll
@@ -118,7 +119,7 @@ ZKV_HD Fp fp_add_nr(const Fp& a, const Fp& b) {
 // Two independent modular additions / subtractions with their carry chains interleaved limb by limb: gfx950 needs
 // wait states between a carry-writing VALU op and the dependent v_addc/v_subb, and the second chain fills them.
 ZKV_HD void fp_add_x2(const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1, Fp& r0, Fp& r1) {
-    const uint32_t P[8] = ZKV_FP_P_LIMBS;
+    const uint32_t P[8] = ZKV_FP_2P_LIMBS;
     Fp t0, t1, s0, s1; uint32_t c0 = 0, c1 = 0, w0 = 0, w1 = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) { t0.v[i] = addc(a0.v[i], b0.v[i], c0); t1.v[i] = addc(a1.v[i], b1.v[i], c1); }
@@ -128,7 +129,7 @@ ZKV_HD void fp_add_x2(const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1, Fp
     for (int i = 0; i < 8; i++) { r0.v[i] = w0 ? t0.v[i] : s0.v[i]; r1.v[i] = w1 ? t1.v[i] : s1.v[i]; }
 }
 ZKV_HD void fp_sub_x2(const Fp& a0, const Fp& b0, const Fp& a1, const Fp& b1, Fp& r0, Fp& r1) {
-    const uint32_t P[8] = ZKV_FP_P_LIMBS;
+    const uint32_t P[8] = ZKV_FP_2P_LIMBS;
     Fp t0, t1; uint32_t w0 = 0, w1 = 0, c0 = 0, c1 = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) { t0.v[i] = subb(a0.v[i], b0.v[i], w0); t1.v[i] = subb(a1.v[i], b1.v[i], w1); }
@@ -164,12 +165,11 @@ ZKV_HD void fp_mac81(COL col[18], const uint32_t x[9], const uint32_t y[9]) {   
         for (int j = 0; j < 9; j++) col[i + j] = (COL)((uint64_t)col[i + j] + (uint64_t)x[i] * y[j]);
     }
 }
-// Montgomery reduction of an 18-column value V >= 0 (V = sum col[k] 2^(29k)): returns V * 2^-261 mod p, canonical.
-// Requires V / 2^261 + p < 2p, i.e. V < p * 2^261 (about 169 p^2).
+// Montgomery reduction of an 18-column value V >= 0 (V = sum col[k] 2^(29k)): returns V * 2^-261 mod p in the loose range:
+// the result is < V / 2^261 + p, which is < 2p because every caller keeps V < p * 2^261 (about 169 p^2; operands are < 4p).
 template <typename COL>                          // int64_t: signed columns (arithmetic carries); uint64_t: all terms >= 0
 ZKV_HD Fp fp_reduce_cols(COL col[18]) {
     const uint32_t P29[9] = ZKV_FP_P29_LIMBS;
-    const uint32_t P[8] = ZKV_FP_P_LIMBS;
     const uint32_t M29 = 0x1fffffffu;
 #pragma unroll
     for (int i = 0; i < 9; i++) {                 // one 29-bit digit per step
@@ -185,20 +185,15 @@ ZKV_HD Fp fp_reduce_cols(COL col[18]) {
         col[k + 1] += col[k] >> 29;
     }
     r[8] = (uint32_t)col[17];
-    uint32_t t[8];
+    Fp o;
 #pragma unroll
-    for (int w = 0; w < 8; w++) {                 // pack 9 x 29 -> 8 x 32
+    for (int w = 0; w < 8; w++) {                 // pack 9 x 29 -> 8 x 32 (the value is < 2p < 2^255)
         const int bit = 32 * w, k = bit / 29, s = bit - 29 * k, got = 29 - s;
         uint32_t v = r[k] >> s;
         if (k + 1 < 9) v |= r[k + 1] << got;
         if (got + 29 < 32 && k + 2 < 9) v |= r[k + 2] << (got + 29);
-        t[w] = v;
+        o.v[w] = v;
     }
-    Fp o, sb; uint32_t br = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) sb.v[i] = subb(t[i], P[i], br);
-#pragma unroll
-    for (int i = 0; i < 8; i++) o.v[i] = br ? t[i] : sb.v[i];
     return o;
 }
 #if defined(ZKV_FP_MUL_NOINLINE)
@@ -225,10 +220,12 @@ ZKV_HD Fp fp_from_raw(const uint32_t* limbs) {        // canonical value < p -> 
     for (int i = 0; i < 8; i++) t.v[i] = limbs[i];
     return fp_mul(t, r2);
 }
-ZKV_HD void fp_to_raw(uint32_t* limbs, const Fp& a) {
+ZKV_HD void fp_to_raw(uint32_t* limbs, const Fp& a) {      // out of Montgomery form, canonical
+    const uint32_t P[8] = ZKV_FP_P_LIMBS;
     Fp one = fp_zero(); one.v[0] = 1;
-    Fp t = fp_mul(a, one);
-    for (int i = 0; i < 8; i++) limbs[i] = t.v[i];
+    Fp t = fp_mul(a, one), s; uint32_t br = 0;            // t <= p
+    for (int i = 0; i < 8; i++) s.v[i] = subb(t.v[i], P[i], br);
+    for (int i = 0; i < 8; i++) limbs[i] = br ? t.v[i] : s.v[i];
 }
 // a^(p-2); inv(0) = 0.  Deliberately a loop (not unrolled): 254 squarings + multiplies.
 ZKV_HD Fp fp_inv(const Fp& a) {
@@ -245,7 +242,7 @@ ZKV_HD Fp fp_inv(const Fp& a) {
 // N independent modular additions / subtractions, carry chains interleaved limb by limb (same idea as *_x2).
 template <int N>
 ZKV_HD void fp_add_n(const Fp (&a)[N], const Fp (&b)[N], Fp (&r)[N]) {
-    const uint32_t P[8] = ZKV_FP_P_LIMBS;
+    const uint32_t P[8] = ZKV_FP_2P_LIMBS;
     Fp t[N], s[N]; uint32_t c[N], w[N];
 #pragma unroll
     for (int k = 0; k < N; k++) { c[k] = 0; w[k] = 0; }
@@ -267,7 +264,7 @@ ZKV_HD void fp_add_n(const Fp (&a)[N], const Fp (&b)[N], Fp (&r)[N]) {
 }
 template <int N>
 ZKV_HD void fp_sub_n(const Fp (&a)[N], const Fp (&b)[N], Fp (&r)[N]) {
-    const uint32_t P[8] = ZKV_FP_P_LIMBS;
+    const uint32_t P[8] = ZKV_FP_2P_LIMBS;
     Fp t[N]; uint32_t w[N], c[N], m[N];
 #pragma unroll
     for (int k = 0; k < N; k++) { c[k] = 0; w[k] = 0; }
@@ -302,7 +299,7 @@ ZKV_HD Fp2 f2_conj(const Fp2& a) { Fp2 r; r.c0 = a.c0; r.c1 = fp_neg(a.c1); retu
 // Fp2 product with the Montgomery reductions shared: three 81-term column products (a0 b0, a1 b1,
 // (a0+a1)(b0+b1)) and only TWO reductions -- c1 = M - T0 - T1 is non-negative column by column, c0 = T0 - T1 + 16 p^2
 // is non-negative as a whole and reduces on signed columns.  405 multiplies instead of 486.
-// Operand components may be lazy sums < 2p (so T1 < 4 p^2 <= 16 p^2 and every total stays < 169 p^2).
+// Operand components may be lazy sums < 4p (so T1 < 16 p^2 and every total stays < 64 p^2 < 169 p^2).
 ZKV_HD void f2_mul_core(const Fp& a0, const Fp& a1, const Fp& b0, const Fp& b1, Fp& c0, Fp& c1) {
 #if defined(ZKV_COUNT_FP_MUL)
     zkv_fp_mul_counter += 3;
@@ -339,7 +336,7 @@ ZKV_HD Fp2 f2_mul(const Fp2& a, const Fp2& b) { return f2_mul_ni(ZKV_A8(a.c0), Z
 #else
 ZKV_HD Fp2 f2_mul(const Fp2& a, const Fp2& b) { Fp2 r; f2_mul_core(a.c0, a.c1, b.c0, b.c1, r.c0, r.c1); return r; }
 #endif
-ZKV_HD Fp2 f2_sqr(const Fp2& a) {           // canonical input
+ZKV_HD Fp2 f2_sqr(const Fp2& a) {           // reduced (< 2p) input
     Fp2 r;
     r.c0 = fp_mul(fp_add_nr(a.c0, a.c1), fp_sub(a.c0, a.c1));
     r.c1 = fp_mul(fp_add_nr(a.c0, a.c0), a.c1);
@@ -383,14 +380,12 @@ ZKV_HD Fp2 f2_const(const Fp2C& c) { Fp2 r; r.h = fp_sel(zkv_parity() != 0, c.c1
 ZKV_HD Fp2 f2_zero() { Fp2 r; r.h = fp_zero(); return r; }
 ZKV_HD Fp2 f2_one() { Fp2 r; r.h = fp_sel(zkv_parity() != 0, fp_zero(), fp_one()); return r; }
 ZKV_HD bool f2_is_zero(const Fp2& a) {
-    uint32_t o = 0;
-    for (int i = 0; i < 8; i++) o |= a.h.v[i];
+    uint32_t o = fp_is_zero(a.h) ? 0u : 1u;
     o |= zkv_partner_u32(o);
     return o == 0;
 }
 ZKV_HD bool f2_eq(const Fp2& a, const Fp2& b) {
-    uint32_t o = 0;
-    for (int i = 0; i < 8; i++) o |= a.h.v[i] ^ b.h.v[i];
+    uint32_t o = fp_eq(a.h, b.h) ? 0u : 1u;
     o |= zkv_partner_u32(o);
     return o == 0;
 }
@@ -400,9 +395,9 @@ ZKV_HD Fp2 f2_neg(const Fp2& a) { Fp2 r; r.h = fp_neg(a.h); return r; }
 ZKV_HD Fp2 f2_add_nr(const Fp2& a, const Fp2& b) { Fp2 r; r.h = fp_add_nr(a.h, b.h); return r; }
 ZKV_HD Fp2 f2_dbl(const Fp2& a) { return f2_add(a, a); }
 ZKV_HD Fp2 f2_conj(const Fp2& a) { Fp2 r; r.h = fp_sel(zkv_parity() != 0, fp_neg(a.h), a.h); return r; }
-// (a0 + a1 u)(b0 + b1 u): the even lane forms a0 b0 + a1 (4p - b1), the odd lane a0 b1 + a1 b0 -- two 81-term column
-// products and ONE Montgomery reduction per lane, all terms non-negative (4p - b1 in borrow-free 29-bit limbs).
-// Components may be lazy sums < 2p.
+// (a0 + a1 u)(b0 + b1 u): the even lane forms a0 b0 + a1 (8p - b1), the odd lane a0 b1 + a1 b0 -- two 81-term column
+// products and ONE Montgomery reduction per lane, all terms non-negative (8p - b1 in borrow-free 29-bit limbs).
+// Components may be lazy sums < 4p: the column value stays below 16 p^2 + 32 p^2.
 #if defined(ZKV_FP_MUL_NOINLINE)
 ZKV_HD_NI
 #else
@@ -412,7 +407,7 @@ Fp f2_mul_lane(Fp my_a, Fp my_b) {
 #if defined(ZKV_COUNT_FP_MUL)
     zkv_fp_mul_counter += 2;
 #endif
-    const uint32_t FAT[9] = ZKV_FP_FAT4P_LIMBS;
+    const uint32_t FAT[9] = ZKV_FP_FAT8P_LIMBS;
     const bool odd = zkv_parity() != 0;
     uint32_t xa[9], xo[9], yb[9], yo[9], U[9], V[9];
     fp_unpack29(my_a, xa); fp_unpack29(my_b, yb);        // each lane unpacks its own operands once ...
@@ -430,7 +425,7 @@ Fp f2_mul_lane(Fp my_a, Fp my_b) {
     return fp_reduce_cols(col);
 }
 ZKV_HD Fp2 f2_mul(const Fp2& a, const Fp2& b) { Fp2 r; r.h = f2_mul_lane(a.h, b.h); return r; }
-ZKV_HD Fp2 f2_sqr(const Fp2& a) {           // canonical input: even lane (a0+a1)(a0-a1), odd lane (2 a1) a0
+ZKV_HD Fp2 f2_sqr(const Fp2& a) {           // reduced (< 2p) input: even lane (a0+a1)(a0-a1), odd lane (2 a1) a0
     const bool odd = zkv_parity() != 0;
     Fp o = zkv_partner(a.h);
     Fp x = fp_add_nr(a.h, fp_sel(odd, a.h, o));

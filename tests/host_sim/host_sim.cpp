@@ -143,6 +143,52 @@ void hs_fp_mulmod(const uint8_t* a, const uint8_t* b, uint8_t* out) {
     fp_to_raw(r, fp_mul(fp_from_raw(x), fp_from_raw(y)));
     for (int i = 0; i < 8; i++) for (int k = 0; k < 4; k++) out[31 - 4 * i - k] = r[i] >> (8 * k);
 }
+// Loose-range invariance: every field operation must give the same residue whichever representation (x or x + p) its
+// operands use, results must stay below 2p, and the comparisons must treat both representations as equal.
+// a, b: canonical big-endian values.  Returns 0 when everything holds, otherwise the number of the failing check.
+static Fp plus_p(const Fp& x) { const uint32_t P[8] = ZKV_FP_P_LIMBS; Fp r; uint32_t c = 0; for (int i = 0; i < 8; i++) r.v[i] = addc(x.v[i], P[i], c); return r; }
+static bool below_2p(const Fp& x) { const uint32_t P2[8] = ZKV_FP_2P_LIMBS; return !u256_geq(x.v, P2); }
+static bool same_residue(const Fp& x, const Fp& y) { uint32_t a[8], b[8]; fp_to_raw(a, x); fp_to_raw(b, y); for (int i = 0; i < 8; i++) if (a[i] != b[i]) return false; return true; }
+int hs_fp_loose_check(const uint8_t* a32, const uint8_t* b32) {
+    uint32_t ra[8], rb[8];
+    load_be256(ra, a32); load_be256(rb, b32);
+    Fp A[2], B[2];
+    A[0] = fp_from_raw(ra); B[0] = fp_from_raw(rb);
+    // representatives as produced by the multiplier, then their + p twins
+    A[1] = plus_p(A[0]); B[1] = plus_p(B[0]);
+    if (!below_2p(A[0]) || !below_2p(B[0])) return 1;
+    if (!below_2p(A[1])) A[1] = A[0];                // A[0] was already >= p: its twin would leave the range
+    if (!below_2p(B[1])) B[1] = B[0];
+    Fp ref_add = fp_add(A[0], B[0]), ref_sub = fp_sub(A[0], B[0]), ref_mul = fp_mul(A[0], B[0]), ref_neg = fp_neg(A[0]);
+    Fp ref_lazy = fp_mul(fp_add_nr(A[0], B[0]), fp_add_nr(B[0], B[0]));
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) {
+        Fp s = fp_add(A[i], B[j]), d = fp_sub(A[i], B[j]), m = fp_mul(A[i], B[j]), n = fp_neg(A[i]);
+        Fp lz = fp_mul(fp_add_nr(A[i], B[j]), fp_add_nr(B[j], B[1 - j]));
+        if (!below_2p(s) || !below_2p(d) || !below_2p(m) || !below_2p(n) || !below_2p(lz)) return 2;
+        if (!same_residue(s, ref_add) || !fp_eq(s, ref_add)) return 3;
+        if (!same_residue(d, ref_sub) || !fp_eq(d, ref_sub)) return 4;
+        if (!same_residue(m, ref_mul) || !fp_eq(m, ref_mul)) return 5;
+        if (!same_residue(n, ref_neg)) return 6;
+        if (!same_residue(lz, ref_lazy)) return 7;
+        if (!fp_eq(A[i], A[1 - i]) || !fp_is_zero(fp_sub(A[i], A[1 - i]))) return 8;
+        Fp x2[2], y2[2], r2[2]; x2[0] = A[i]; x2[1] = B[j]; y2[0] = B[j]; y2[1] = A[i];
+        fp_add_n<2>(x2, y2, r2);
+        if (!same_residue(r2[0], ref_add) || !below_2p(r2[1])) return 9;
+        fp_sub_n<2>(x2, y2, r2);
+        if (!same_residue(r2[0], ref_sub) || !below_2p(r2[0]) || !below_2p(r2[1])) return 10;
+        Fp r0, r1;
+        fp_add_x2(A[i], B[j], B[j], A[i], r0, r1);
+        if (!same_residue(r0, ref_add) || !same_residue(r1, ref_add) || !below_2p(r0)) return 11;
+        fp_sub_x2(A[i], B[j], B[j], A[i], r0, r1);
+        if (!same_residue(r0, ref_sub) || !below_2p(r0) || !below_2p(r1)) return 12;
+    }
+    bool az = true; for (int i = 0; i < 8; i++) az = az && ra[i] == 0;
+    if (fp_is_zero(A[0]) != az || fp_is_zero(A[1]) != az) return 13;
+    if (same_residue(A[0], B[0]) != fp_eq(A[1], B[0])) return 14;
+    Fp inv = fp_inv(A[1]);
+    if (!az && !same_residue(fp_mul(inv, A[0]), fp_one())) return 15;
+    return 0;
+}
 // returns 1 when the Granger-Scott cyclotomic squaring equals the generic squaring on a random element of the
 // cyclotomic subgroup (x^((p^6-1)(p^2+1)) for x built from the seed bytes)
 int hs_cyclo_sqr_check(const uint8_t* seed384) {
@@ -153,7 +199,7 @@ int hs_cyclo_sqr_check(const uint8_t* seed384) {
     f12m_frob(B, A, 2); f12m_mul(A, B, A);                                  // ^(p^2+1)
     f12m_copy(B, A); f12m_copy(C, A);
     f12m_sqr(B); f12m_cyclo_sqr(C);
-    for (int k = 0; k < 96; k++) if (buf[192 + k] != buf[288 + k]) return 0;
+    for (int k = 0; k < 12; k++) if (!fp_eq(m_ld_fp(B, 8 * k), m_ld_fp(C, 8 * k))) return 0;      // values live in the loose range [0, 2p)
     return f12m_is_one(A) ? -1 : 1;
 }
 // One instance of a verifier set through setup_instance (the code of k_setup_instances): selector, control-id range flag and

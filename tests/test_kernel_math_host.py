@@ -49,6 +49,17 @@ def test_fp_mul_matches_bigint(hs):
         assert int.from_bytes(o.raw, 'big') == a * b % m.P
 
 
+def test_loose_range_invariance(hs):
+    """Field values live in [0, 2p): every operation must return the same residue for either representation of its operands,
+    stay below 2p, and the comparisons must identify x with x + p (edge values 0, 1, p-1 and random ones)."""
+    rng = random.Random(0x5A4B5681)
+    edge = [0, 1, 2, m.P - 1, m.P - 2, (m.P + 1) // 2, (1 << 253) - 1]
+    vals = edge + [rng.randrange(m.P) for _ in range(40)]
+    for a in vals:
+        for b in edge + [rng.randrange(m.P) for _ in range(3)]:
+            assert hs.hs_fp_loose_check(a.to_bytes(32, 'big'), b.to_bytes(32, 'big')) == 0, (hex(a), hex(b))
+
+
 def test_digest_chain(hs, real_proofs):
     r = real_proofs['risc0']
     d, lo, hi = (C.create_string_buffer(32) for _ in range(3))
