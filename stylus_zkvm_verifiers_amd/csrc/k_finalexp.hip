@@ -15,7 +15,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_finalexp(size_t n, Workspace ws, 
     MRef F = m_ref(ws.f + i, st);
     MRef E = m_ref(ws.fe + i, st);
     MRef Y1 = m_off(E, 96), Y3 = m_off(E, 192), Y4 = m_off(E, 288);
-    status[i] = final_exp_is_one_m(F, E, Y1, Y3, Y4, acc) ? ST_OK : ST_VERIFICATION_FAILED;
+    status[i] = final_exp_is_one_m(F, E, Y1, Y3, Y4, m_off(E, 384), acc) ? ST_OK : ST_VERIFICATION_FAILED;
 }
 
 void launch_finalexp(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s) {

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_finalexp2(size_t n, Workspace 
     MRef F = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, st, 16);
     MRef E = m_ref(ws.fe + (size_t)(8 * par) * ws.cap + i, st, 16);
     MRef Y1 = m_off(E, 96), Y3 = m_off(E, 192), Y4 = m_off(E, 288);
-    bool one = final_exp_is_one_m(F, E, Y1, Y3, Y4, acc);
+    bool one = final_exp_is_one_m(F, E, Y1, Y3, Y4, m_off(E, 384), acc);
     if (!par) status[i] = one ? ST_OK : ST_VERIFICATION_FAILED;
 }
 

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_pairing(size_t n, uint32_t k, con
         f12m_mul(P, P, fm);
     }
     uint8_t res = 0;
-    if (good) res = final_exp_is_one_m(P, E, m_off(E, 96), m_off(E, 192), m_off(E, 288), fm) ? 1 : 0;
+    if (good) res = final_exp_is_one_m(P, E, m_off(E, 96), m_off(E, 192), m_off(E, 288), m_off(E, 384), fm) ? 1 : 0;
     result[i] = res;
     ok[i] = good ? 1 : 0;
 }

@@ -10,7 +10,7 @@ namespace zkv {
 constexpr int WS_PREP_WORDS = 64 + 8 * MAX_VAR;   // ax ay cx cy (4x8) | bx.c0 bx.c1 by.c0 by.c1 (4x8) | per-proof scalars (MAX_VAR x 8)
 constexpr int WS_NORM_WORDS = 48;   // axs ays lxs lys cxs cys
 constexpr int WS_F_WORDS = 96;      // Fp12 Miller value (slot F of the final exponentiation)
-constexpr int WS_FE_WORDS = 5 * 96; // cold Fp12 slots E, Y1, Y3, Y4 of the final exponentiation (+1 spare: f/T or acc when not in LDS)
+constexpr int WS_FE_WORDS = 7 * 96; // cold Fp12 slots of the final exponentiation: E, Y1, Y3, Y4 and the window slots x^3, x^5, x^7
 struct Workspace {
     uint32_t* prep; uint32_t* norm; uint32_t* f; uint32_t* fe; uint32_t* flags;
     size_t cap;

@@ -257,38 +257,46 @@ ZKV_HD void miller_loop_m(const VkTables& vk, uint32_t flags, const G1Norm& n, c
 }
 
 // ---------------------------------------------------------------- stage FINALEXP
-// acc <- x^u  (acc and x are different slots; x in the cyclotomic subgroup).  Signed-digit (NAF) square-and-multiply:
-// 62 cyclotomic squarings and 23 multiplications, the -1 digits multiply by conj(x) = x^-1.
-ZKV_HD int8_t u_naf(int i) {
-    const int8_t NAF[ZKV_U_NAF_LEN] = ZKV_U_NAF;
-    return NAF[i];
+// acc <- x^u  (acc and x are different slots; x in the cyclotomic subgroup).  Width-3 signed sliding window: x^3, x^5, x^7
+// go to the three scratch slots at W (one cyclotomic squaring + 3 multiplications), then 62 cyclotomic squarings and 13
+// multiplications, negative digits multiplying by the conjugate (= inverse).  16 multiplications instead of the 23 of the
+// plain NAF.
+ZKV_HD int8_t u_wnaf3(int i) {
+    const int8_t D[ZKV_U_WNAF3_LEN] = ZKV_U_WNAF3;
+    return D[i];
 }
-template <class RA, class RX> ZKV_HD void exp_u_m(RA acc, RX x) {
-    f12m_copy(acc, x);
+template <class RA> ZKV_HD void exp_u_m(RA acc, MRef x, MRef W) {
+    const MRef X3 = W, X5 = m_off(W, 96), X7 = m_off(W, 192);
+    f12m_copy(acc, x); f12m_cyclo_sqr(acc);             // x^2
+    f12m_mul(X3, acc, x); f12m_mul(X5, X3, acc); f12m_mul(X7, X5, acc);
+    f12m_copy(acc, x);                                  // leading digit 1
 #pragma unroll 1
-    for (int i = ZKV_U_NAF_LEN - 2; i >= 0; i--) {
+    for (int i = ZKV_U_WNAF3_LEN - 2; i >= 0; i--) {
         f12m_cyclo_sqr(acc);
-        int d = u_naf(i);
-        if (d > 0) f12m_mul(acc, acc, x);
-        else if (d < 0) f12m_mul_conj(acc, acc, x);
+        const int d = u_wnaf3(i);
+        if (d == 0) continue;
+        const int m = d < 0 ? -d : d;
+        const MRef S = m == 1 ? x : m == 3 ? X3 : m == 5 ? X5 : X7;
+        if (d > 0) f12m_mul(acc, acc, S);
+        else f12m_mul_conj(acc, acc, S);
     }
 }
 // f^(k (p^12-1)/r) == 1 with k = 2u(6u^2+3u+1), gcd(k, r) = 1  (Fuentes-Castaneda hard part; the chain is
-// checked symbolically in tests).  F holds the Miller value on entry (clobbered); E, Y1, Y3, Y4 are scratch
-// slots; acc is the hot accumulator (LDS on the device).
-template <class RA> ZKV_HD bool final_exp_is_one_m(MRef F, MRef E, MRef Y1, MRef Y3, MRef Y4, RA acc) {
+// checked symbolically in tests).  F holds the Miller value on entry (clobbered); E, Y1, Y3, Y4 and the three slots at W
+// are scratch; acc is the hot accumulator (LDS on the device).
+template <class RA> ZKV_HD bool final_exp_is_one_m(MRef F, MRef E, MRef Y1, MRef Y3, MRef Y4, MRef W, RA acc) {
     f12m_copy(acc, F); f12m_conj(acc);
     f12m_inv(F, F);
     f12m_mul(acc, acc, F);                  // f^(p^6-1)
     f12m_frob(F, acc, 2);
     f12m_mul(E, F, acc);                    // e = ^(p^2+1)
-    exp_u_m(acc, E); f12m_conj(acc);        // y0
+    exp_u_m(acc, E, W); f12m_conj(acc);     // y0
     f12m_cyclo_sqr(acc); f12m_copy(Y1, acc);    // y1
     f12m_cyclo_sqr(acc);                    // y2
     f12m_mul(acc, acc, Y1); f12m_copy(Y3, acc);     // y3
-    exp_u_m(acc, Y3); f12m_conj(acc); f12m_copy(Y4, acc);   // y4
+    exp_u_m(acc, Y3, W); f12m_conj(acc); f12m_copy(Y4, acc);   // y4
     f12m_cyclo_sqr(acc); f12m_copy(F, acc); // y5
-    exp_u_m(acc, F);                        // y6 (two conjugations cancel)
+    exp_u_m(acc, F, W);                     // y6 (two conjugations cancel)
     f12m_conj(Y3);
     f12m_mul(acc, acc, Y4);                 // y7
     f12m_mul(acc, acc, Y3); f12m_copy(Y3, acc);     // y8

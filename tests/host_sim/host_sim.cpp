@@ -54,14 +54,14 @@ int hs_groth16(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* wor
     msm_normalize(*t, p, fl, n);
     g_stage_muls[1] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
     // same slot structure as the kernels: f and T in one buffer (LDS on the device), 5 Fp12 slots for the final exp
-    static thread_local uint32_t buf[96 + 48], slots[5 * 96];
+    static thread_local uint32_t buf[96 + 48], slots[8 * 96];
     MRef fm = m_ref(buf, 1), tm = m_ref(buf + 96, 1);
     miller_loop_m(*t, fl, n, p.bx, p.by, true, fm, tm);
     g_stage_muls[3] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
     MRef F = m_ref(slots, 1), E = m_ref(slots + 96, 1), Y1 = m_ref(slots + 192, 1), Y3 = m_ref(slots + 288, 1), Y4 = m_ref(slots + 384, 1);
     for (int k = 0; k < 96; k++) slots[k] = t->f_alpha_beta[k];
     f12m_mul(F, F, fm);
-    int acc = final_exp_is_one_m(F, E, Y1, Y3, Y4, fm) ? 1 : 0;
+    int acc = final_exp_is_one_m(F, E, Y1, Y3, Y4, m_ref(slots + 480, 1), fm) ? 1 : 0;
     g_stage_muls[4] = zkv_fp_mul_counter - c0;
     return acc;
 }
@@ -118,13 +118,13 @@ int hs_groth16_generic(const uint8_t* vk_words, int n_ic, int negate_a, const ui
     if (!(p.flags & FL_B_INF) && !g2_in_subgroup(p.bx, p.by)) return 0;
     G1Norm n; uint32_t fl = p.flags;
     msm_normalize(*t, p, fl, n);
-    static thread_local uint32_t buf[96 + 48], slots[5 * 96];
+    static thread_local uint32_t buf[96 + 48], slots[8 * 96];
     MRef fm = m_ref(buf, 1), tm = m_ref(buf + 96, 1);
     miller_loop_m(*t, fl, n, p.bx, p.by, true, fm, tm);
     MRef F = m_ref(slots, 1), E = m_ref(slots + 96, 1), Y1 = m_ref(slots + 192, 1), Y3 = m_ref(slots + 288, 1), Y4 = m_ref(slots + 384, 1);
     for (int k = 0; k < 96; k++) slots[k] = t->f_alpha_beta[k];
     f12m_mul(F, F, fm);
-    return final_exp_is_one_m(F, E, Y1, Y3, Y4, fm) ? 1 : 0;
+    return final_exp_is_one_m(F, E, Y1, Y3, Y4, m_ref(slots + 480, 1), fm) ? 1 : 0;
 }
 void hs_risc0_scalars(const uint8_t* image_id, const uint8_t* journal, uint8_t* digest32, uint8_t* lo32, uint8_t* hi32) {
     Risc0Consts k; host::risc0_consts(k);

@@ -39,13 +39,13 @@ static void lane(Job* j, uint32_t par) {
     if (!sub) { j->accept[par] = 0; return; }
     // lane-private half slots (f2w = 8) for f, T and the accumulator; full-layout slots (f2w = 16) for the cold values
     static thread_local uint32_t half[48 + 24];
-    static uint32_t full[5 * 96];                    // shared by the two lanes like the HBM slots
+    static uint32_t full[8 * 96];                    // shared by the two lanes like the HBM slots
     MRef fm = m_ref(half, 1, 8), tm = m_ref(half + 48, 1, 8);
     miller_loop_m(*j->t, j->flags, n, bx, by, true, fm, tm);
     MRef ab = m_ref((uint32_t*)j->t->f_alpha_beta + 8 * par, 1, 16);
     MRef F = m_ref(full + 8 * par, 1, 16), E = m_ref(full + 96 + 8 * par, 1, 16);
     f12m_mul(F, fm, ab);
-    j->accept[par] = final_exp_is_one_m(F, E, m_off(E, 96), m_off(E, 192), m_off(E, 288), fm) ? 1 : 0;
+    j->accept[par] = final_exp_is_one_m(F, E, m_off(E, 96), m_off(E, 192), m_off(E, 288), m_off(E, 384), fm) ? 1 : 0;
 }
 
 extern "C" int hs2_pairing(const void* tables, uint32_t flags, const uint32_t* norm48, const uint32_t* b32, int* sub_ok) {
