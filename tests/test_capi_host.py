@@ -109,3 +109,15 @@ def test_wire_layer_host_side(z, wire_cases):
         with pytest.raises(_lib.ZkvRuntimeError) as ei:
             z.wire.eth_call_batch(z.Sp1Verifier(), [z.wire.function_selector('version()')])
         assert ei.value.code == _lib.ERR_NO_DEVICE
+
+
+def test_bench_fails_loudly_without_a_gpu(z):
+    """bench.py must not fall back to a CPU path: without a HIP device it exits with an explicit message."""
+    import subprocess
+    import sys
+    if z.device_count() > 0:
+        pytest.skip('a gfx950 device is present')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0'], capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert 'no HIP device' in (p.stderr + p.stdout)
+    assert '"metric"' not in p.stdout

@@ -501,3 +501,93 @@ def test_verifier_set_matches_per_instance_oracles(zkv, real_proofs):
         lo, hi = oracles[k].get_control_root()
         assert got.pop(0) == ol.groth16_vk_x(0, [lo.rjust(32, b'\0'), hi.rjust(32, b'\0'), a, b, ids[k]])
     vs.close()
+
+
+def test_differential_fuzz_against_the_oracle(zkv, r0, sp1, real_proofs):
+    """Seeded random damage -- byte flips, word swaps, coordinate edits near 0 / Q / 2^256, truncations -- applied to valid
+    seals and to canonical calldata; every outcome (status, received selector, return / revert data) must equal the oracle's."""
+    import random
+    import oracle_lib as ol
+    rng = random.Random(0x5A4B5691)
+    Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    r, s = real_proofs['risc0'], real_proofs['sp1']
+    orc = ol.Risc0Oracle(); orc.initialize(H(r['control_root']), H(r['bn254_control_id']))
+
+    def damage(seal):
+        b = bytearray(seal)
+        for _ in range(rng.choice((1, 1, 1, 2, 3))):
+            k = rng.randrange(8)
+            if k == 0:
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+            elif k == 1:                                     # replace one word by an edge value
+                w = 4 + 32 * rng.randrange(8)
+                v = rng.choice((0, 1, 2, Q - 1, Q, Q + 1, (1 << 256) - 1, rng.randrange(1 << 256), rng.randrange(Q)))
+                b[w:w + 32] = v.to_bytes(32, 'big')
+            elif k == 2:                                     # swap two words
+                i, j = 4 + 32 * rng.randrange(8), 4 + 32 * rng.randrange(8)
+                b[i:i + 32], b[j:j + 32] = b[j:j + 32], b[i:i + 32]
+            elif k == 3:
+                del b[rng.randrange(len(b) + 1):]
+            elif k == 4:
+                b += rng.randbytes(rng.randrange(1, 40))
+            elif k == 5:                                     # zero a whole point
+                w = rng.choice((4, 68, 196))
+                n = 128 if w == 68 else 64
+                b[w:w + n] = bytes(n)
+            elif k == 6:                                     # negate a G1 y coordinate (valid point, wrong proof)
+                w = rng.choice((36, 228))
+                y = int.from_bytes(b[w:w + 32], 'big')
+                if 0 < y < Q:
+                    b[w:w + 32] = (Q - y).to_bytes(32, 'big')
+            # k == 7: leave as is
+        return bytes(b)
+
+    n = 1500
+    seals = [damage(H(r['seal'])) for _ in range(n)]
+    ids = [H(r['image_id'])] * n
+    jds = [H(r['journal_digest']) if rng.random() < 0.9 else rng.randbytes(32) for _ in range(n)]
+    st, rv = r0.verify_batch(seals, ids, jds)
+    ost, orv = orc.verify_batch(seals, ids, jds, threads=8)
+    assert (st == ost).all() and (rv.reshape(-1) == orv).all()
+    assert {0, 1, 4, 5} <= set(int(x) for x in st)
+    proofs = [damage(H(s['proof'])) for _ in range(n)]
+    vks = [H(s['vkey']) if rng.random() < 0.9 else rng.randbytes(32) for _ in range(n)]
+    pvs = [H(s['public_values']) if rng.random() < 0.8 else rng.randbytes(rng.randrange(0, 200)) for _ in range(n)]
+    st, rv = sp1.verify_batch(vks, pvs, proofs)
+    ost, orv = ol.sp1_verify_batch(vks, pvs, proofs, threads=8)
+    assert (st == ost).all() and (rv.reshape(-1) == orv).all()
+
+    # calldata: damage anywhere in the canonical encoding
+    def damage_cd(cd):
+        b = bytearray(cd)
+        for _ in range(rng.choice((1, 1, 2))):
+            k = rng.randrange(6)
+            if k == 0:
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+            elif k == 1:
+                del b[rng.randrange(len(b) + 1):]
+            elif k == 2:
+                b += bytes(rng.randrange(1, 70))
+            elif k == 3:                                     # edit one of the first six words (heads, lengths)
+                w = 4 + 32 * rng.randrange(6)
+                b[w + 28:w + 32] = rng.choice((0, 0x20, 0x40, 0x60, 0x80, 259, 260, 261, 96, 1 << 31)).to_bytes(4, 'big')
+            elif k == 4:                                     # drop or duplicate a whole word
+                w = 4 + 32 * rng.randrange(max(1, (len(b) - 4) // 32))
+                if rng.random() < 0.5:
+                    del b[w:w + 32]
+                else:
+                    b[w:w] = b[w:w + 32]
+        return bytes(b)
+
+    m_ = 400
+    base = zkv.wire.encode_risc0_verify(H(r['seal']), H(r['image_id']), H(r['journal_digest']))
+    base_i = zkv.wire.encode_risc0_verify_integrity(H(r['seal']), H(r['claim_digest']))
+    cds = [damage_cd(base if rng.random() < 0.7 else base_i) for _ in range(m_)]
+    rev, ret, wst = zkv.wire.eth_call_batch(r0, cds)
+    for cd, a, b in zip(cds, rev, ret):
+        assert (bool(a), b) == orc.eth_call(cd)[:2]
+    base = zkv.wire.encode_sp1_verify_proof(H(s['vkey']), H(s['public_values']), H(s['proof']))
+    cds = [damage_cd(base) for _ in range(m_)]
+    rev, ret, wst = zkv.wire.eth_call_batch(sp1, cds)
+    for cd, a, b in zip(cds, rev, ret):
+        assert (bool(a), b) == ol.sp1_eth_call(cd)[:2]
