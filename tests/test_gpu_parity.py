@@ -591,3 +591,44 @@ def test_differential_fuzz_against_the_oracle(zkv, r0, sp1, real_proofs):
     rev, ret, wst = zkv.wire.eth_call_batch(sp1, cds)
     for cd, a, b in zip(cds, rev, ret):
         assert (bool(a), b) == ol.sp1_eth_call(cd)[:2]
+
+
+def test_two_contexts_from_two_host_threads(zkv, real_proofs, verify_corpus):
+    """One context per host thread is the documented way to overlap work: two threads, two RISC Zero contexts and one SP1
+    context on the same device, all verifying the corpus concurrently (ctypes releases the GIL during the calls)."""
+    import threading
+    r = real_proofs['risc0']
+    rc = [c for c in verify_corpus['cases'] if c['vm'] == 'risc0'] * 3
+    sc = [c for c in verify_corpus['cases'] if c['vm'] == 'sp1'] * 3
+    out, errs = {}, []
+
+    def risc0_worker(tag):
+        try:
+            v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+            for rep in range(3):
+                st, _ = v.verify_batch([H(c['seal']) for c in rc], [H(c['image_id']) for c in rc], [H(c['journal_digest']) for c in rc])
+                out[(tag, rep)] = list(st)
+            v.close()
+        except Exception as e:                      # surfaced below: an exception in a thread must fail the test
+            errs.append(e)
+
+    def sp1_worker(tag):
+        try:
+            v = zkv.Sp1Verifier()
+            for rep in range(3):
+                st, _ = v.verify_batch([H(c['vkey']) for c in sc], [H(c['public_values']) for c in sc], [H(c['proof']) for c in sc])
+                out[(tag, rep)] = list(st)
+            v.close()
+        except Exception as e:
+            errs.append(e)
+
+    ts = [threading.Thread(target=risc0_worker, args=('a',)), threading.Thread(target=risc0_worker, args=('b',)),
+          threading.Thread(target=sp1_worker, args=('s',))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for rep in range(3):
+        assert out[('a', rep)] == out[('b', rep)] == [c['status'] for c in rc]
+        assert out[('s', rep)] == [c['status'] for c in sc]
