@@ -115,13 +115,17 @@ ZKV_HD bool g2j_eq(const G2J& a, const G2J& b) {
     if (!f2_eq(f2_mul(a.x, zb2), f2_mul(b.x, za2))) return false;
     return f2_eq(f2_mul(a.y, f2_mul(zb2, b.z)), f2_mul(b.y, f2_mul(za2, a.z)));
 }
-// [u]P for the BN parameter u (63 bits), P affine, complete formulas (P may have small order)
+// [u]P for the BN parameter u (63 bits), P affine, complete formulas (P may have small order).  Signed digits (NAF of u,
+// 24 non-zero digits instead of 28 set bits): a -1 digit adds -P = (x, -y).
 ZKV_HD G2J g2_mul_u(const Fp2& px, const Fp2& py) {
+    const int8_t NAF[ZKV_U_NAF_LEN] = ZKV_U_NAF;
+    const Fp2 ny = f2_neg(py);
     G2J acc; acc.x = px; acc.y = py; acc.z = f2_one();
 #pragma unroll 1
-    for (int i = 61; i >= 0; i--) {
+    for (int i = ZKV_U_NAF_LEN - 2; i >= 0; i--) {
         acc = g2j_dbl(acc);
-        if ((ZKV_BN_U >> i) & 1ULL) acc = g2j_add_affine(acc, px, py);
+        const int d = NAF[i];
+        if (d != 0) acc = g2j_add_affine(acc, px, d > 0 ? py : ny);
     }
     return acc;
 }

@@ -227,14 +227,24 @@ ZKV_HD void fp_to_raw(uint32_t* limbs, const Fp& a) {      // out of Montgomery 
     for (int i = 0; i < 8; i++) s.v[i] = subb(t.v[i], P[i], br);
     for (int i = 0; i < 8; i++) limbs[i] = br ? t.v[i] : s.v[i];
 }
-// a^(p-2); inv(0) = 0.  Deliberately a loop (not unrolled): 254 squarings + multiplies.
+// a^(p-2); inv(0) = 0.  Sliding window of width 3 over a, a^3, a^5, a^7 (schedule generated by gen_constants.py):
+// a loop, not unrolled.
 ZKV_HD Fp fp_inv(const Fp& a) {
-    const uint32_t E[8] = ZKV_FP_PM2_LIMBS;
-    Fp acc = fp_one();
+    const uint8_t S[ZKV_FP_INV_SCHED_LEN] = ZKV_FP_INV_SCHED;
+    Fp odd[4];
+    odd[0] = a;
+    const Fp a2 = fp_sqr(a);
+    odd[1] = fp_mul(a2, a); odd[2] = fp_mul(odd[1], a2); odd[3] = fp_mul(odd[2], a2);
+    Fp acc = odd[(S[0] & 7) >> 1];
 #pragma unroll 1
-    for (int i = 253; i >= 0; i--) {
-        acc = fp_sqr(acc);
-        if ((E[i >> 5] >> (i & 31)) & 1u) acc = fp_mul(acc, a);
+    for (int i = 1; i < ZKV_FP_INV_SCHED_LEN; i++) {
+        const int nsq = S[i] >> 3, v = S[i] & 7;
+#pragma unroll 1
+        for (int k = 0; k < nsq; k++) acc = fp_sqr(acc);
+        if (v) {
+            const Fp m = v == 1 ? odd[0] : v == 3 ? odd[1] : v == 5 ? odd[2] : odd[3];
+            acc = fp_mul(acc, m);
+        }
     }
     return acc;
 }
