@@ -147,14 +147,13 @@ ZKV_HD bool g2_in_subgroup(const Fp2& qx, const Fp2& qy) {
 struct G2H { Fp2 x, y, z; };
 
 ZKV_HD void line_dbl(G2H& T, Fp2& l0, Fp2& l1, Fp2& l3) {
-    const Fp two_inv = ZKV_FP_TWO_INV;
     const Fp2C b3c = ZKV_TWIST_3B;
     const Fp2 b3 = f2_const(b3c);
-    Fp2 a = f2_mul_fp(f2_mul(T.x, T.y), two_inv);
+    Fp2 a = f2_half(f2_mul(T.x, T.y));
     Fp2 b = f2_sqr(T.y), c = f2_sqr(T.z);
     Fp2 e = f2_mul(b3, c);                              // 3 b' Z^2
     Fp2 f = f2_add(f2_dbl(e), e);                       // 9 b' Z^2
-    Fp2 g = f2_mul_fp(f2_add(b, f), two_inv);
+    Fp2 g = f2_half(f2_add(b, f));
     Fp2 h = f2_sub(f2_sqr(f2_add(T.y, T.z)), f2_add(b, c));   // 2YZ
     Fp2 j = f2_sqr(T.x);
     Fp2 e2 = f2_sqr(e);

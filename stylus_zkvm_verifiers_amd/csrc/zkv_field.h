@@ -108,6 +108,19 @@ ZKV_HD Fp fp_sub(const Fp& a, const Fp& b) {
 ZKV_HD bool fp_eq(const Fp& a, const Fp& b) { return fp_is_zero(fp_sub(a, b)); }      // a - b in {0, p} after the loose subtraction
 ZKV_HD Fp fp_neg(const Fp& a) { return fp_sub(fp_zero(), a); }
 ZKV_HD Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
+// a / 2: add p when a is odd (p is odd, so the sum is even and < 3p < 2^256), then shift right by one; result < 2p.
+ZKV_HD Fp fp_half(const Fp& a) {
+    const uint32_t P[8] = ZKV_FP_P_LIMBS;
+    const uint32_t m = 0u - (a.v[0] & 1u);
+    Fp t; uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t.v[i] = addc(a.v[i], P[i] & m, c);
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 7; i++) r.v[i] = (t.v[i] >> 1) | (t.v[i + 1] << 31);
+    r.v[7] = t.v[7] >> 1;
+    return r;
+}
 // a + b without the modular reduction: for sums that only feed a multiplier (which accepts any 256-bit operand).
 // At most TWO loose values may be summed this way: 4p < 2^256 and every product bound in this file assumes operands < 4p.
 ZKV_HD Fp fp_add_nr(const Fp& a, const Fp& b) {
@@ -305,6 +318,7 @@ ZKV_HD Fp2 f2_neg(const Fp2& a) { Fp2 r; Fp z = fp_zero(); fp_sub_x2(z, a.c0, z,
 // lazy sum (components < 2p) that may only be passed to f2_mul
 ZKV_HD Fp2 f2_add_nr(const Fp2& a, const Fp2& b) { Fp2 r; r.c0 = fp_add_nr(a.c0, b.c0); r.c1 = fp_add_nr(a.c1, b.c1); return r; }
 ZKV_HD Fp2 f2_dbl(const Fp2& a) { return f2_add(a, a); }
+ZKV_HD Fp2 f2_half(const Fp2& a) { Fp2 r; r.c0 = fp_half(a.c0); r.c1 = fp_half(a.c1); return r; }
 ZKV_HD Fp2 f2_conj(const Fp2& a) { Fp2 r; r.c0 = a.c0; r.c1 = fp_neg(a.c1); return r; }
 // Fp2 product with the Montgomery reductions shared: three 81-term column products (a0 b0, a1 b1,
 // (a0+a1)(b0+b1)) and only TWO reductions -- c1 = M - T0 - T1 is non-negative column by column, c0 = T0 - T1 + 16 p^2
@@ -404,6 +418,7 @@ ZKV_HD Fp2 f2_sub(const Fp2& a, const Fp2& b) { Fp2 r; r.h = fp_sub(a.h, b.h); r
 ZKV_HD Fp2 f2_neg(const Fp2& a) { Fp2 r; r.h = fp_neg(a.h); return r; }
 ZKV_HD Fp2 f2_add_nr(const Fp2& a, const Fp2& b) { Fp2 r; r.h = fp_add_nr(a.h, b.h); return r; }
 ZKV_HD Fp2 f2_dbl(const Fp2& a) { return f2_add(a, a); }
+ZKV_HD Fp2 f2_half(const Fp2& a) { Fp2 r; r.h = fp_half(a.h); return r; }
 ZKV_HD Fp2 f2_conj(const Fp2& a) { Fp2 r; r.h = fp_sel(zkv_parity() != 0, fp_neg(a.h), a.h); return r; }
 // (a0 + a1 u)(b0 + b1 u): the even lane forms a0 b0 + a1 (8p - b1), the odd lane a0 b1 + a1 b0 -- two 81-term column
 // products and ONE Montgomery reduction per lane, all terms non-negative (8p - b1 in borrow-free 29-bit limbs).

@@ -171,6 +171,7 @@ int hs_fp_loose_check(const uint8_t* a32, const uint8_t* b32) {
         if (!same_residue(n, ref_neg)) return 6;
         if (!same_residue(lz, ref_lazy)) return 7;
         if (!fp_eq(A[i], A[1 - i]) || !fp_is_zero(fp_sub(A[i], A[1 - i]))) return 8;
+        { Fp hf = fp_half(A[i]); if (!below_2p(hf) || !same_residue(fp_add(hf, hf), A[0])) return 16; }
         Fp x2[2], y2[2], r2[2]; x2[0] = A[i]; x2[1] = B[j]; y2[0] = B[j]; y2[1] = A[i];
         fp_add_n<2>(x2, y2, r2);
         if (!same_residue(r2[0], ref_add) || !below_2p(r2[1])) return 9;
