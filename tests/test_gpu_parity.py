@@ -632,3 +632,71 @@ def test_two_contexts_from_two_host_threads(zkv, real_proofs, verify_corpus):
     for rep in range(3):
         assert out[('a', rep)] == out[('b', rep)] == [c['status'] for c in rc]
         assert out[('s', rep)] == [c['status'] for c in sc]
+
+
+def test_small_chunks_give_the_same_answers(zkv, r0, sp1, real_proofs):
+    """Every entry point loops over workspace chunks (ZKV_CHUNK proofs).  Contexts created with a 192-proof chunk must return
+    exactly what the default contexts return on 700-proof batches: host and device-resident seal paths, calldata paths,
+    verifier sets, vk_x and the generic / precompile entry points that share the loop."""
+    import torch
+    from stylus_zkvm_verifiers_amd import synth
+    dev = torch.device('cuda', 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    r, s = real_proofs['risc0'], real_proofs['sp1']
+    n = 700
+    seals, mut, mclass, flip = synth.make_batch('risc0', H(r['seal']), n, 0x5A4B56A1, pool=4, mutate_every=5)
+    ids = np.tile(np.frombuffer(H(r['image_id']), dtype=np.uint8), (n, 1))
+    jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (n, 1)); jds[flip, 0] ^= 1
+    proofs, smut, _, sflip = synth.make_batch('sp1', H(s['proof']), n, 0x5A4B56A2, pool=4, mutate_every=5)
+    vk = np.tile(np.frombuffer(H(s['vkey']), dtype=np.uint8), (n, 1))
+    pv = np.tile(np.frombuffer(H(s['public_values']), dtype=np.uint8), (n, 1)); pv[sflip, -1] ^= 1
+    rows = lambda a: [x.tobytes() for x in a]
+    os.environ['ZKV_CHUNK'] = '192'
+    try:
+        r0s = zkv.RiscZeroVerifier(); r0s.initialize(H(r['control_root']), H(r['bn254_control_id']))
+        sp1s = zkv.Sp1Verifier()
+        sets = zkv.RiscZeroVerifierSet([H(r['control_root']), bytes(32)], [H(r['bn254_control_id']), bytes(32)])
+        # host seal paths
+        want, want_rv = r0.verify_batch(rows(seals), rows(ids), rows(jds))
+        got, got_rv = r0s.verify_batch(rows(seals), rows(ids), rows(jds))
+        assert (got == want).all() and (got_rv == want_rv).all() and ((want == 0) == ~mut).all()
+        swant, _ = sp1.verify_batch(rows(vk), rows(pv), rows(proofs))
+        sgot, _ = sp1s.verify_batch(rows(vk), rows(pv), rows(proofs))
+        assert (sgot == swant).all() and ((swant == 0) == ~smut).all()
+        # device-resident seal path
+        d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (seals, ids, jds)]
+        d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+        r0s.verify_batch_dev(n, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d_st.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        assert (d_st.cpu().numpy() == want).all()
+        # calldata, host and device-resident
+        cds = [zkv.wire.encode_risc0_verify(a, b, c) for a, b, c in zip(rows(seals), rows(ids), rows(jds))]
+        rev, ret, wst = zkv.wire.eth_call_batch(r0s, cds)
+        assert (wst == want).all()
+        cd = synth.calldata_sp1_verify_proof(vk, pv, proofs)
+        off = np.arange(n + 1, dtype=np.uint64) * np.uint64(cd.shape[1])
+        d_cd, d_off = torch.from_numpy(cd).to(dev), torch.from_numpy(off.view(np.int64)).to(dev)
+        d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+        zkv.wire.eth_call_batch_dev(sp1s, n, d_cd.data_ptr(), d_off.data_ptr(), cd.size, d_st.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        assert (d_st.cpu().numpy() == swant).all()
+        # verifier set: instance 0 is the real verifier, instance 1 another one
+        inst = np.array([i % 2 for i in range(n)], dtype=np.uint32)
+        st_set, _ = sets.verify_batch(inst, rows(seals), rows(ids), rows(jds))
+        assert (st_set[inst == 0] == want[inst == 0]).all() and set(st_set[inst == 1]) <= {4, 5}
+        # vk_x
+        sig = [(bytes(16) + bytes([i % 251] * 16), bytes(16) + bytes([(7 * i) % 253] * 16)) for i in range(n)]
+        assert r0s.vk_x_batch(sig) == r0.vk_x_batch(sig)
+        # precompile seam (same chunk loop)
+        pc = zkv.Bn254Precompiles()
+        G = (1).to_bytes(32, 'big') + (2).to_bytes(32, 'big')
+        muls = [G + (i * 0x9E3779B97F4A7C15 % (1 << 200)).to_bytes(32, 'big') for i in range(n)]
+        small = pc.ecmul(muls)
+        pc.close()
+        for v in (r0s, sp1s, sets):
+            v.close()
+    finally:
+        os.environ.pop('ZKV_CHUNK', None)
+    pc2 = zkv.Bn254Precompiles()
+    assert pc2.ecmul(muls) == small
+    pc2.close()
