@@ -34,3 +34,28 @@ def test_corpus_slice_runs_clean(driver, verify_corpus):
         assert p.returncode == 0, (c['name'], p.stderr.decode()[-2000:])
         assert b'runtime error' not in p.stderr and b'AddressSanitizer' not in p.stderr, c['name']
         assert int(p.stdout.strip()) == c['status'], c['name']
+
+
+def test_wire_layer_decoding_runs_clean(driver, wire_cases):
+    """The calldata decoder of the oracle under ASan / UBSan on damaged calldata (truncations, huge lengths, bad offsets):
+    no over-reads, and the golden return / revert data."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from wire_util import calldata_of
+    import oracle_lib as ol
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='halt_on_error=1')
+    ctx = wire_cases['risc0_ctx']
+    picks = [c for c in wire_cases['cases'] if c['reverted'] and c['status'] in (6, 4) or c['method'] == 'raw'][:60]
+    picks += [c for c in wire_cases['cases'] if c['name'].startswith('real proof')]
+    assert len(picks) >= 40
+    for c in picks:
+        cd = calldata_of(c, ol.risc0_encode_call, ol.risc0_encode_call, ol.sp1_encode_call).hex()
+        if c['vm'] == 'risc0':
+            args = ['call_risc0'] + ([ctx['control_root'], ctx['bn254_control_id']] if c['ctx'] == 'init' else ['-', '-']) + [cd]
+        else:
+            args = ['call_sp1', cd]
+        p = subprocess.run([driver] + args, capture_output=True, env=env, timeout=120)
+        assert p.returncode == 0, (c['name'], p.stderr.decode()[-2000:])
+        assert b'runtime error' not in p.stderr and b'AddressSanitizer' not in p.stderr, c['name']
+        rev, _, ret = p.stdout.decode().strip().partition(' ')
+        assert (rev == '1', ret) == (c['reverted'], c['returndata']), c['name']
