@@ -190,6 +190,19 @@ int hs_fp_loose_check(const uint8_t* a32, const uint8_t* b32) {
     if (!az && !same_residue(fp_mul(inv, A[0]), fp_one())) return 15;
     return 0;
 }
+// One-proof-per-lane multipliers on raw operands below 4p (the edge of their contract): out = a*b (Fp, canonical) followed by
+// the two components of (a0 + a1 u)(b0 + b1 u); returns 0 when a result leaves the loose range.
+int hs_mul_edge(const uint32_t* in32, uint32_t* out24) {
+    const uint32_t P2[8] = ZKV_FP_2P_LIMBS;
+    Fp a0, a1, b0, b1;
+    memcpy(a0.v, in32, 32); memcpy(a1.v, in32 + 8, 32); memcpy(b0.v, in32 + 16, 32); memcpy(b1.v, in32 + 24, 32);
+    Fp m = fp_mul(a0, b0);
+    Fp2 x, y; x.c0 = a0; x.c1 = a1; y.c0 = b0; y.c1 = b1;
+    Fp2 z = f2_mul(x, y);
+    if (u256_geq(m.v, P2) || u256_geq(z.c0.v, P2) || u256_geq(z.c1.v, P2)) return 0;
+    fp_to_raw(out24, m); fp_to_raw(out24 + 8, z.c0); fp_to_raw(out24 + 16, z.c1);
+    return 1;
+}
 // returns 1 when the Granger-Scott cyclotomic squaring equals the generic squaring on a random element of the
 // cyclotomic subgroup (x^((p^6-1)(p^2+1)) for x built from the seed bytes)
 int hs_cyclo_sqr_check(const uint8_t* seed384) {

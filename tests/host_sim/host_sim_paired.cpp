@@ -58,3 +58,34 @@ extern "C" int hs2_pairing(const void* tables, uint32_t flags, const uint32_t* n
     *sub_ok = j.sub_ok[0];
     return j.accept[0];
 }
+
+// Lane-pair Fp2 arithmetic on raw operands at the edge of the multipliers' contract (any value below 4p: lazy sums of two
+// loose values).  in: a0 a1 b0 b1 as 8 little-endian words each (Montgomery-domain integers, NOT reduced); out: 5 results x 2
+// components x 8 words, brought out of Montgomery form (canonical): a*b, a^2 (needs a < 2p), xi*a (a < 2p), a+b and a-b (a, b < 2p).
+struct EdgeJob { const uint32_t* in; uint32_t* out; int ok[2]; };
+static void edge_lane(EdgeJob* j, uint32_t par) {
+    tl_par = par;
+    const uint32_t P2[8] = ZKV_FP_2P_LIMBS;
+    Fp2 a, b;
+    memcpy(a.h.v, j->in + 8 * par, 32); memcpy(b.h.v, j->in + 16 + 8 * par, 32);
+    const bool reduced = !u256_geq(a.h.v, P2) && !u256_geq(b.h.v, P2);
+    const bool both_reduced = (zkv_partner_u32(reduced ? 1u : 0u) != 0) && reduced;
+    Fp2 r[5];
+    r[0] = f2_mul(a, b);
+    if (both_reduced) { r[1] = f2_sqr(a); r[2] = f2_mul_xi(a); r[3] = f2_add(a, b); r[4] = f2_sub(a, b); }
+    else { r[1] = r[2] = r[3] = r[4] = f2_zero(); }
+    int ok = 1;
+    for (int k = 0; k < 5; k++) {
+        if (u256_geq(r[k].h.v, P2)) ok = 0;                       // every result stays in the loose range
+        fp_to_raw(j->out + 16 * k + 8 * par, r[k].h);
+    }
+    j->ok[par] = ok;
+}
+extern "C" int hs2_f2_edge(const uint32_t* in32, uint32_t* out80) {
+    EdgeJob j; j.in = in32; j.out = out80;
+    g_cnt = 0;
+    std::thread t1(edge_lane, &j, 1u);
+    edge_lane(&j, 0u);
+    t1.join();
+    return j.ok[0] && j.ok[1];
+}

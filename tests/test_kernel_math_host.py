@@ -192,3 +192,70 @@ def test_verifier_set_instance_setup_matches_oracle(hs, real_proofs):
             lo, hi = o.get_control_root()
             want = ol.groth16_vk_x(0, [lo.rjust(32, b'\0'), hi.rjust(32, b'\0'), s0, s1, cid])
             assert vkx.raw == want
+
+
+def test_lane_pair_products_at_the_edge_of_their_contract(hs_pair):
+    """The lane-pair Fp2 product must be exact for every operand below 4p (a lazy sum of two loose values), squaring, xi and
+    the additions for every operand below 2p, and all results must stay below 2p.  Operands are Montgomery-domain integers;
+    expectations are computed with Python integers."""
+    rng = random.Random(0x5A4B56B1)
+    P, RI = m.P, pow(1 << 261, -1, m.P)
+    edge4 = [0, 1, P - 1, P, P + 1, 2 * P - 1, 2 * P, 2 * P + 1, 3 * P, 4 * P - 1]
+    edge2 = [v for v in edge4 if v < 2 * P]
+    L = hs_pair
+    L.hs2_f2_edge.argtypes = [C.c_void_p, C.c_void_p]
+
+    def words(v): return [(v >> (32 * i)) & 0xffffffff for i in range(8)]
+    def unwords(w): return sum(int(x) << (32 * i) for i, x in enumerate(w))
+
+    def run(a0, a1, b0, b1):
+        buf = (C.c_uint32 * 32)(*(words(a0) + words(a1) + words(b0) + words(b1)))
+        out = (C.c_uint32 * 80)()
+        assert L.hs2_f2_edge(buf, out) == 1, (hex(a0), hex(a1), hex(b0), hex(b1))
+        got = [(unwords(out[16 * k:16 * k + 8]), unwords(out[16 * k + 8:16 * k + 16])) for k in range(5)]
+        mont = lambda x: x * RI % P                              # fp_to_raw: out of Montgomery form
+        want_mul = (mont((a0 * b0 - a1 * b1) * RI), mont((a0 * b1 + a1 * b0) * RI))
+        assert got[0] == (want_mul[0] % P, want_mul[1] % P), 'mul'
+        if max(a0, a1, b0, b1) < 2 * P:
+            assert got[1] == (mont((a0 * a0 - a1 * a1) * RI) % P, mont(2 * a0 * a1 * RI) % P), 'sqr'
+            assert got[2] == (mont(9 * a0 - a1) % P, mont(9 * a1 + a0) % P), 'xi'
+            assert got[3] == (mont(a0 + b0) % P, mont(a1 + b1) % P), 'add'
+            assert got[4] == (mont(a0 - b0) % P, mont(a1 - b1) % P), 'sub'
+
+    for a0 in edge4:
+        for a1 in (0, P, 4 * P - 1, rng.randrange(4 * P)):
+            for b0, b1 in ((0, 4 * P - 1), (4 * P - 1, 4 * P - 1), (rng.randrange(4 * P), rng.randrange(4 * P)), (P, 2 * P)):
+                run(a0, a1, b0, b1)
+    for a0 in edge2:
+        for a1 in edge2[::2] + [rng.randrange(2 * P)]:
+            run(a0, a1, rng.choice(edge2), rng.choice(edge2))
+    for _ in range(200):
+        run(*(rng.randrange(4 * P) for _ in range(4)))
+        run(*(rng.randrange(2 * P) for _ in range(4)))
+
+
+def test_one_proof_per_lane_multipliers_at_the_edge_of_their_contract(hs):
+    """fp_mul and the fused Fp2 product of the one-proof-per-lane kernels (three column products, two reductions, signed
+    columns) on operands up to 4p - 1."""
+    rng = random.Random(0x5A4B56B2)
+    P, RI = m.P, pow(1 << 261, -1, m.P)
+    edge = [0, 1, P - 1, P, 2 * P - 1, 2 * P, 3 * P + 1, 4 * P - 1]
+    hs.hs_mul_edge.argtypes = [C.c_void_p, C.c_void_p]
+
+    def words(v): return [(v >> (32 * i)) & 0xffffffff for i in range(8)]
+    def unwords(w): return sum(int(x) << (32 * i) for i, x in enumerate(w))
+
+    def run(a0, a1, b0, b1):
+        buf = (C.c_uint32 * 32)(*(words(a0) + words(a1) + words(b0) + words(b1)))
+        out = (C.c_uint32 * 24)()
+        assert hs.hs_mul_edge(buf, out) == 1
+        got = [unwords(out[8 * k:8 * k + 8]) for k in range(3)]
+        assert got[0] == a0 * b0 * RI * RI % P
+        assert got[1] == (a0 * b0 - a1 * b1) * RI * RI % P and got[2] == (a0 * b1 + a1 * b0) * RI * RI % P
+
+    for a0 in edge:
+        for a1 in edge[::3]:
+            for b0, b1 in ((4 * P - 1, 4 * P - 1), (0, 4 * P - 1), (P, 2 * P), (rng.randrange(4 * P), rng.randrange(4 * P))):
+                run(a0, a1, b0, b1)
+    for _ in range(300):
+        run(*(rng.randrange(4 * P) for _ in range(4)))
