@@ -95,8 +95,10 @@ __global__ __launch_bounds__(BLOCK) void k_wire_risc0(WireArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const size_t i = (size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     if (i >= a.n) return;
-    const uint8_t* cd = a.cd + a.off[i];
-    const uint64_t len = a.off[i + 1] - a.off[i];
+    const uint64_t o0 = a.off[i], o1 = a.off[i + 1];
+    const bool in_blob = o0 <= o1 && o1 <= a.cd_bytes;       // offsets come from the caller: never read outside the blob
+    const uint8_t* cd = a.cd + (in_blob ? o0 : 0);
+    const uint64_t len = in_blob ? o1 - o0 : 0;
     const bool al = (((uintptr_t)cd) & 3u) == 0;
     uint32_t L = WIRE_BAD, kind = 0;
     if (len >= 4) {
@@ -122,11 +124,13 @@ __global__ __launch_bounds__(BLOCK) void k_wire_sp1(WireArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const size_t i = (size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     if (i >= a.n) return;
-    const uint8_t* cd = a.cd + a.off[i];
-    const uint64_t len = a.off[i + 1] - a.off[i];
+    const uint64_t o0 = a.off[i], o1 = a.off[i + 1];
+    const bool in_blob = o0 <= o1 && o1 <= a.cd_bytes;       // offsets come from the caller: never read outside the blob
+    const uint8_t* cd = a.cd + (in_blob ? o0 : 0);
+    const uint64_t len = in_blob ? o1 - o0 : 0;
     const bool al = (((uintptr_t)cd) & 3u) == 0;
     uint32_t L = WIRE_BAD, lpv = 0;
-    const uint64_t pv_at = a.off[i] / 32;         // decoded public values of request i: at most len / 32 bytes
+    const uint64_t pv_at = in_blob ? o0 / 32 : 0; // decoded public values of request i: at most len / 32 bytes
     if (len >= 4 + 96 + 64 && load_be32(cd) == a.sel_a_be) {
         const uint8_t* args = cd + 4;
         WordVal o1 = wire_word(args + 32, al), o2 = wire_word(args + 64, al), n1 = wire_word(args + 96, al);

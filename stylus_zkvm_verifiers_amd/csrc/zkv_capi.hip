@@ -209,12 +209,18 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     if (timed) (void)hipEventRecord(c->ev[5], s);
 }
 
+// Offsets handed over by the caller must be non-decreasing: the kernels index the blob with them.
+static bool offsets_ok(const uint64_t* off, size_t n) {
+    for (size_t i = 0; i < n; i++) if (off[i + 1] < off[i]) return false;
+    return true;
+}
 static uint32_t be32_of(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
 // Host-pointer batch driver shared by risc0 verify / verify_integrity / sp1 verify_proof.
 static int run_host_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const uint64_t* off, const uint8_t* in_a, const uint8_t* in_b,
                           const uint8_t* pv_blob, const uint64_t* pv_off, uint8_t* status, uint8_t* recv) {
     if (!c || (n && (!blob || !off || !status))) return ZKV_ERR_INVALID_ARG;
+    if (n && (!offsets_ok(off, n) || (pv_off && !offsets_ok(pv_off, n)))) return ZKV_ERR_INVALID_ARG;
     if (recv) memset(recv, 0, 4 * n);
     if (c->vm == ZKV_VM_RISC0 && !c->initialized) {              // risc0/verifier.rs:84-86, 99-101
         memset(status, ZKV_STATUS_INVALID_INITIALIZATION, n);
@@ -411,6 +417,7 @@ static int run_set_batch(zkv_ctx* c, size_t n, const uint32_t* inst, const uint8
                          uint8_t* status, uint8_t* recv, bool dev, void* stream) {
     if (!c || c->vm != ZKV_VM_RISC0_SET) return ZKV_ERR_WRONG_CTX;
     if (n && (!inst || !blob || (!dev && !off) || !ids || !jds || !status)) return ZKV_ERR_INVALID_ARG;
+    if (n && !dev && !offsets_ok(off, n)) return ZKV_ERR_INVALID_ARG;
     if (!n) return ZKV_OK;
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_device_init(c);
@@ -602,7 +609,7 @@ static int enqueue_wire_chunk(zkv_ctx* c, size_t m, const uint8_t* d_cd, const u
     const host::Selectors& S = host::selectors();
     WireArgs w;
     memset(&w, 0, sizeof w);
-    w.n = m; w.cd = d_cd; w.off = d_cdoff;
+    w.n = m; w.cd = d_cd; w.off = d_cdoff; w.cd_bytes = cd_bytes;
     w.seals = c->d_blob; w.seal_len = c->d_len; w.in_a = c->d_a; w.in_b = c->d_b; w.kind = c->d_kind;
     w.pv = c->d_pv; w.pv_off = c->d_pvoff; w.pv_len = c->d_pvlen;
     if (timed) (void)hipEventRecord(c->ev_wire[0], s);
@@ -662,6 +669,7 @@ static int run_eth_call_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const u
                               uint32_t* returndata_len, uint8_t* status) {
     if (!c || (n && (!blob || !off || !reverted || !returndata || !returndata_len))) return ZKV_ERR_INVALID_ARG;
     if (!n) return ZKV_OK;
+    if (!offsets_ok(off, n)) return ZKV_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_device_init(c);
     if (rc != ZKV_OK) return rc;

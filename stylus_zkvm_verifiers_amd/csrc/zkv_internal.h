@@ -60,6 +60,7 @@ struct WireArgs {
     size_t n;
     const uint8_t* cd;          // calldata blob
     const uint64_t* off;        // n+1 offsets
+    uint64_t cd_bytes;          // size of the blob: a request whose offsets leave [0, cd_bytes] or run backwards is never read
     uint32_t sel_a_be, sel_b_be;    // risc0: verify / verifyIntegrity; sp1: verifyProof / unused
     uint8_t* seals;             // n x 260: first min(L, 260) decoded seal / proof bytes
     uint32_t* seal_len;         // n: decoded length L, or 0xFFFFFFFF when the calldata is not a canonical verify call

@@ -121,3 +121,22 @@ def test_bench_fails_loudly_without_a_gpu(z):
     assert p.returncode != 0
     assert 'no HIP device' in (p.stderr + p.stdout)
     assert '"metric"' not in p.stdout
+
+
+def test_offsets_running_backwards_are_rejected(z, real_proofs):
+    """Caller-supplied offsets index the blob inside the kernels: non-monotonic offsets are an argument error, not a read."""
+    import numpy as np
+    from stylus_zkvm_verifiers_amd import _lib
+    L = _lib.lib()
+    r = real_proofs['risc0']
+    v = z.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    blob = H(r['seal']) * 2 + b'\0'
+    bad = np.array([0, 520, 260], dtype=np.uint64)
+    ids = H(r['image_id']) * 2; jds = H(r['journal_digest']) * 2
+    st = np.zeros(2, dtype=np.uint8)
+    assert L.zkv_risc0_verify_batch(v._h, 2, blob, bad.ctypes.data, ids, jds, st.ctypes.data, None) == _lib.ERR_INVALID_ARG
+    rev = np.zeros(2, dtype=np.uint8); ret = np.zeros(2 * 96, dtype=np.uint8); rl = np.zeros(2, dtype=np.uint32)
+    assert L.zkv_risc0_eth_call_batch(v._h, 2, blob, bad.ctypes.data, rev.ctypes.data, ret.ctypes.data, rl.ctypes.data, None) == _lib.ERR_INVALID_ARG
+    sp = z.Sp1Verifier()
+    good = np.array([0, 260, 520], dtype=np.uint64)
+    assert L.zkv_sp1_verify_batch(sp._h, 2, ids, blob, bad.ctypes.data, blob, good.ctypes.data, st.ctypes.data, None) == _lib.ERR_INVALID_ARG

@@ -700,3 +700,22 @@ def test_small_chunks_give_the_same_answers(zkv, r0, sp1, real_proofs):
     pc2 = zkv.Bn254Precompiles()
     assert pc2.ecmul(muls) == small
     pc2.close()
+
+
+def test_device_calldata_with_corrupt_offsets_is_never_read(zkv, r0, real_proofs):
+    """zkv_eth_call_batch_dev takes its offsets from device memory: requests whose offsets run backwards or leave the blob get
+    BAD_CALLDATA without being dereferenced; their neighbours are unaffected."""
+    import torch
+    dev = torch.device('cuda', 0)
+    r = real_proofs['risc0']
+    cd = np.frombuffer(zkv.wire.encode_risc0_verify(H(r['seal']), H(r['image_id']), H(r['journal_digest'])), dtype=np.uint8)
+    n, L = 6, len(cd)
+    blob = np.tile(cd, n)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    off[2] = np.uint64(1) << np.uint64(62)                      # request 1 ends far outside, request 2 starts there
+    off[5] = off[4] - np.uint64(8)                              # request 4 runs backwards; request 5 then is 8 bytes too long
+    d_cd, d_off = torch.from_numpy(blob).to(dev), torch.from_numpy(off.view(np.int64)).to(dev)
+    d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+    zkv.wire.eth_call_batch_dev(r0, n, d_cd.data_ptr(), d_off.data_ptr(), blob.size, d_st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert list(d_st.cpu().numpy()) == [0, 6, 6, 0, 6, 6]
