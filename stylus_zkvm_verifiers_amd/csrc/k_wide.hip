@@ -1,0 +1,72 @@
+// Small-batch variants of the Miller loop and the final exponentiation: ONE PROOF PER 16 LANES (four proofs per
+// wavefront), the six Fp2 coefficients of every Fp12 value spread over six lane pairs (csrc/zkv_tower_wide.h).  Selected
+// by the C ABI for chunks of at most ZKV_WIDE_BELOW proofs (default 8,192), where the lane-pair kernels cannot fill the
+// chip anyway: the answer is the same, a proof just finishes sooner.
+#define ZKV_PAIRED 1
+#include "zkv_internal.h"
+#include "zkv_tower_wide.h"
+
+namespace zkv {
+
+constexpr int WIDE_GROUP = 16;                          // lanes per proof
+constexpr int WIDE_PER_BLOCK = ZKV_BLOCK / WIDE_GROUP;  // proofs per wavefront
+
+struct WideLane { size_t i; uint32_t g, half; int q; };
+__device__ __forceinline__ WideLane wide_lane() {
+    WideLane w;
+    w.g = threadIdx.x / WIDE_GROUP;
+    w.half = threadIdx.x & 1u;
+    w.q = (int)((threadIdx.x >> 1) & 7u);
+    if (w.q >= 6) w.q -= 6;                             // pairs 6 and 7 shadow pairs 0 and 1
+    w.i = (size_t)blockIdx.x * WIDE_PER_BLOCK + w.g;
+    return w;
+}
+__device__ __forceinline__ Fp2 ld_b_w(const Workspace& ws, int word0, size_t i, uint32_t half) {
+    Fp2 r; r.h = ws_ld(ws.prep, ws.cap, word0 + 8 * (int)half, i);
+    return r;
+}
+
+__global__ __launch_bounds__(ZKV_BLOCK) void k_miller_w(size_t n, const VkTables* __restrict__ vk, Workspace ws) {
+    __shared__ uint32_t lds[WIDE_PER_BLOCK * (96 + 48)];  // per proof: f (6 Fp2) and T (3 Fp2), both components
+    const WideLane w = wide_lane();
+    if (w.i >= n) return;
+    const uint32_t flags = ws.flags[w.i];
+    if (!(flags & FL_ALIVE)) return;
+    G1Norm nm;
+    nm.axs = ws_ld(ws.norm, ws.cap, 0, w.i); nm.ays = ws_ld(ws.norm, ws.cap, 8, w.i);
+    nm.lxs = ws_ld(ws.norm, ws.cap, 16, w.i); nm.lys = ws_ld(ws.norm, ws.cap, 24, w.i);
+    nm.cxs = ws_ld(ws.norm, ws.cap, 32, w.i); nm.cys = ws_ld(ws.norm, ws.cap, 40, w.i);
+    Fp2 bx = ld_b_w(ws, 32, w.i, w.half), by = ld_b_w(ws, 48, w.i, w.half);
+    uint32_t* base = lds + w.g * (96 + 48) + 8 * w.half;
+    MRef fm = m_ref(base, 1, 16), tm = m_ref(base + 96, 1, 16);
+    miller_loop_w(*vk, flags, nm, bx, by, fm, tm, w.q);
+    MRef ab = m_ref((uint32_t*)(vk->f_alpha_beta) + 8 * w.half, 1, 16);
+    MRef out = m_ref(ws.f + (size_t)(8 * w.half) * ws.cap + w.i, (uint32_t)ws.cap, 16);
+    w12_mul(out, fm, ab, w.q, false);
+}
+
+__global__ __launch_bounds__(ZKV_BLOCK) void k_finalexp_w(size_t n, Workspace ws, uint8_t* __restrict__ status) {
+    __shared__ uint32_t lds[WIDE_PER_BLOCK * 96];
+    const WideLane w = wide_lane();
+    if (w.i >= n) return;
+    const uint32_t flags = ws.flags[w.i];
+    if (!(flags & FL_ALIVE)) return;
+    const uint32_t st = (uint32_t)ws.cap;
+    MRef acc = m_ref(lds + w.g * 96 + 8 * w.half, 1, 16);
+    MRef F = m_ref(ws.f + (size_t)(8 * w.half) * ws.cap + w.i, st, 16);
+    MRef E = m_ref(ws.fe + (size_t)(8 * w.half) * ws.cap + w.i, st, 16);
+    const bool one = final_exp_is_one_w(F, E, m_off(E, 96), m_off(E, 192), m_off(E, 288), m_off(E, 384), acc, w.q);
+    if ((threadIdx.x & (WIDE_GROUP - 1)) == 0) status[w.i] = one ? ST_OK : ST_VERIFICATION_FAILED;
+}
+
+static inline unsigned wide_grid(size_t n) { return (unsigned)((n + WIDE_PER_BLOCK - 1) / WIDE_PER_BLOCK); }
+void launch_miller_w(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_miller_w, dim3(wide_grid(n)), dim3(ZKV_BLOCK), 0, s, n, d_tab, ws);
+}
+void launch_finalexp_w(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_finalexp_w, dim3(wide_grid(n)), dim3(ZKV_BLOCK), 0, s, n, ws, status);
+}
+
+}  // namespace zkv

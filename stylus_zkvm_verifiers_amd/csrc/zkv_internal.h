@@ -85,6 +85,9 @@ void launch_finalexp(size_t n, const Workspace& ws, uint8_t* status, hipStream_t
 void launch_g2chk2(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
 void launch_miller2(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
 void launch_finalexp2(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
+// coefficient-parallel small-batch variants (k_wide.hip): one proof per 16 lanes
+void launch_miller_w(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
+void launch_finalexp_w(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
 
 // precompile-level batches (k_precompile.hip)
 void launch_ecadd(size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok, hipStream_t s);

@@ -1,0 +1,205 @@
+// Coefficient-parallel ("wide") Fp12 arithmetic for small batches: ONE PROOF PER 16 LANES.
+//
+// In the lane-pair kernels a proof owns one lane pair and walks the 18 Fp2 products of an Fp12 multiplication one after
+// the other, so its latency (12 ms) does not depend on the batch size and a batch below 2^16 proofs leaves most of the
+// chip idle.  Here the six Fp2 coefficients of every Fp12 value (memory order g0 g1 g2 h0 h1 h2 = powers 0 2 4 1 3 5 of
+// w, w^6 = xi) are spread over six lane pairs of a 16-lane group: pair q computes coefficient q of every result.  A pair
+// is still "even lane = real part, odd lane = imaginary part", so all Fp2 arithmetic of zkv_field.h is reused unchanged;
+// only the Fp12-level routines are new.  Operands live in slots every lane of the group can address (LDS, or the HBM
+// struct-of-arrays slots of the final exponentiation); because the whole group sits in one wavefront, every load of a
+// routine is issued before any of its stores and no barrier is needed.
+//   multiplication      c_e = sum_i a_i b_(e-i) xi^[i + (e-i) mod 6 >= 6]   6 Fp2 products per pair instead of 18 in sequence
+//   cyclotomic squaring 2 products per pair instead of 6, sparse line products 3 (or 2) instead of 13 (or 10)
+// Work that has no six-way parallelism (the line functions on the running point, the one inversion) is executed
+// redundantly by every pair from the same inputs, which needs no data exchange at all.  Pairs 6 and 7 of a group shadow
+// pairs 0 and 1 (same loads, same stores).
+#pragma once
+#include "zkv_verify.h"
+
+#if defined(ZKV_PAIRED)
+namespace zkv {
+
+ZKV_HD int w_pow(int mi) { return mi < 3 ? 2 * mi : 2 * (mi - 3) + 1; }         // memory index -> power of w
+ZKV_HD int w_mem(int pw) { return (pw & 1) ? 3 + (pw >> 1) : (pw >> 1); }       // power of w -> memory index
+ZKV_HD Fp2 f2_sel(bool c, const Fp2& if_true, const Fp2& if_false) { Fp2 r; r.h = fp_sel(c, if_true.h, if_false.h); return r; }
+// Coefficients written by one pair are read by the others: make the stores of a routine visible to the group before the next
+// routine loads (work-group scope: the lanes share one wavefront, so this is a wait for outstanding memory operations).
+ZKV_HD void wide_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#endif
+}
+
+ZKV_HD void w12_set_one(MRef d, int q) { m_st_f2(d, q, f2_sel(q == 0, f2_one(), f2_zero())); wide_fence(); }
+ZKV_HD void w12_copy(MRef d, MRef a, int q) { m_st_f2(d, q, m_ld_f2(a, q)); wide_fence(); }
+ZKV_HD void w12_conj(MRef d, int q) {                     // in place: negate the h coefficients
+    Fp2 c = m_ld_f2(d, q);
+    m_st_f2(d, q, f2_sel(q >= 3, f2_neg(c), c));
+    wide_fence();
+}
+// d <- a * b, or a * conj(b) (d may alias a or b)
+ZKV_HD_NI void w12_mul(MRef d, MRef a, MRef b, int q, bool conj_b) {
+    const int e = w_pow(q);
+    Fp2 accn = f2_zero(), accw = f2_zero();
+    const Fp2 zero = f2_zero();
+#pragma unroll 1
+    for (int i = 0; i < 6; i++) {
+        int j = e - i;
+        if (j < 0) j += 6;
+        const bool wrap = i + j >= 6;
+        const int mj = w_mem(j);
+        Fp2 x = m_ld_f2(a, w_mem(i)), y = m_ld_f2(b, mj);
+        if (conj_b) y = f2_sel(mj >= 3, f2_neg(y), y);
+        Fp2 p = f2_mul(x, y);
+        accw = f2_add(accw, f2_sel(wrap, p, zero));
+        accn = f2_add(accn, f2_sel(wrap, zero, p));
+    }
+    m_st_f2(d, q, f2_add(accn, f2_mul_xi(accw)));
+    wide_fence();
+}
+// f <- f^2 (generic)
+ZKV_HD void w12_sqr(MRef f, int q) { w12_mul(f, f, f, q, false); }
+// f <- f^2 for f in the cyclotomic subgroup (Granger-Scott): pair q needs one Fp4 squaring (A + B y)^2, y^2 = xi.
+ZKV_HD_NI void w12_cyclo_sqr(MRef f, int q) {
+    const int ia = (q == 0 || q == 4) ? 0 : (q == 2 || q == 3) ? 1 : 3;
+    const int ib = ia == 0 ? 4 : ia == 1 ? 5 : 2;
+    const bool odd = q >= 3;                              // this pair's result uses 2AB, otherwise A^2 + xi B^2
+    Fp2 A = m_ld_f2(f, ia), B = m_ld_f2(f, ib), z = m_ld_f2(f, q);
+    Fp2 ab = f2_mul(A, B);
+    Fp2 s = f2_mul(f2_add(A, B), f2_add(f2_mul_xi(B), A));
+    Fp2 te = f2_sub(f2_sub(s, ab), f2_mul_xi(ab));
+    Fp2 T = f2_sel(odd, f2_dbl(ab), te);
+    T = f2_sel(q == 3, f2_mul_xi(T), T);
+    Fp2 u = f2_add(T, f2_sel(odd, z, f2_neg(z)));        // 3T + 2z (odd) / 3T - 2z (even)
+    m_st_f2(f, q, f2_add(f2_dbl(u), T));
+    wide_fence();
+}
+// f <- f * (c0 + c3 w + c4 w^3); with `one` the constant coefficient is 1 and c0 is not read
+ZKV_HD_NI void w12_mul_sparse(MRef f, const Fp2* c0, const Fp2* c3, const Fp2* c4, int q, bool one) {
+    const int e = w_pow(q);
+    const int e1 = e >= 1 ? e - 1 : e + 5, e3 = e >= 3 ? e - 3 : e + 3;
+    Fp2 a0 = m_ld_f2(f, q), a1 = m_ld_f2(f, w_mem(e1)), a3 = m_ld_f2(f, w_mem(e3));
+    Fp2 t = one ? a0 : f2_mul(a0, *c0);
+    Fp2 p3 = f2_mul(a1, *c3), p4 = f2_mul(a3, *c4);
+    p3 = f2_sel(e < 1, f2_mul_xi(p3), p3);
+    p4 = f2_sel(e < 3, f2_mul_xi(p4), p4);
+    m_st_f2(f, q, f2_add(f2_add(t, p3), p4));
+    wide_fence();
+}
+// d <- pi^k(a), k = 1, 2, 3
+ZKV_HD_NI void w12_frob(MRef d, MRef a, int k, int q) {
+    const Fp2C G1[6] = ZKV_FROB1;
+    const Fp G2[6] = ZKV_FROB2;
+    const Fp2C G3[6] = ZKV_FROB3;
+    const int e = w_pow(q);
+    Fp2 c = m_ld_f2(a, q);
+    if (k == 2) c = f2_mul_fp(c, G2[e]);
+    else c = f2_mul(f2_conj(c), f2_const(k == 1 ? G1[e] : G3[e]));      // the constant of power 0 is 1
+    m_st_f2(d, q, c);
+    wide_fence();
+}
+
+// ---------------------------------------------------------------- Miller loop and final exponentiation on wide slots
+ZKV_HD void fixed_line_mul_w(MRef fm, const LineAffC& L, const Fp& xs, const Fp& ys, int q) {
+    Fp2 c3 = f2_mul_fp(f2_const(L.nl), xs), c4 = f2_mul_fp(f2_const(L.c), ys);
+    w12_mul_sparse(fm, &c3, &c3, &c4, q, true);
+}
+ZKV_HD void var_line_mul_w(MRef fm, const Fp2& l0, const Fp2& l1, const Fp2& l3, const Fp& xs, const Fp& ys, int q) {
+    Fp2 c3 = f2_mul_fp(l1, xs), c4 = f2_mul_fp(l3, ys);
+    w12_mul_sparse(fm, &l0, &c3, &c4, q, false);
+}
+// Same schedule as miller_loop_m; the running point T (full-layout slot tm) is advanced redundantly by every pair.
+ZKV_HD void miller_loop_w(const VkTables& vk, uint32_t flags, const G1Norm& n, const Fp2& bx, const Fp2& by, MRef fm, MRef tm, int q) {
+    const bool do_ab = !(flags & (FL_A_INF | FL_B_INF));
+    const bool do_l = !(flags & FL_L_INF) && !vk.skip_fixed[0], do_c = !(flags & FL_C_INF) && !vk.skip_fixed[1];
+    w12_set_one(fm, q);
+    m_st_f2(tm, 0, bx); m_st_f2(tm, 1, by); m_st_f2(tm, 2, f2_one());
+    Fp2 nby = f2_neg(by);
+    Fp2 l0, l1, l3;
+    int li = 0;
+#pragma unroll 1
+    for (int i = ZKV_ATE_NAF_LEN - 2; i >= 0; i--) {
+        if (i != ZKV_ATE_NAF_LEN - 2) w12_sqr(fm, q);
+        if (do_ab) {
+            g2m_line_dbl(tm, &l0, &l1, &l3);
+            var_line_mul_w(fm, l0, l1, l3, n.axs, n.ays, q);
+        }
+        if (do_l) fixed_line_mul_w(fm, vk.lines[0][li], n.lxs, n.lys, q);
+        if (do_c) fixed_line_mul_w(fm, vk.lines[1][li], n.cxs, n.cys, q);
+        li++;
+        int d = ate_naf(i);
+        if (d != 0) {
+            if (do_ab) {
+                Fp2 qy = d > 0 ? by : nby;
+                g2m_line_add(tm, &bx, &qy, &l0, &l1, &l3);
+                var_line_mul_w(fm, l0, l1, l3, n.axs, n.ays, q);
+            }
+            if (do_l) fixed_line_mul_w(fm, vk.lines[0][li], n.lxs, n.lys, q);
+            if (do_c) fixed_line_mul_w(fm, vk.lines[1][li], n.cxs, n.cys, q);
+            li++;
+        }
+    }
+    Fp2 qx[2], qy[2];
+    g2_frob_affine(qx[0], qy[0], bx, by);
+    g2_frob2_affine(qx[1], qy[1], bx, by);
+    qy[1] = f2_neg(qy[1]);
+#pragma unroll 1
+    for (int s = 0; s < 2; s++) {
+        if (do_ab) {
+            g2m_line_add(tm, &qx[s], &qy[s], &l0, &l1, &l3);
+            var_line_mul_w(fm, l0, l1, l3, n.axs, n.ays, q);
+        }
+        if (do_l) fixed_line_mul_w(fm, vk.lines[0][li], n.lxs, n.lys, q);
+        if (do_c) fixed_line_mul_w(fm, vk.lines[1][li], n.cxs, n.cys, q);
+        li++;
+    }
+}
+// acc <- x^u, same window schedule as exp_u_m
+ZKV_HD void exp_u_w(MRef acc, MRef x, MRef W, int q) {
+    const MRef X3 = W, X5 = m_off(W, 96), X7 = m_off(W, 192);
+    w12_copy(acc, x, q); w12_cyclo_sqr(acc, q);
+    w12_mul(X3, acc, x, q, false); w12_mul(X5, X3, acc, q, false); w12_mul(X7, X5, acc, q, false);
+    w12_copy(acc, x, q);
+#pragma unroll 1
+    for (int i = ZKV_U_WNAF3_LEN - 2; i >= 0; i--) {
+        w12_cyclo_sqr(acc, q);
+        const int d = u_wnaf3(i);
+        if (d == 0) continue;
+        const int m = d < 0 ? -d : d;
+        const MRef S = m == 1 ? x : m == 3 ? X3 : m == 5 ? X5 : X7;
+        w12_mul(acc, acc, S, q, d < 0);
+    }
+}
+// Same chain as final_exp_is_one_m.  The inversion and the final comparison run redundantly on every pair.
+ZKV_HD bool final_exp_is_one_w(MRef F, MRef E, MRef Y1, MRef Y3, MRef Y4, MRef W, MRef acc, int q) {
+    w12_copy(acc, F, q); w12_conj(acc, q);
+    f12m_inv(F, F); wide_fence();
+    w12_mul(acc, acc, F, q, false);          // f^(p^6-1)
+    w12_frob(F, acc, 2, q);
+    w12_mul(E, F, acc, q, false);            // e = ^(p^2+1)
+    exp_u_w(acc, E, W, q); w12_conj(acc, q);              // y0
+    w12_cyclo_sqr(acc, q); w12_copy(Y1, acc, q);          // y1
+    w12_cyclo_sqr(acc, q);                                // y2
+    w12_mul(acc, acc, Y1, q, false); w12_copy(Y3, acc, q);        // y3
+    exp_u_w(acc, Y3, W, q); w12_conj(acc, q); w12_copy(Y4, acc, q);   // y4
+    w12_cyclo_sqr(acc, q); w12_copy(F, acc, q);           // y5
+    exp_u_w(acc, F, W, q);                                // y6
+    w12_conj(Y3, q);
+    w12_mul(acc, acc, Y4, q, false);                      // y7
+    w12_mul(acc, acc, Y3, q, false); w12_copy(Y3, acc, q);        // y8
+    w12_mul(F, acc, Y1, q, false);                        // y9
+    w12_mul(acc, acc, Y4, q, false);                      // y10
+    w12_mul(acc, acc, E, q, false);                       // y11
+    w12_frob(Y1, F, 1, q);
+    w12_mul(acc, Y1, acc, q, false);                      // y13
+    w12_frob(Y3, Y3, 2, q);
+    w12_mul(acc, Y3, acc, q, false);                      // y14
+    w12_conj(E, q);
+    w12_mul(E, E, F, q, false);
+    w12_frob(E, E, 3, q);                                 // y15
+    w12_mul(acc, E, acc, q, false);
+    return f12m_is_one(acc);
+}
+
+}  // namespace zkv
+#endif  // ZKV_PAIRED

@@ -719,3 +719,39 @@ def test_device_calldata_with_corrupt_offsets_is_never_read(zkv, r0, real_proofs
     zkv.wire.eth_call_batch_dev(r0, n, d_cd.data_ptr(), d_off.data_ptr(), blob.size, d_st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert list(d_st.cpu().numpy()) == [0, 6, 6, 0, 6, 6]
+
+
+def test_sixteen_lanes_per_proof_kernels_match_the_oracle(zkv, real_proofs, verify_corpus):
+    """The small-batch kernels (one proof per 16 lanes, coefficient-parallel Fp12 arithmetic, csrc/zkv_tower_wide.h) against the
+    golden corpus, the oracle on a seeded batch with every mutation class (partial last wavefront: 4 proofs per wave), and the
+    lane-pair kernels on the same inputs; the automatic choice (small chunks -> 16 lanes) returns the same bytes."""
+    import oracle_lib as ol
+    from stylus_zkvm_verifiers_amd import synth
+    r, s = real_proofs['risc0'], real_proofs['sp1']
+    rc = [c for c in verify_corpus['cases'] if c['vm'] == 'risc0']
+    sc = [c for c in verify_corpus['cases'] if c['vm'] == 'sp1']
+    n = 301
+    seals, mut, mclass, flip = synth.make_batch('risc0', H(r['seal']), n, 0x5A4B56C1, pool=4, mutate_every=4)
+    ids = [H(r['image_id'])] * n
+    jds = [H(r['journal_digest']) if not f else bytes([H(r['journal_digest'])[0] ^ 1]) + H(r['journal_digest'])[1:] for f in flip]
+    orc = ol.Risc0Oracle(); orc.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    want, _ = orc.verify_batch([x.tobytes() for x in seals], ids, jds, threads=8)
+    proofs, smut, _, sflip = synth.make_batch('sp1', H(s['proof']), n, 0x5A4B56C2, pool=4, mutate_every=4)
+    pvs = [H(s['public_values']) if not f else H(s['public_values'])[:-1] + bytes([H(s['public_values'])[-1] ^ 1]) for f in sflip]
+    swant, _ = ol.sp1_verify_batch([H(s['vkey'])] * n, pvs, [x.tobytes() for x in proofs], threads=8)
+    got = {}
+    for lanes in (16, 2, 0):
+        v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id'])); v.set_lanes_per_proof(lanes)
+        st, rv = v.verify_batch([H(c['seal']) for c in rc], [H(c['image_id']) for c in rc], [H(c['journal_digest']) for c in rc])
+        assert [int(x) for x in st] == [c['status'] for c in rc], lanes
+        st, _ = v.verify_batch([x.tobytes() for x in seals], ids, jds)
+        assert (st == want).all(), lanes
+        sp = zkv.Sp1Verifier(); sp.set_lanes_per_proof(lanes)
+        st2, _ = sp.verify_batch([H(c['vkey']) for c in sc], [H(c['public_values']) for c in sc], [H(c['proof']) for c in sc])
+        assert [int(x) for x in st2] == [c['status'] for c in sc], lanes
+        st3, _ = sp.verify_batch([H(s['vkey'])] * n, pvs, [x.tobytes() for x in proofs])
+        assert (st3 == swant).all(), lanes
+        got[lanes] = (st.tobytes(), st3.tobytes(), v.last_stage_ms())
+        v.close(); sp.close()
+    assert got[16][:2] == got[2][:2] == got[0][:2]
+    assert ((want == 0) == ~mut).all() and ((swant == 0) == ~smut).all()

@@ -1,0 +1,19 @@
+import os, sys, json, time
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/oracle')
+import numpy as np
+import stylus_zkvm_verifiers_amd as z
+import oracle_lib as ol
+H = bytes.fromhex
+g = json.load(open('/root/repo/tests/golden/real_proofs.json')); corpus = json.load(open('/root/repo/tests/golden/verify_corpus.json'))
+r = g['risc0']
+v = z.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+rc = [c for c in corpus['cases'] if c['vm'] == 'risc0']
+st, _ = v.verify_batch([H(c['seal']) for c in rc], [H(c['image_id']) for c in rc], [H(c['journal_digest']) for c in rc])
+bad = [(c['name'], int(s), c['status']) for c, s in zip(rc, st) if int(s) != c['status']]
+print('risc0 corpus mismatches:', bad[:10], 'of', len(rc), 'stage ms', v.last_stage_ms())
+sc = [c for c in corpus['cases'] if c['vm'] == 'sp1']
+sp = z.Sp1Verifier()
+st, _ = sp.verify_batch([H(c['vkey']) for c in sc], [H(c['public_values']) for c in sc], [H(c['proof']) for c in sc])
+bad = [(c['name'], int(s), c['status']) for c, s in zip(sc, st) if int(s) != c['status']]
+print('sp1 corpus mismatches:', bad[:10], 'of', len(sc), 'stage ms', sp.last_stage_ms())
+t0 = time.time(); ok = v.verify(H(r['seal']), H(r['image_id']), H(r['journal_digest'])); print('single verify', ok, (time.time() - t0) * 1e3, 'ms', v.last_stage_ms())
