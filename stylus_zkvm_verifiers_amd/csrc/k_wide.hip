@@ -26,7 +26,7 @@ __device__ __forceinline__ Fp2 ld_b_w(const Workspace& ws, int word0, size_t i, 
     return r;
 }
 
-__global__ __launch_bounds__(ZKV_BLOCK) void k_miller_w(size_t n, const VkTables* __restrict__ vk, Workspace ws) {
+__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller_w(size_t n, const VkTables* __restrict__ vk, Workspace ws) {
     __shared__ uint32_t lds[WIDE_PER_BLOCK * (96 + 48)];  // per proof: f (6 Fp2) and T (3 Fp2), both components
     const WideLane w = wide_lane();
     if (w.i >= n) return;
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_miller_w(size_t n, const VkTables
     w12_mul(out, fm, ab, w.q, false);
 }
 
-__global__ __launch_bounds__(ZKV_BLOCK) void k_finalexp_w(size_t n, Workspace ws, uint8_t* __restrict__ status) {
+__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_finalexp_w(size_t n, Workspace ws, uint8_t* __restrict__ status) {
     __shared__ uint32_t lds[WIDE_PER_BLOCK * 96];
     const WideLane w = wide_lane();
     if (w.i >= n) return;

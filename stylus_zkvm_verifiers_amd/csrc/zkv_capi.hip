@@ -67,12 +67,12 @@ static int lanes_per_proof() {
     return v;
 }
 
-// Chunks of at most this many proofs take the coefficient-parallel kernels (one proof per 16 lanes): 4,096 proofs are one
-// wavefront per SIMD, below that the lane-pair kernels leave most of the chip idle and only the latency of a proof matters
-// (6.7 ms against 12.4 ms).  ZKV_WIDE_BELOW=0 disables them.
+// Chunks of at most this many proofs take the coefficient-parallel kernels (one proof per 16 lanes).  Measured on 2^9 ... 2^14
+// proofs: 6.0-6.3 ms against 11.6 ms up to 4,096 proofs (one wavefront per SIMD), 8.8 against 11.7 ms at 8,192, break-even
+// near 12,000; above that the lane-pair kernels win because they do a third of the work per proof.  ZKV_WIDE_BELOW=0 disables.
 static size_t wide_below() {
     const char* e = getenv("ZKV_WIDE_BELOW");
-    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)4096;
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)8192;
 }
 
 static bool device_is_gfx950(int dev) {
