@@ -27,7 +27,8 @@ __device__ __forceinline__ Fp2 ld_b_w(const Workspace& ws, int word0, size_t i, 
 }
 
 __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller_w(size_t n, const VkTables* __restrict__ vk, Workspace ws) {
-    __shared__ uint32_t lds[WIDE_PER_BLOCK * (96 + 48)];  // per proof: f (6 Fp2) and T (3 Fp2), both components
+    constexpr int SLOT = 96 + 48 + 13 * 16;                // per proof: f (6 Fp2), T (3 Fp2), 13 scratch Fp2, both components
+    __shared__ uint32_t lds[WIDE_PER_BLOCK * SLOT];
     const WideLane w = wide_lane();
     if (w.i >= n) return;
     const uint32_t flags = ws.flags[w.i];
@@ -37,9 +38,9 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller_w(size_t n, const VkTab
     nm.lxs = ws_ld(ws.norm, ws.cap, 16, w.i); nm.lys = ws_ld(ws.norm, ws.cap, 24, w.i);
     nm.cxs = ws_ld(ws.norm, ws.cap, 32, w.i); nm.cys = ws_ld(ws.norm, ws.cap, 40, w.i);
     Fp2 bx = ld_b_w(ws, 32, w.i, w.half), by = ld_b_w(ws, 48, w.i, w.half);
-    uint32_t* base = lds + w.g * (96 + 48) + 8 * w.half;
-    MRef fm = m_ref(base, 1, 16), tm = m_ref(base + 96, 1, 16);
-    miller_loop_w(*vk, flags, nm, bx, by, fm, tm, w.q);
+    uint32_t* base = lds + w.g * SLOT + 8 * w.half;
+    MRef fm = m_ref(base, 1, 16), tm = m_ref(base + 96, 1, 16), sc = m_ref(base + 144, 1, 16);
+    miller_loop_w(*vk, flags, nm, bx, by, fm, tm, sc, w.q);
     MRef ab = m_ref((uint32_t*)(vk->f_alpha_beta) + 8 * w.half, 1, 16);
     MRef out = m_ref(ws.f + (size_t)(8 * w.half) * ws.cap + w.i, (uint32_t)ws.cap, 16);
     w12_mul(out, fm, ab, w.q, false);

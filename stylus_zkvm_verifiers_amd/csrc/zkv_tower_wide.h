@@ -10,8 +10,8 @@
 // routine is issued before any of its stores and no barrier is needed.
 //   multiplication      c_e = sum_i a_i b_(e-i) xi^[i + (e-i) mod 6 >= 6]   6 Fp2 products per pair instead of 18 in sequence
 //   cyclotomic squaring 2 products per pair instead of 6, sparse line products 3 (or 2) instead of 13 (or 10)
-// Work that has no six-way parallelism (the line functions on the running point, the one inversion) is executed
-// redundantly by every pair from the same inputs, which needs no data exchange at all.  Pairs 6 and 7 of a group shadow
+// The line functions spread their independent products over the pairs round by round; the one inversion of the final
+// exponentiation is executed redundantly by every pair from the same inputs, which needs no data exchange at all.  Pairs 6 and 7 of a group shadow
 // pairs 0 and 1 (same loads, same stores).
 #pragma once
 #include "zkv_verify.h"
@@ -57,8 +57,26 @@ ZKV_HD_NI void w12_mul(MRef d, MRef a, MRef b, int q, bool conj_b) {
     m_st_f2(d, q, f2_add(accn, f2_mul_xi(accw)));
     wide_fence();
 }
-// f <- f^2 (generic)
-ZKV_HD void w12_sqr(MRef f, int q) { w12_mul(f, f, f, q, false); }
+// f <- f^2 (generic): c_e = sum over unordered {i, j}, i + j = e mod 6, of a_i a_j (twice when i != j): at most four products per
+// pair.  Table entry = i | j << 3 | doubled << 6 | wrapped << 7 | valid << 8 for output power e, term t (index 4 e + t).
+ZKV_HD_NI void w12_sqr(MRef f, int q) {
+    const uint16_t TERMS[24] = {256, 489, 482, 411, 328, 490, 483, 0, 336, 265, 491, 420, 344, 337, 492, 0, 352, 345, 274, 429, 360, 353, 346, 0};
+    const int e = w_pow(q);
+    Fp2 accn = f2_zero(), accw = f2_zero();
+    const Fp2 zero = f2_zero();
+#pragma unroll 1
+    for (int t = 0; t < 4; t++) {
+        const uint32_t w = TERMS[4 * e + t];
+        Fp2 p = f2_mul(m_ld_f2(f, w_mem((int)(w & 7u))), m_ld_f2(f, w_mem((int)((w >> 3) & 7u))));
+        p = f2_sel(((w >> 6) & 1u) != 0, f2_dbl(p), p);
+        p = f2_sel(((w >> 8) & 1u) != 0, p, zero);
+        const bool wrap = ((w >> 7) & 1u) != 0;
+        accw = f2_add(accw, f2_sel(wrap, p, zero));
+        accn = f2_add(accn, f2_sel(wrap, zero, p));
+    }
+    m_st_f2(f, q, f2_add(accn, f2_mul_xi(accw)));
+    wide_fence();
+}
 // f <- f^2 for f in the cyclotomic subgroup (Granger-Scott): pair q needs one Fp4 squaring (A + B y)^2, y^2 = xi.
 ZKV_HD_NI void w12_cyclo_sqr(MRef f, int q) {
     const int ia = (q == 0 || q == 4) ? 0 : (q == 2 || q == 3) ? 1 : 3;
@@ -99,6 +117,79 @@ ZKV_HD_NI void w12_frob(MRef d, MRef a, int k, int q) {
     wide_fence();
 }
 
+// ---------------------------------------------------------------- line functions, products spread over the pairs
+// Same formulas as line_dbl / line_add (zkv_curve.h).  Each round every pair forms ONE of the independent Fp2 products of
+// that round (its two operands picked with selects, so the instruction stream stays uniform), parks it in the group's
+// scratch slots `sc` (full layout, 13 Fp2) and after the fence every pair reads what it needs; the few additions in between
+// are cheap and done redundantly.  3 rounds instead of 10 products in sequence for the tangent, 4 instead of 13 for the chord.
+ZKV_HD Fp2 w_pick4(int r, const Fp2& a0, const Fp2& a1, const Fp2& a2, const Fp2& a3) {
+    return f2_sel(r == 0, a0, f2_sel(r == 1, a1, f2_sel(r == 2, a2, a3)));
+}
+ZKV_HD_NI void w_line_dbl(MRef Tm, MRef sc, Fp2* l0, Fp2* l1, Fp2* l3, int q) {
+    const Fp2C b3c = ZKV_TWIST_3B;
+    const Fp2 b3 = f2_const(b3c);
+    const Fp2 x = m_ld_f2(Tm, 0), y = m_ld_f2(Tm, 1), z = m_ld_f2(Tm, 2);
+    {   // round 1: x y | y^2 | z^2 | (y+z)^2 | x^2 (pair 5 repeats pair 4)
+        const Fp2 yz = f2_add(y, z);
+        const int r = q > 4 ? 4 : q;
+        const Fp2 A = f2_sel(r == 4, x, w_pick4(r, x, y, z, yz));
+        const Fp2 B = f2_sel(r == 4, x, w_pick4(r, y, y, z, yz));
+        m_st_f2(sc, r, f2_mul(A, B));
+        wide_fence();
+    }
+    const Fp2 a = f2_half(m_ld_f2(sc, 0)), b = m_ld_f2(sc, 1), c = m_ld_f2(sc, 2), j = m_ld_f2(sc, 4);
+    const Fp2 h = f2_sub(m_ld_f2(sc, 3), f2_add(b, c));                      // 2YZ
+    {   // round 2: e = 3b' Z^2 | Tz = b h
+        const int r = q & 1;
+        m_st_f2(sc, 5 + r, f2_mul(f2_sel(r == 1, b, b3), f2_sel(r == 1, h, c)));
+        wide_fence();
+    }
+    const Fp2 e = m_ld_f2(sc, 5), tz = m_ld_f2(sc, 6);
+    const Fp2 f = f2_add(f2_dbl(e), e);                                      // 9 b' Z^2
+    const Fp2 g = f2_half(f2_add(b, f));
+    {   // round 3: e^2 | g^2 | a (b - f)
+        const int r = q % 3;
+        const Fp2 bf = f2_sub(b, f);
+        m_st_f2(sc, 7 + r, f2_mul(f2_sel(r == 0, e, f2_sel(r == 1, g, a)), f2_sel(r == 0, e, f2_sel(r == 1, g, bf))));
+        wide_fence();
+    }
+    const Fp2 e2 = m_ld_f2(sc, 7), g2 = m_ld_f2(sc, 8), tx = m_ld_f2(sc, 9);
+    *l0 = f2_neg(h); *l1 = f2_add(f2_dbl(j), j); *l3 = f2_sub(e, b);
+    m_st_f2(Tm, 0, tx); m_st_f2(Tm, 1, f2_sub(g2, f2_add(f2_dbl(e2), e2))); m_st_f2(Tm, 2, tz);
+    wide_fence();
+}
+ZKV_HD_NI void w_line_add(MRef Tm, MRef sc, const Fp2* qx, const Fp2* qy, Fp2* l0, Fp2* l1, Fp2* l3, int q) {
+    const Fp2 x = m_ld_f2(Tm, 0), y = m_ld_f2(Tm, 1), z = m_ld_f2(Tm, 2);
+    {   // round 1: qy Z | qx Z
+        const int r = q & 1;
+        m_st_f2(sc, r, f2_mul(f2_sel(r == 1, *qx, *qy), z));
+        wide_fence();
+    }
+    const Fp2 theta = f2_sub(y, m_ld_f2(sc, 0)), lambda = f2_sub(x, m_ld_f2(sc, 1));
+    {   // round 2: theta^2 | lambda^2 | theta qx | lambda qy
+        const int r = q & 3;
+        m_st_f2(sc, 2 + r, f2_mul(f2_sel((r & 1) == 0, theta, lambda), w_pick4(r, theta, lambda, *qx, *qy)));
+        wide_fence();
+    }
+    const Fp2 c = m_ld_f2(sc, 2), d = m_ld_f2(sc, 3);
+    *l3 = f2_sub(m_ld_f2(sc, 4), m_ld_f2(sc, 5));
+    {   // round 3: e = lambda d | f = Z c | g = X d
+        const int r = q % 3;
+        m_st_f2(sc, 6 + r, f2_mul(f2_sel(r == 0, lambda, f2_sel(r == 1, z, x)), f2_sel(r == 1, c, d)));
+        wide_fence();
+    }
+    const Fp2 e = m_ld_f2(sc, 6), g = m_ld_f2(sc, 8);
+    const Fp2 h = f2_sub(f2_add(e, m_ld_f2(sc, 7)), f2_dbl(g));
+    {   // round 4: lambda h | theta (g - h) | e Y | Z e
+        const int r = q & 3;
+        m_st_f2(sc, 9 + r, f2_mul(w_pick4(r, lambda, theta, e, z), w_pick4(r, h, f2_sub(g, h), y, e)));
+        wide_fence();
+    }
+    *l0 = lambda; *l1 = f2_neg(theta);
+    m_st_f2(Tm, 0, m_ld_f2(sc, 9)); m_st_f2(Tm, 1, f2_sub(m_ld_f2(sc, 10), m_ld_f2(sc, 11))); m_st_f2(Tm, 2, m_ld_f2(sc, 12));
+    wide_fence();
+}
+
 // ---------------------------------------------------------------- Miller loop and final exponentiation on wide slots
 ZKV_HD void fixed_line_mul_w(MRef fm, const LineAffC& L, const Fp& xs, const Fp& ys, int q) {
     Fp2 c3 = f2_mul_fp(f2_const(L.nl), xs), c4 = f2_mul_fp(f2_const(L.c), ys);
@@ -108,8 +199,8 @@ ZKV_HD void var_line_mul_w(MRef fm, const Fp2& l0, const Fp2& l1, const Fp2& l3,
     Fp2 c3 = f2_mul_fp(l1, xs), c4 = f2_mul_fp(l3, ys);
     w12_mul_sparse(fm, &l0, &c3, &c4, q, false);
 }
-// Same schedule as miller_loop_m; the running point T (full-layout slot tm) is advanced redundantly by every pair.
-ZKV_HD void miller_loop_w(const VkTables& vk, uint32_t flags, const G1Norm& n, const Fp2& bx, const Fp2& by, MRef fm, MRef tm, int q) {
+// Same schedule as miller_loop_m; the running point T lives in the full-layout slot tm, `sc` is the line functions' scratch.
+ZKV_HD void miller_loop_w(const VkTables& vk, uint32_t flags, const G1Norm& n, const Fp2& bx, const Fp2& by, MRef fm, MRef tm, MRef sc, int q) {
     const bool do_ab = !(flags & (FL_A_INF | FL_B_INF));
     const bool do_l = !(flags & FL_L_INF) && !vk.skip_fixed[0], do_c = !(flags & FL_C_INF) && !vk.skip_fixed[1];
     w12_set_one(fm, q);
@@ -121,7 +212,7 @@ ZKV_HD void miller_loop_w(const VkTables& vk, uint32_t flags, const G1Norm& n, c
     for (int i = ZKV_ATE_NAF_LEN - 2; i >= 0; i--) {
         if (i != ZKV_ATE_NAF_LEN - 2) w12_sqr(fm, q);
         if (do_ab) {
-            g2m_line_dbl(tm, &l0, &l1, &l3);
+            w_line_dbl(tm, sc, &l0, &l1, &l3, q);
             var_line_mul_w(fm, l0, l1, l3, n.axs, n.ays, q);
         }
         if (do_l) fixed_line_mul_w(fm, vk.lines[0][li], n.lxs, n.lys, q);
@@ -131,7 +222,7 @@ ZKV_HD void miller_loop_w(const VkTables& vk, uint32_t flags, const G1Norm& n, c
         if (d != 0) {
             if (do_ab) {
                 Fp2 qy = d > 0 ? by : nby;
-                g2m_line_add(tm, &bx, &qy, &l0, &l1, &l3);
+                w_line_add(tm, sc, &bx, &qy, &l0, &l1, &l3, q);
                 var_line_mul_w(fm, l0, l1, l3, n.axs, n.ays, q);
             }
             if (do_l) fixed_line_mul_w(fm, vk.lines[0][li], n.lxs, n.lys, q);
@@ -146,7 +237,7 @@ ZKV_HD void miller_loop_w(const VkTables& vk, uint32_t flags, const G1Norm& n, c
 #pragma unroll 1
     for (int s = 0; s < 2; s++) {
         if (do_ab) {
-            g2m_line_add(tm, &qx[s], &qy[s], &l0, &l1, &l3);
+            w_line_add(tm, sc, &qx[s], &qy[s], &l0, &l1, &l3, q);
             var_line_mul_w(fm, l0, l1, l3, n.axs, n.ays, q);
         }
         if (do_l) fixed_line_mul_w(fm, vk.lines[0][li], n.lxs, n.lys, q);
