@@ -1,10 +1,14 @@
+#!/usr/bin/env python3
+"""Small-batch probe: the golden corpus and one single verification through the C ABI, with the per-stage HIP-event times.
+Run it with ZKV_WIDE_BELOW=0 and without to compare the lane-pair kernels with the 16-lanes-per-proof kernels."""
 import os, sys, json, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/oracle')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import numpy as np
 import stylus_zkvm_verifiers_amd as z
 import oracle_lib as ol
 H = bytes.fromhex
-g = json.load(open('/root/repo/tests/golden/real_proofs.json')); corpus = json.load(open('/root/repo/tests/golden/verify_corpus.json'))
+g = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'real_proofs.json'))); corpus = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'verify_corpus.json')))
 r = g['risc0']
 v = z.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
 rc = [c for c in corpus['cases'] if c['vm'] == 'risc0']
