@@ -204,7 +204,7 @@ int zkv_ctx_vk_x_batch(zkv_ctx* ctx, size_t n, const uint8_t* var_signals, uint8
 int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_* */
 /* Tuning knob (no reference counterpart): kernel mapping of the G2 / Miller / final-exponentiation stages.
  * 0 = automatic (default): one proof per pair of lanes, and for chunks of at most ZKV_WIDE_BELOW proofs (environment,
- * default 8192) one proof per 16 lanes, which halves the latency of a small batch; 2 = always lane pairs; 16 = always
+ * default 12288) one proof per 16 lanes, which halves the latency of a small batch; 2 = always lane pairs; 16 = always
  * 16 lanes per proof; 1 = one proof per lane (A/B reference).  Results are identical. */
 int zkv_ctx_set_lanes_per_proof(zkv_ctx* ctx, int lanes);
 /* Blocks until everything enqueued on the context's stream has finished. */

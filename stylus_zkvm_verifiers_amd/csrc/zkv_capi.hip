@@ -67,12 +67,13 @@ static int lanes_per_proof() {
     return v;
 }
 
-// Chunks of at most this many proofs take the coefficient-parallel kernels (one proof per 16 lanes).  Measured on 2^9 ... 2^14
-// proofs: 6.0-6.3 ms against 11.6 ms up to 4,096 proofs (one wavefront per SIMD), 8.8 against 11.7 ms at 8,192, break-even
-// near 12,000; above that the lane-pair kernels win because they do a third of the work per proof.  ZKV_WIDE_BELOW=0 disables.
+// Chunks of at most this many proofs take the coefficient-parallel kernels (one proof per 16 lanes).  Measured: 5.3-5.6 ms
+// against 11.6 ms up to 4,096 proofs (one wavefront per SIMD), 7.7 against 11.7 ms at 8,192, 10.8 against 11.9 ms at 12,288,
+// 13.2 against 11.9 ms at 16,384: above the threshold the lane-pair kernels win because they do a third of the work per proof.
+// ZKV_WIDE_BELOW=0 disables the 16-lane kernels.
 static size_t wide_below() {
     const char* e = getenv("ZKV_WIDE_BELOW");
-    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)8192;
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)12288;
 }
 
 static bool device_is_gfx950(int dev) {
