@@ -755,3 +755,31 @@ def test_sixteen_lanes_per_proof_kernels_match_the_oracle(zkv, real_proofs, veri
         v.close(); sp.close()
     assert got[16][:2] == got[2][:2] == got[0][:2]
     assert ((want == 0) == ~mut).all() and ((swant == 0) == ~smut).all()
+
+
+def test_last_small_chunk_switches_kernels_inside_one_batch(zkv, real_proofs):
+    """A batch of 16,384 + 300 proofs on a context with 16,384-proof chunks: the first chunk runs on the lane-pair kernels, the
+    300-proof remainder on the 16-lane kernels; statuses must equal the base batch they were tiled from."""
+    import torch
+    from stylus_zkvm_verifiers_amd import synth
+    dev = torch.device('cuda', 0)
+    r = real_proofs['risc0']
+    nb = 1024
+    seals, mut, _, flip = synth.make_batch('risc0', H(r['seal']), nb, 0x5A4B56D1, pool=4, mutate_every=6)
+    ids = np.tile(np.frombuffer(H(r['image_id']), dtype=np.uint8), (nb, 1))
+    jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (nb, 1)); jds[flip, 0] ^= 1
+    os.environ['ZKV_CHUNK'] = '16384'
+    try:
+        v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+        n = 16384 + 300
+        src = np.random.default_rng(0x5A4B56D2).integers(0, nb, n)
+        d = [torch.from_numpy(np.ascontiguousarray(x[src])).to(dev) for x in (seals, ids, jds)]
+        d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+        v.verify_batch_dev(n, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d_st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        st = d_st.cpu().numpy()
+        v.close()
+    finally:
+        os.environ.pop('ZKV_CHUNK', None)
+    assert ((st == 0) == ~mut[src]).all()
+    assert len(set(st[16384:])) >= 2                             # the remainder holds accepted and rejected proofs
