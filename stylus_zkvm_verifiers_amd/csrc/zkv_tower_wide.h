@@ -24,16 +24,29 @@ ZKV_HD int w_mem(int pw) { return (pw & 1) ? 3 + (pw >> 1) : (pw >> 1); }       
 ZKV_HD Fp2 f2_sel(bool c, const Fp2& if_true, const Fp2& if_false) { Fp2 r; r.h = fp_sel(c, if_true.h, if_false.h); return r; }
 // Coefficients written by one pair are read by the others: make the stores of a routine visible to the group before the next
 // routine loads (work-group scope: the lanes share one wavefront, so this is a wait for outstanding memory operations).
+#if !defined(__HIP_DEVICE_COMPILE__)
+void zkv_wide_host_barrier();           // host emulation (tests/host_sim): the lanes of a group are threads
+#endif
 ZKV_HD void wide_fence() {
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#else
+    zkv_wide_host_barrier();
+#endif
+}
+// On the device the lanes of a group run in lockstep, so every load of a routine has been issued when the first store is;
+// the host emulation needs a rendezvous at that point.
+ZKV_HD void wide_sync() {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    zkv_wide_host_barrier();
 #endif
 }
 
-ZKV_HD void w12_set_one(MRef d, int q) { m_st_f2(d, q, f2_sel(q == 0, f2_one(), f2_zero())); wide_fence(); }
-ZKV_HD void w12_copy(MRef d, MRef a, int q) { m_st_f2(d, q, m_ld_f2(a, q)); wide_fence(); }
+ZKV_HD void w12_set_one(MRef d, int q) { wide_sync(); m_st_f2(d, q, f2_sel(q == 0, f2_one(), f2_zero())); wide_fence(); }
+ZKV_HD void w12_copy(MRef d, MRef a, int q) { Fp2 c = m_ld_f2(a, q); wide_sync(); m_st_f2(d, q, c); wide_fence(); }
 ZKV_HD void w12_conj(MRef d, int q) {                     // in place: negate the h coefficients
     Fp2 c = m_ld_f2(d, q);
+    wide_sync();
     m_st_f2(d, q, f2_sel(q >= 3, f2_neg(c), c));
     wide_fence();
 }
@@ -54,6 +67,7 @@ ZKV_HD_NI void w12_mul(MRef d, MRef a, MRef b, int q, bool conj_b) {
         accw = f2_add(accw, f2_sel(wrap, p, zero));
         accn = f2_add(accn, f2_sel(wrap, zero, p));
     }
+    wide_sync();
     m_st_f2(d, q, f2_add(accn, f2_mul_xi(accw)));
     wide_fence();
 }
@@ -74,6 +88,7 @@ ZKV_HD_NI void w12_sqr(MRef f, int q) {
         accw = f2_add(accw, f2_sel(wrap, p, zero));
         accn = f2_add(accn, f2_sel(wrap, zero, p));
     }
+    wide_sync();
     m_st_f2(f, q, f2_add(accn, f2_mul_xi(accw)));
     wide_fence();
 }
@@ -89,6 +104,7 @@ ZKV_HD_NI void w12_cyclo_sqr(MRef f, int q) {
     Fp2 T = f2_sel(odd, f2_dbl(ab), te);
     T = f2_sel(q == 3, f2_mul_xi(T), T);
     Fp2 u = f2_add(T, f2_sel(odd, z, f2_neg(z)));        // 3T + 2z (odd) / 3T - 2z (even)
+    wide_sync();
     m_st_f2(f, q, f2_add(f2_dbl(u), T));
     wide_fence();
 }
@@ -101,6 +117,7 @@ ZKV_HD_NI void w12_mul_sparse(MRef f, const Fp2* c0, const Fp2* c3, const Fp2* c
     Fp2 p3 = f2_mul(a1, *c3), p4 = f2_mul(a3, *c4);
     p3 = f2_sel(e < 1, f2_mul_xi(p3), p3);
     p4 = f2_sel(e < 3, f2_mul_xi(p4), p4);
+    wide_sync();
     m_st_f2(f, q, f2_add(f2_add(t, p3), p4));
     wide_fence();
 }
@@ -113,6 +130,7 @@ ZKV_HD_NI void w12_frob(MRef d, MRef a, int k, int q) {
     Fp2 c = m_ld_f2(a, q);
     if (k == 2) c = f2_mul_fp(c, G2[e]);
     else c = f2_mul(f2_conj(c), f2_const(k == 1 ? G1[e] : G3[e]));      // the constant of power 0 is 1
+    wide_sync();
     m_st_f2(d, q, c);
     wide_fence();
 }
@@ -134,14 +152,18 @@ ZKV_HD_NI void w_line_dbl(MRef Tm, MRef sc, Fp2* l0, Fp2* l1, Fp2* l3, int q) {
         const int r = q > 4 ? 4 : q;
         const Fp2 A = f2_sel(r == 4, x, w_pick4(r, x, y, z, yz));
         const Fp2 B = f2_sel(r == 4, x, w_pick4(r, y, y, z, yz));
-        m_st_f2(sc, r, f2_mul(A, B));
+        const Fp2 p = f2_mul(A, B);
+        wide_sync();
+        m_st_f2(sc, r, p);
         wide_fence();
     }
     const Fp2 a = f2_half(m_ld_f2(sc, 0)), b = m_ld_f2(sc, 1), c = m_ld_f2(sc, 2), j = m_ld_f2(sc, 4);
     const Fp2 h = f2_sub(m_ld_f2(sc, 3), f2_add(b, c));                      // 2YZ
     {   // round 2: e = 3b' Z^2 | Tz = b h
         const int r = q & 1;
-        m_st_f2(sc, 5 + r, f2_mul(f2_sel(r == 1, b, b3), f2_sel(r == 1, h, c)));
+        const Fp2 p = f2_mul(f2_sel(r == 1, b, b3), f2_sel(r == 1, h, c));
+        wide_sync();
+        m_st_f2(sc, 5 + r, p);
         wide_fence();
     }
     const Fp2 e = m_ld_f2(sc, 5), tz = m_ld_f2(sc, 6);
@@ -150,11 +172,14 @@ ZKV_HD_NI void w_line_dbl(MRef Tm, MRef sc, Fp2* l0, Fp2* l1, Fp2* l3, int q) {
     {   // round 3: e^2 | g^2 | a (b - f)
         const int r = q % 3;
         const Fp2 bf = f2_sub(b, f);
-        m_st_f2(sc, 7 + r, f2_mul(f2_sel(r == 0, e, f2_sel(r == 1, g, a)), f2_sel(r == 0, e, f2_sel(r == 1, g, bf))));
+        const Fp2 p = f2_mul(f2_sel(r == 0, e, f2_sel(r == 1, g, a)), f2_sel(r == 0, e, f2_sel(r == 1, g, bf)));
+        wide_sync();
+        m_st_f2(sc, 7 + r, p);
         wide_fence();
     }
     const Fp2 e2 = m_ld_f2(sc, 7), g2 = m_ld_f2(sc, 8), tx = m_ld_f2(sc, 9);
     *l0 = f2_neg(h); *l1 = f2_add(f2_dbl(j), j); *l3 = f2_sub(e, b);
+    wide_sync();
     m_st_f2(Tm, 0, tx); m_st_f2(Tm, 1, f2_sub(g2, f2_add(f2_dbl(e2), e2))); m_st_f2(Tm, 2, tz);
     wide_fence();
 }
@@ -162,31 +187,41 @@ ZKV_HD_NI void w_line_add(MRef Tm, MRef sc, const Fp2* qx, const Fp2* qy, Fp2* l
     const Fp2 x = m_ld_f2(Tm, 0), y = m_ld_f2(Tm, 1), z = m_ld_f2(Tm, 2);
     {   // round 1: qy Z | qx Z
         const int r = q & 1;
-        m_st_f2(sc, r, f2_mul(f2_sel(r == 1, *qx, *qy), z));
+        const Fp2 p = f2_mul(f2_sel(r == 1, *qx, *qy), z);
+        wide_sync();
+        m_st_f2(sc, r, p);
         wide_fence();
     }
     const Fp2 theta = f2_sub(y, m_ld_f2(sc, 0)), lambda = f2_sub(x, m_ld_f2(sc, 1));
     {   // round 2: theta^2 | lambda^2 | theta qx | lambda qy
         const int r = q & 3;
-        m_st_f2(sc, 2 + r, f2_mul(f2_sel((r & 1) == 0, theta, lambda), w_pick4(r, theta, lambda, *qx, *qy)));
+        const Fp2 p = f2_mul(f2_sel((r & 1) == 0, theta, lambda), w_pick4(r, theta, lambda, *qx, *qy));
+        wide_sync();
+        m_st_f2(sc, 2 + r, p);
         wide_fence();
     }
     const Fp2 c = m_ld_f2(sc, 2), d = m_ld_f2(sc, 3);
     *l3 = f2_sub(m_ld_f2(sc, 4), m_ld_f2(sc, 5));
     {   // round 3: e = lambda d | f = Z c | g = X d
         const int r = q % 3;
-        m_st_f2(sc, 6 + r, f2_mul(f2_sel(r == 0, lambda, f2_sel(r == 1, z, x)), f2_sel(r == 1, c, d)));
+        const Fp2 p = f2_mul(f2_sel(r == 0, lambda, f2_sel(r == 1, z, x)), f2_sel(r == 1, c, d));
+        wide_sync();
+        m_st_f2(sc, 6 + r, p);
         wide_fence();
     }
     const Fp2 e = m_ld_f2(sc, 6), g = m_ld_f2(sc, 8);
     const Fp2 h = f2_sub(f2_add(e, m_ld_f2(sc, 7)), f2_dbl(g));
     {   // round 4: lambda h | theta (g - h) | e Y | Z e
         const int r = q & 3;
-        m_st_f2(sc, 9 + r, f2_mul(w_pick4(r, lambda, theta, e, z), w_pick4(r, h, f2_sub(g, h), y, e)));
+        const Fp2 p = f2_mul(w_pick4(r, lambda, theta, e, z), w_pick4(r, h, f2_sub(g, h), y, e));
+        wide_sync();
+        m_st_f2(sc, 9 + r, p);
         wide_fence();
     }
     *l0 = lambda; *l1 = f2_neg(theta);
-    m_st_f2(Tm, 0, m_ld_f2(sc, 9)); m_st_f2(Tm, 1, f2_sub(m_ld_f2(sc, 10), m_ld_f2(sc, 11))); m_st_f2(Tm, 2, m_ld_f2(sc, 12));
+    const Fp2 nx = m_ld_f2(sc, 9), ny = f2_sub(m_ld_f2(sc, 10), m_ld_f2(sc, 11)), nz = m_ld_f2(sc, 12);
+    wide_sync();
+    m_st_f2(Tm, 0, nx); m_st_f2(Tm, 1, ny); m_st_f2(Tm, 2, nz);
     wide_fence();
 }
 
@@ -245,6 +280,21 @@ ZKV_HD void miller_loop_w(const VkTables& vk, uint32_t flags, const G1Norm& n, c
         li++;
     }
 }
+// F <- F^-1, executed redundantly by every pair (all lanes read the whole value, all write the same result).
+#if !defined(__HIP_DEVICE_COMPILE__)
+uint32_t* zkv_wide_host_pair_tmp();     // host emulation: 96 words shared by the two threads of a pair
+#endif
+ZKV_HD void f12m_inv_w(MRef F) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    f12m_inv(F, F);                     // lockstep: every lane has loaded F before the first lane stores
+#else
+    MRef T = m_ref(zkv_wide_host_pair_tmp() + 8 * zkv_parity(), 1, 16);
+    f12m_inv(T, F);
+    wide_sync();
+    f12m_copy(F, T);
+#endif
+    wide_fence();
+}
 // acc <- x^u, same window schedule as exp_u_m
 ZKV_HD void exp_u_w(MRef acc, MRef x, MRef W, int q) {
     const MRef X3 = W, X5 = m_off(W, 96), X7 = m_off(W, 192);
@@ -264,7 +314,7 @@ ZKV_HD void exp_u_w(MRef acc, MRef x, MRef W, int q) {
 // Same chain as final_exp_is_one_m.  The inversion and the final comparison run redundantly on every pair.
 ZKV_HD bool final_exp_is_one_w(MRef F, MRef E, MRef Y1, MRef Y3, MRef Y4, MRef W, MRef acc, int q) {
     w12_copy(acc, F, q); w12_conj(acc, q);
-    f12m_inv(F, F); wide_fence();
+    f12m_inv_w(F);
     w12_mul(acc, acc, F, q, false);          // f^(p^6-1)
     w12_frob(F, acc, 2, q);
     w12_mul(E, F, acc, q, false);            // e = ^(p^2+1)

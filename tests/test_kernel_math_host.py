@@ -105,6 +105,49 @@ def test_groth16_core_on_corpus(hs, verify_corpus, real_proofs):
     assert n > 40
 
 
+@pytest.fixture(scope='module')
+def hs_wide(hs):
+    src = os.path.join(HERE, 'host_sim', 'host_sim_wide.cpp')
+    lib = os.path.join(HERE, 'host_sim', 'libhost_sim_wide.so')
+    csrc = os.path.join(HERE, '..', 'stylus_zkvm_verifiers_amd', 'csrc')
+    deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith('.h')]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wno-unknown-pragmas', '-o', lib, src])
+    L = C.CDLL(lib)
+    L.hs3_pairing.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    hs.hs_prepare.restype = C.c_void_p
+    return L
+
+
+def test_sixteen_lane_kernels_on_corpus(hs, hs_pair, hs_wide, verify_corpus, real_proofs):
+    """The coefficient-parallel code of k_wide.hip (csrc/zkv_tower_wide.h: six lane pairs per proof, operands exchanged through
+    shared slots), emulated with twelve host threads: same accept/reject as the lane-pair emulation and the golden corpus on
+    every case that reaches the pairing (the G2 subgroup check is not part of these kernels)."""
+    r0 = real_proofs['risc0']
+    cr, cid = H(r0['control_root']), H(r0['bn254_control_id'])
+    v = m.Risc0Verifier(); v.initialize(cr, cid)
+    n = 0
+    for c in verify_corpus['cases']:
+        if c['status'] not in (0, 1):
+            continue
+        if c['vm'] == 'risc0':
+            sig = v.signals(m.receipt_claim_ok_digest(H(c['image_id']), H(c['journal_digest'])))
+            args = (0, cr, cid, H(c['seal'])[4:], m.be32(sig[2]), m.be32(sig[3]))
+        else:
+            args = (1, None, None, H(c['proof'])[4:], H(c['vkey']), m.be32(m.sp1_hash_public_values(H(c['public_values']))))
+        fl = C.c_uint32(0); norm = (C.c_uint32 * 48)(); b = (C.c_uint32 * 32)(); sub = C.c_int(0)
+        t = hs.hs_prepare(*args, C.byref(fl), norm, b)
+        if not t:
+            continue
+        acc2 = hs_pair.hs2_pairing(t, fl.value, norm, b, C.byref(sub))
+        if not sub.value:
+            continue
+        acc3 = hs_wide.hs3_pairing(t, fl.value, norm, b)
+        assert acc3 == acc2 == (1 if c['status'] == 0 else 0), c['name']
+        n += 1
+    assert n > 30
+
+
 def test_lane_pair_kernels_on_corpus(hs, hs_pair, verify_corpus, real_proofs):
     """The ZKV_PAIRED code of k_pair.hip (one proof per two lanes, operands exchanged between the lanes), emulated with
     two host threads: same accept/reject as the golden corpus on every case that reaches the pairing."""
