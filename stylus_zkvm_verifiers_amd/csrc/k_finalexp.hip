@@ -9,7 +9,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_finalexp(size_t n, Workspace ws, 
     size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t flags = ws.flags[i];
-    if (!(flags & FL_ALIVE)) return;
+    if (!(flags & FL_ALIVE) || ws.g2bad[i]) return;
     uint32_t st = (uint32_t)ws.cap;
     LRef acc = l_ref(lds + threadIdx.x);
     MRef F = m_ref(ws.f + i, st);

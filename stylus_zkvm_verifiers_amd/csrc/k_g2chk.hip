@@ -11,7 +11,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_g2chk(size_t n, Workspace ws, uin
     Fp2 bx, by;
     bx.c0 = ws_ld(ws.prep, ws.cap, 32, i); bx.c1 = ws_ld(ws.prep, ws.cap, 40, i);
     by.c0 = ws_ld(ws.prep, ws.cap, 48, i); by.c1 = ws_ld(ws.prep, ws.cap, 56, i);
-    if (!g2_in_subgroup(bx, by)) { ws.flags[i] = 0; status[i] = ST_VERIFICATION_FAILED; }
+    if (!g2_in_subgroup(bx, by)) { ws.g2bad[i] = 1; status[i] = ST_VERIFICATION_FAILED; }
 }
 
 void launch_g2chk(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s) {

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_g2chk2(size_t n, Workspace ws,
     if (!(flags & FL_ALIVE) || (flags & FL_B_INF)) return;
     Fp2 bx = ld_b(ws, 32, i), by = ld_b(ws, 48, i);
     bool ok = g2_in_subgroup(bx, by);
-    if (!ok && !(threadIdx.x & 1u)) { ws.flags[i] = 0; status[i] = ST_VERIFICATION_FAILED; }
+    if (!ok && !(threadIdx.x & 1u)) { ws.g2bad[i] = 1; status[i] = ST_VERIFICATION_FAILED; }
 }
 
 __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller2(size_t n, const VkTables* __restrict__ vk, Workspace ws) {
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller2(size_t n, const VkTabl
     size_t i = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
     if (i >= n) return;
     uint32_t flags = ws.flags[i];
-    if (!(flags & FL_ALIVE)) return;
+    if (!(flags & FL_ALIVE) || ws.g2bad[i]) return;
     const uint32_t par = threadIdx.x & 1u;
     G1Norm nm;                                             // Fp values: both lanes of the pair hold them
     nm.axs = ws_ld(ws.norm, ws.cap, 0, i); nm.ays = ws_ld(ws.norm, ws.cap, 8, i);
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_finalexp2(size_t n, Workspace 
     size_t i = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
     if (i >= n) return;
     uint32_t flags = ws.flags[i];
-    if (!(flags & FL_ALIVE)) return;
+    if (!(flags & FL_ALIVE) || ws.g2bad[i]) return;
     const uint32_t par = threadIdx.x & 1u;
     const uint32_t st = (uint32_t)ws.cap;
     LRef acc = l_ref(lds + threadIdx.x);

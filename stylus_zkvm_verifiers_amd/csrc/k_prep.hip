@@ -102,6 +102,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_prep_risc0(PrepArgs a, Risc0Const
         if (prep_points(w, true, o)) { flags = o.flags | inst_bits; store_prep(ws, i, o); }
     }
     ws.flags[i] = flags;
+    ws.g2bad[i] = 0;
     a.status[i] = st;
 }
 
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_prep_sp1(PrepArgs a, Workspace ws
         }
     }
     ws.flags[i] = flags;
+    ws.g2bad[i] = 0;
     a.status[i] = st;
 }
 
@@ -159,6 +161,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_prep_groth16(PrepArgs a, Workspac
         }
     }
     ws.flags[i] = flags;
+    ws.g2bad[i] = 0;
     a.status[i] = ST_VERIFICATION_FAILED;
 }
 

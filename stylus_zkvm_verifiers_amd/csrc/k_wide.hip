@@ -32,7 +32,7 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller_w(size_t n, const VkTab
     const WideLane w = wide_lane();
     if (w.i >= n) return;
     const uint32_t flags = ws.flags[w.i];
-    if (!(flags & FL_ALIVE)) return;
+    if (!(flags & FL_ALIVE) || ws.g2bad[w.i]) return;
     G1Norm nm;
     nm.axs = ws_ld(ws.norm, ws.cap, 0, w.i); nm.ays = ws_ld(ws.norm, ws.cap, 8, w.i);
     nm.lxs = ws_ld(ws.norm, ws.cap, 16, w.i); nm.lys = ws_ld(ws.norm, ws.cap, 24, w.i);
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_finalexp_w(size_t n, Workspace
     const WideLane w = wide_lane();
     if (w.i >= n) return;
     const uint32_t flags = ws.flags[w.i];
-    if (!(flags & FL_ALIVE)) return;
+    if (!(flags & FL_ALIVE) || ws.g2bad[w.i]) return;
     const uint32_t st = (uint32_t)ws.cap;
     MRef acc = m_ref(lds + w.g * 96 + 8 * w.half, 1, 16);
     MRef F = m_ref(ws.f + (size_t)(8 * w.half) * ws.cap + w.i, st, 16);

@@ -33,7 +33,9 @@ struct zkv_ctx {
     bool dev_ready = false;
     hipStream_t stream = nullptr;
     VkTables* d_tab = nullptr;
-    Workspace ws = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    Workspace ws = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    hipStream_t side = nullptr;                              // small chunks: the G2 subgroup check runs beside the MSM
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint8_t *d_blob = nullptr, *d_a = nullptr, *d_b = nullptr, *d_pv = nullptr, *d_status = nullptr, *d_recv = nullptr;
     uint64_t *d_off = nullptr, *d_pvoff = nullptr;
     size_t blob_cap = 0, pv_cap = 0;
@@ -96,7 +98,7 @@ ZKV_EXPORT const char* zkv_version(void) { return "zkv-mi355x 0.1 (gfx950)"; }
 static void ctx_free_device(zkv_ctx* c) {
     if (!c->dev_ready && !c->stream) return;
     (void)hipSetDevice(c->device);
-    void* ptrs[] = {c->d_tab, c->ws.prep, c->ws.norm, c->ws.f, c->ws.fe, c->ws.flags, c->d_blob, c->d_a, c->d_b, c->d_pv,
+    void* ptrs[] = {c->d_tab, c->ws.prep, c->ws.norm, c->ws.f, c->ws.fe, c->ws.flags, c->ws.g2bad, c->d_blob, c->d_a, c->d_b, c->d_pv,
                     c->d_status, c->d_recv, c->d_off, c->d_pvoff, c->d_cd[0], c->d_cd[1], c->d_kind, c->d_cdoff[0], c->d_cdoff[1], c->d_len,
                     c->d_pvlen, c->d_st_all, c->d_rv_all, c->d_inst, c->d_inst_idx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -110,6 +112,10 @@ static void ctx_free_device(zkv_ctx* c) {
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     c->copy_stream = nullptr;
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    c->ev_fork = c->ev_join = nullptr; c->side = nullptr;
     if (c->stream) (void)hipStreamDestroy(c->stream);
     c->dev_ready = false; c->stream = nullptr;
 }
@@ -125,6 +131,9 @@ static int ctx_device_init(zkv_ctx* c) {
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->ev_wire) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     if (c->vm != ZKV_VM_BN254) {
         VkRaw raw;
         if (c->vm == ZKV_VM_RISC0 || c->vm == ZKV_VM_RISC0_SET) host::fill_vk_risc0(raw, c->control_root_0, c->control_root_1, c->control_id);
@@ -166,7 +175,7 @@ static int ctx_device_init(zkv_ctx* c) {
         hipMalloc(&c->ws.norm, sizeof(uint32_t) * WS_NORM_WORDS * cap) != hipSuccess ||
         hipMalloc(&c->ws.f, sizeof(uint32_t) * WS_F_WORDS * cap) != hipSuccess ||
         hipMalloc(&c->ws.fe, sizeof(uint32_t) * WS_FE_WORDS * cap) != hipSuccess ||
-        hipMalloc(&c->ws.flags, sizeof(uint32_t) * cap) != hipSuccess ||
+        hipMalloc(&c->ws.flags, sizeof(uint32_t) * cap) != hipSuccess || hipMalloc(&c->ws.g2bad, sizeof(uint32_t) * cap) != hipSuccess ||
         hipMalloc(&c->d_a, 32 * cap) != hipSuccess || hipMalloc(&c->d_b, 32 * cap) != hipSuccess ||
         hipMalloc(&c->d_status, cap) != hipSuccess || hipMalloc(&c->d_recv, 4 * cap) != hipSuccess ||
         hipMalloc(&c->d_off, sizeof(uint64_t) * (cap + 1)) != hipSuccess ||
@@ -207,11 +216,23 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     else if (c->vm == ZKV_VM_GROTH16) launch_prep_groth16(a, c->ws, s);
     else launch_prep_sp1(a, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[1], s);
-    launch_msm(a.n, c->d_tab, a.inst ? c->d_inst : nullptr, c->ws, s);
-    if (timed) (void)hipEventRecord(c->ev[2], s);
     const int lanes = c->lanes ? c->lanes : lanes_per_proof();
     const bool pair = lanes == 2 || lanes == 16;
-    if (pair) launch_g2chk2(a.n, c->ws, a.status, s); else launch_g2chk(a.n, c->ws, a.status, s);
+    // Small chunks leave most of the chip idle, and the subgroup check of B only needs the PREP output: run it on a second
+    // stream beside the MSM (it reports into ws.g2bad, the MSM owns ws.flags).  The stage times [1] and [2] then overlap:
+    // [2] is what remains of the check after the MSM has finished.
+    const bool fork = a.n <= wide_below() && c->side != nullptr;
+    if (fork) {
+        (void)hipEventRecord(c->ev_fork, s);
+        (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
+        if (pair) launch_g2chk2(a.n, c->ws, a.status, c->side); else launch_g2chk(a.n, c->ws, a.status, c->side);
+        (void)hipEventRecord(c->ev_join, c->side);
+    }
+    launch_msm(a.n, c->d_tab, a.inst ? c->d_inst : nullptr, c->ws, s);
+    if (timed) (void)hipEventRecord(c->ev[2], s);
+    if (fork) (void)hipStreamWaitEvent(s, c->ev_join, 0);
+    else if (pair) launch_g2chk2(a.n, c->ws, a.status, s);
+    else launch_g2chk(a.n, c->ws, a.status, s);
     if (timed) (void)hipEventRecord(c->ev[3], s);
     const bool wide = lanes == 16 || (pair && c->lanes == 0 && a.n <= wide_below());
     if (wide) launch_miller_w(a.n, c->d_tab, c->ws, s);

@@ -13,6 +13,7 @@ constexpr int WS_F_WORDS = 96;      // Fp12 Miller value (slot F of the final ex
 constexpr int WS_FE_WORDS = 7 * 96; // cold Fp12 slots of the final exponentiation: E, Y1, Y3, Y4 and the window slots x^3, x^5, x^7
 struct Workspace {
     uint32_t* prep; uint32_t* norm; uint32_t* f; uint32_t* fe; uint32_t* flags;
+    uint32_t* g2bad;            // 1 = B failed the subgroup check (own word: the check may run beside the MSM, which owns `flags`)
     size_t cap;
 };
 
