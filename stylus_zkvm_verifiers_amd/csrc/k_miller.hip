@@ -11,7 +11,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_miller(size_t n, const VkTables* 
     size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t flags = ws.flags[i];
-    if (!(flags & FL_ALIVE) || ws.g2bad[i]) return;
+    if (!(flags & FL_ALIVE)) return;        // the subgroup check of B may still be running: its verdict is read by the final exponentiation
     G1Norm nm;
     nm.axs = ws_ld(ws.norm, ws.cap, 0, i); nm.ays = ws_ld(ws.norm, ws.cap, 8, i);
     nm.lxs = ws_ld(ws.norm, ws.cap, 16, i); nm.lys = ws_ld(ws.norm, ws.cap, 24, i);

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller2(size_t n, const VkTabl
     size_t i = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
     if (i >= n) return;
     uint32_t flags = ws.flags[i];
-    if (!(flags & FL_ALIVE) || ws.g2bad[i]) return;
+    if (!(flags & FL_ALIVE)) return;        // the subgroup check of B may still be running: its verdict is read by k_finalexp2
     const uint32_t par = threadIdx.x & 1u;
     G1Norm nm;                                             // Fp values: both lanes of the pair hold them
     nm.axs = ws_ld(ws.norm, ws.cap, 0, i); nm.ays = ws_ld(ws.norm, ws.cap, 8, i);

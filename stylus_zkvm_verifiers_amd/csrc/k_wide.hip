@@ -32,7 +32,7 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller_w(size_t n, const VkTab
     const WideLane w = wide_lane();
     if (w.i >= n) return;
     const uint32_t flags = ws.flags[w.i];
-    if (!(flags & FL_ALIVE) || ws.g2bad[w.i]) return;
+    if (!(flags & FL_ALIVE)) return;        // the subgroup check of B may still be running: its verdict is read by k_finalexp_w
     G1Norm nm;
     nm.axs = ws_ld(ws.norm, ws.cap, 0, w.i); nm.ays = ws_ld(ws.norm, ws.cap, 8, w.i);
     nm.lxs = ws_ld(ws.norm, ws.cap, 16, w.i); nm.lys = ws_ld(ws.norm, ws.cap, 24, w.i);

@@ -218,10 +218,10 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     if (timed) (void)hipEventRecord(c->ev[1], s);
     const int lanes = c->lanes ? c->lanes : lanes_per_proof();
     const bool pair = lanes == 2 || lanes == 16;
-    // The subgroup check of B only needs the PREP output: it runs on a second stream beside the MSM (it reports into
-    // ws.g2bad, the MSM owns ws.flags).  Small chunks leave most of the chip idle, so the check disappears behind the MSM
-    // (-0.5 ms); at 2^16 proofs the MSM occupies one wave per SIMD and the overlap is still worth 0.13 ms.  The stage times
-    // [1] and [2] then overlap: [2] is what remains of the check after the MSM has finished.
+    // The subgroup check of B only needs the PREP output and only its verdict (ws.g2bad; the MSM owns ws.flags) is needed, by the
+    // final exponentiation: it runs on a second stream beside the MSM and the Miller loop, which is computed speculatively for
+    // the rare proof whose B fails the check.  Small chunks leave most of the chip idle, so the check disappears (-0.7 ms); at
+    // 2^16 proofs the overlap with the one-wave-per-SIMD MSM is still worth 0.13 ms.  Stage time [2] is then ~0.
     const bool fork = c->side != nullptr;
     if (fork) {
         (void)hipEventRecord(c->ev_fork, s);
@@ -231,15 +231,14 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     }
     launch_msm(a.n, c->d_tab, a.inst ? c->d_inst : nullptr, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[2], s);
-    if (fork) (void)hipStreamWaitEvent(s, c->ev_join, 0);
-    else if (pair) launch_g2chk2(a.n, c->ws, a.status, s);
-    else launch_g2chk(a.n, c->ws, a.status, s);
+    if (!fork) { if (pair) launch_g2chk2(a.n, c->ws, a.status, s); else launch_g2chk(a.n, c->ws, a.status, s); }
     if (timed) (void)hipEventRecord(c->ev[3], s);
     const bool wide = lanes == 16 || (pair && c->lanes == 0 && a.n <= wide_below());
     if (wide) launch_miller_w(a.n, c->d_tab, c->ws, s);
     else if (pair) launch_miller2(a.n, c->d_tab, c->ws, s);
     else launch_miller(a.n, c->d_tab, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[4], s);
+    if (fork) (void)hipStreamWaitEvent(s, c->ev_join, 0);      // the final exponentiation reads the verdict of the subgroup check
     if (wide) launch_finalexp_w(a.n, c->ws, a.status, s);
     else if (pair) launch_finalexp2(a.n, c->ws, a.status, s);
     else launch_finalexp(a.n, c->ws, a.status, s);
