@@ -1,5 +1,5 @@
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r1i; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r1k; mkdir -p $O
 timeout -k 10 300 python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1
 timeout -k 10 400 python bench.py --steps 5 --warmup 1 > $O/bench_risc0_2p16.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
