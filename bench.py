@@ -66,10 +66,7 @@ class Shard:
         self.stage_ms = np.zeros(5)
         self.stage_samples = 0
         # context set-up (stream, VK tables, workspace) happens here, outside any timed region even with --warmup 0
-        if vm == 'risc0':
-            self.ctx.verify_batch_dev(0, 0, 0, 0, 0, 0, 0)
-        else:
-            self.ctx.verify_batch_dev(0, 0, 0, self.h_b.shape[1], 0, 0, 0, 0)
+        self.ctx.reserve(n)
         self.ctx.synchronize()
 
     def enqueue(self, stream):
@@ -165,7 +162,7 @@ def wire_leg(shard, dev, stream, steps=3):
         _lib.check(fn(shard.ctx._h, n, cd.ctypes.data, off.ctypes.data, rv8.ctypes.data, retb.ctypes.data, rl.ctypes.data, st8.ctypes.data), 'eth_call_batch')
         host_rate = n / (time.perf_counter() - t0)
         same = same and bool((st8 == shard.d_status.cpu().numpy()).all())
-    chunk = int(os.environ.get('ZKV_CHUNK', 1 << 17))
+    chunk = int(os.environ.get('ZKV_CHUNK', 1 << 20))
     last = n - (-(-n // chunk) - 1) * chunk                      # the events bracket the last chunk's decode launch
     ms = float(np.mean(wire_ms))
     out_bytes = 260 + (64 if shard.vm == 'risc0' else 32 + shard.h_b.shape[1]) + 4 + 1
@@ -308,8 +305,8 @@ def main():
         dom = max(shards, key=lambda s: s.stage_ms.sum())
         avg = dom.stage_ms / max(dom.stage_samples, 1)
         k = int(np.argmax(avg))
-        launches = -(-dom.n // (1 << 17)) if not os.environ.get('ZKV_CHUNK') else -(-dom.n // int(os.environ['ZKV_CHUNK']))
-        per_launch = min(dom.n, int(os.environ.get('ZKV_CHUNK', 1 << 17)))
+        launches = -(-dom.n // (1 << 20)) if not os.environ.get('ZKV_CHUNK') else -(-dom.n // int(os.environ['ZKV_CHUNK']))
+        per_launch = min(dom.n, int(os.environ.get('ZKV_CHUNK', 1 << 20)))
         last_chunk = dom.n - (launches - 1) * per_launch          # events bracket the last chunk of a step
         bpp = BYTES_PER_PROOF[dom.vm]
         achieved = last_chunk * bpp / (avg[k] * 1e-3) / 1e9

@@ -207,6 +207,10 @@ int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_* */
  * default 12288) one proof per 16 lanes, which halves the latency of a small batch; 2 = always lane pairs; 16 = always
  * 16 lanes per proof; 1 = one proof per lane (A/B reference).  Results are identical. */
 int zkv_ctx_set_lanes_per_proof(zkv_ctx* ctx, int lanes);
+/* Device set-up (stream, verification-key tables) and per-chunk buffers for batches of up to n proofs, ahead of the first
+ * batch call.  Optional: every batch entry point does this on demand; the buffers (about 3.7 KB per proof in flight) grow to the
+ * largest batch seen, at most ZKV_CHUNK proofs (environment, default 2^20; larger batches run chunk by chunk). */
+int zkv_ctx_reserve(zkv_ctx* ctx, size_t n);
 /* Blocks until everything enqueued on the context's stream has finished. */
 int zkv_ctx_synchronize(zkv_ctx* ctx);
 /* HIP-event durations (ms) of the stages of the most recent batch chunk on this context:

@@ -69,6 +69,10 @@ class Sp1Verifier:
         16 = sixteen lanes per proof, 1 = one proof per lane; same results."""
         _lib.check(self._L.zkv_ctx_set_lanes_per_proof(self._h, lanes), 'zkv_ctx_set_lanes_per_proof')
 
+    def reserve(self, n):
+        """Device set-up and per-chunk buffers for batches of up to n proofs, ahead of the first batch (optional)."""
+        _lib.check(self._L.zkv_ctx_reserve(self._h, n), 'zkv_ctx_reserve')
+
     def synchronize(self):
         _lib.check(self._L.zkv_ctx_synchronize(self._h), 'zkv_ctx_synchronize')
 

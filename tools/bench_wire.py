@@ -46,7 +46,7 @@ def main():
     st = d_st.cpu().numpy()
     bad = np.zeros(n, dtype=bool); bad[3::1000] = True
     assert (st[bad] == 6).all() and (st[~bad] == 0).all(), 'unexpected statuses'
-    chunk = int(os.environ.get('ZKV_CHUNK', 1 << 17))
+    chunk = int(os.environ.get('ZKV_CHUNK', 1 << 20))
     last = n - (-(-n // chunk) - 1) * chunk
     best = min(ms[1:])
     host = None
