@@ -127,6 +127,32 @@ int zkv_sp1_verify_proof(zkv_ctx* ctx, const uint8_t program_vkey[32], const uin
 int zkv_sp1_verify_batch_dev(zkv_ctx* ctx, size_t n, const uint8_t* d_program_vkeys, const uint8_t* d_public_values, size_t pv_len,
                              const uint8_t* d_proofs, uint8_t* d_status, uint8_t* d_recv_selector, void* stream);
 
+/* ------------------------------------------------------------------ mixed batches: one VM tag per proof
+ * The reference's shared core takes the VM per call -- `VMType { Risc0, Sp1 }` (common/types.rs:24-26) selects the A negation and
+ * the key convention in Groth16Verifier::verify_proof_with_key / verify_pairing (common/groth16.rs:23-31, 96-103) -- and a node
+ * serving both deployed verifiers sees their calls interleaved (BASELINE.json config 4).  A mixed context is one RISC Zero
+ * verifier (`initialize`d with the given parameters) and one SP1 verifier behind a per-proof tag: vm[i] = ZKV_VM_RISC0 means
+ * proof i is `IRiscZeroVerifier::verify(seal, in_a = image_id, in_b = journal_digest)` (risc0/verifier.rs:78-92), ZKV_VM_SP1 means
+ * `ISp1Verifier::verify_proof(in_a = program_vkey, in_b = public_values, seal = proof_bytes)` (sp1/verifier.rs:39-46); status and
+ * received selector are exactly that verifier's.  The batch is demultiplexed on the device into two homogeneous sub-batches
+ * (stable partition), which take the ordinary stage pipelines; statuses return in the caller's order.  A tag that is not a
+ * VMType gets ZKV_STATUS_UNKNOWN_VM (no reference counterpart: the Rust enum cannot hold such a value). */
+#define ZKV_VM_MIXED 5
+#define ZKV_STATUS_UNKNOWN_VM 7
+zkv_ctx* zkv_mixed_ctx_create(const uint8_t control_root[32], const uint8_t bn254_control_id[32], int device);
+/* the two verifiers behind the tag (owned by the mixed context; e.g. for the getters) */
+zkv_ctx* zkv_mixed_ctx_risc0(zkv_ctx* ctx);
+zkv_ctx* zkv_mixed_ctx_sp1(zkv_ctx* ctx);
+/* Host buffers, ragged: seal i = seal_blob[seal_off[i] .. seal_off[i+1]), in_a n x 32 bytes, in_b i = in_b_blob[in_b_off[i] ..
+ * in_b_off[i+1]) (exactly 32 bytes for RISC Zero proofs, else ZKV_ERR_INVALID_ARG; any length for SP1 public values). */
+int zkv_mixed_verify_batch(zkv_ctx* ctx, size_t n, const uint8_t* vm, const uint8_t* seal_blob, const uint64_t* seal_off, const uint8_t* in_a,
+                           const uint8_t* in_b_blob, const uint64_t* in_b_off, uint8_t* status, uint8_t* recv_selector);
+/* Fast path, everything resident in HBM: d_vm n tags, d_seals n x 260, d_in_a n x 32, d_in_b n rows of b_stride >= 32 bytes (RISC Zero
+ * rows use the first 32 bytes, SP1 rows the first pv_len <= b_stride bytes).  Asynchronous on `stream` after one synchronisation
+ * (the host learns the two sub-batch sizes from the device). */
+int zkv_mixed_verify_batch_dev(zkv_ctx* ctx, size_t n, const uint8_t* d_vm, const uint8_t* d_seals, const uint8_t* d_in_a, const uint8_t* d_in_b,
+                               size_t b_stride, size_t pv_len, uint8_t* d_status, uint8_t* d_recv_selector, void* stream);
+
 /* ------------------------------------------------------------------ on-chain wire layer: eth_call batches
  * What a client of the deployed example shells sends: calldata for the Solidity view of the two traits
  * (examples/risc0-verifier/examples/interact.rs:31-43, examples/sp1-verifier/examples/interact.rs:11-19; the shells are
@@ -195,10 +221,19 @@ int zkv_groth16_verify_batch(zkv_ctx* ctx, size_t n, const uint8_t* proofs, cons
 
 /* ------------------------------------------------------------------ Groth16 core pieces
  * Groth16Verifier::compute_vk_x (common/groth16.rs:51-58) for a batch: vk_x = IC[0] + sum s_i IC[i+1] with the context's
- * fixed signals (RISC Zero: control root halves and bn254 control id) and the two per-proof signals given here as
- * n x 2 x 32 big-endian bytes (RISC Zero: claim digest low / high halves; SP1: program vkey, public-values hash).
+ * fixed signals (RISC Zero: control root halves and bn254 control id) and the per-proof signals given here as
+ * n x k x 32 big-endian bytes: k = 2 for a RISC Zero (claim digest low / high halves) or SP1 (program vkey, public-values hash)
+ * context, k = n_ic - 1 (all signals) for a ZKV_VM_GROTH16 context.
  * Signals must be < R (the reference rejects the proof before this step otherwise).  out: n x 64 bytes (x, y), (0,0) = infinity. */
 int zkv_ctx_vk_x_batch(zkv_ctx* ctx, size_t n, const uint8_t* var_signals, uint8_t* out);
+
+/* ------------------------------------------------------------------ diagnostics
+ * Secondary roofline (no reference counterpart): rate of the library's own register-resident Montgomery multiplication on this
+ * device, in multiplications per second over the whole chip, measured in time (HIP events).  kind 0 = fp_mul (one product + one
+ * reduction), kind 1 = the lane-pair Fp2 product (two products + one reduction per lane, counted as two multiplications -- the
+ * unit in which the verify kernels' work is counted); waves_per_simd 1..8 resident wavefronts per SIMD; iters loop trips (four
+ * calls each).  *shader_clock_ghz (may be NULL) = shader clock under this load from s_memtime / s_memrealtime. */
+int zkv_diag_mulmod_rate(int device, int kind, int waves_per_simd, uint32_t iters, double* mulmods_per_s, double* shader_clock_ghz);
 
 /* ------------------------------------------------------------------ shared */
 int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_* */

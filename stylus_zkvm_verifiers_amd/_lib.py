@@ -41,6 +41,11 @@ SYMBOLS = {
     'zkv_sp1_verify_batch': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'zkv_sp1_verify_proof': (_i, [_vp, _cp, _cp, _sz, _cp, _sz, _u8p, _cp]),
     'zkv_sp1_verify_batch_dev': (_i, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    'zkv_mixed_ctx_create': (_vp, [_cp, _cp, _i]),
+    'zkv_mixed_ctx_risc0': (_vp, [_vp]),
+    'zkv_mixed_ctx_sp1': (_vp, [_vp]),
+    'zkv_mixed_verify_batch': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'zkv_mixed_verify_batch_dev': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     'zkv_bn254_ctx_create': (_vp, [_i]),
     'zkv_bn254_ecadd_batch': (_i, [_vp, _sz, _vp, _vp, _vp]),
     'zkv_bn254_ecmul_batch': (_i, [_vp, _sz, _vp, _vp, _vp]),
@@ -48,6 +53,7 @@ SYMBOLS = {
     'zkv_groth16_ctx_create': (_vp, [_cp, _sz, _i, _i]),
     'zkv_groth16_verify_batch': (_i, [_vp, _sz, _vp, _vp, _vp]),
     'zkv_ctx_vk_x_batch': (_i, [_vp, _sz, _vp, _vp]),
+    'zkv_diag_mulmod_rate': (_i, [_i, _i, _i, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'zkv_ctx_vm': (_i, [_vp]),
     'zkv_ctx_set_lanes_per_proof': (_i, [_vp, _i]),
     'zkv_ctx_reserve': (_i, [_vp, _sz]),
@@ -83,6 +89,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError('libzkv_mi355x.so is not built (%s); run `python -m stylus_zkvm_verifiers_amd.build` -- '
                               'this package has no CPU fallback' % LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP runtime (another soname than /opt/rocm's, which this library links).  Both can live in one
+        # process only when torch's is initialised first -- otherwise torch later reports "No HIP GPUs are available" -- so the
+        # binding pulls torch in before the library whenever torch is installed (it is the package's plumbing for device memory).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)          # AttributeError when a declared symbol is not exported

@@ -1,4 +1,4 @@
-// Stage MSM: vk_x = base + sum s_b * IC_b via 4-bit fixed-base windows (tables stay L2-resident), then the
+// Stage MSM: vk_x = base + sum s_b * IC_b via 8-bit fixed-base windows (tables stay L2-resident), then the
 // x/y, 1/y normalisation of A', vk_x and C with a single field inversion per proof.
 #include "zkv_internal.h"
 
@@ -35,7 +35,12 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_vk_x(size_t n, const VkTables* __
     size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (i >= n) return;
     PrepOut in;
-    load_be256(in.s[0], sig + 64 * i); load_be256(in.s[1], sig + 64 * i + 32);
+    const uint32_t nv = vk->n_var;                                  // 2 for the RISC Zero / SP1 keys, n_ic - 1 for a generic key
+#pragma unroll 1
+    for (uint32_t b = 0; b < MAX_VAR; b++) {
+        if (b < nv) load_be256(in.s[b], sig + 32 * ((size_t)nv * i + b));
+        else for (int k = 0; k < 8; k++) in.s[b][k] = 0;
+    }
     G1J acc = inst_tab ? msm_accumulate(*vk, in, inst_tab[inst[i]].base, inst_tab[inst[i]].base_inf) : msm_accumulate(*vk, in);
     G1A a; uint32_t inf;
     g1j_to_affine(acc, a, inf);

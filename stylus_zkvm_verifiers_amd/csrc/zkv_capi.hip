@@ -52,6 +52,15 @@ struct zkv_ctx {
     // each call first makes its stream wait for the previous call's last kernel (ev_done), then records ev_done again.
     hipEvent_t ev_done = nullptr;
     bool has_done = false;
+    // host-buffer batches (run_host_batch): whole-batch staging in HBM, filled segment by segment on copy_stream while the previous
+    // segment is verified
+    uint8_t* hb[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // seals, seal offsets, in_a, in_b, public values, pv offsets
+    size_t hb_cap[6] = {0, 0, 0, 0, 0, 0};
+    hipEvent_t ev_seg[2] = {nullptr, nullptr};
+    // ZKV_VM_MIXED: one RISC Zero and one SP1 verifier behind a per-proof VM tag; mx[] are the demultiplexing buffers
+    zkv_ctx* kid[2] = {nullptr, nullptr};
+    uint8_t* mx[20] = {nullptr};
+    size_t mx_cap[20] = {0};
     std::mutex mu;
 };
 
@@ -89,59 +98,58 @@ ZKV_EXPORT int zkv_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     int ok = 0;
     for (int i = 0; i < n; i++) ok += device_is_gfx950(i) ? 1 : 0;
-    return ok == n ? n : ok;
+    return ok;
 }
 ZKV_EXPORT const char* zkv_version(void) { return "zkv-mi355x 0.1 (gfx950)"; }
 
 #define HIP_TRY(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return ZKV_ERR_HIP; } } while (0)
 
+// Releases every device resource of the context and returns it to the "not set up" state (safe on a partially set-up context).
 static void ctx_free_device(zkv_ctx* c) {
     if (!c->dev_ready && !c->stream) return;
     (void)hipSetDevice(c->device);
-    void* ptrs[] = {c->d_tab, c->ws.prep, c->ws.norm, c->ws.f, c->ws.fe, c->ws.flags, c->ws.g2bad, c->d_blob, c->d_a, c->d_b, c->d_pv,
-                    c->d_status, c->d_recv, c->d_off, c->d_pvoff, c->d_cd[0], c->d_cd[1], c->d_kind, c->d_cdoff[0], c->d_cdoff[1], c->d_len,
-                    c->d_pvlen, c->d_st_all, c->d_rv_all, c->d_inst, c->d_inst_idx};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
-    for (auto& e : c->ev_wire) if (e) (void)hipEventDestroy(e);
-    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
-    c->ev_done = nullptr; c->has_done = false;
-    for (int b = 0; b < 2; b++) {
-        if (c->ev_copied[b]) (void)hipEventDestroy(c->ev_copied[b]);
-        if (c->ev_decoded[b]) (void)hipEventDestroy(c->ev_decoded[b]);
-    }
-    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    c->copy_stream = nullptr;
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->side) (void)hipStreamDestroy(c->side);
-    c->ev_fork = c->ev_join = nullptr; c->side = nullptr;
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    c->dev_ready = false; c->stream = nullptr;
+    void** ptrs[] = {(void**)&c->d_tab, (void**)&c->ws.prep, (void**)&c->ws.norm, (void**)&c->ws.f, (void**)&c->ws.fe, (void**)&c->ws.flags,
+                     (void**)&c->ws.g2bad, (void**)&c->d_blob, (void**)&c->d_a, (void**)&c->d_b, (void**)&c->d_pv, (void**)&c->d_status,
+                     (void**)&c->d_recv, (void**)&c->d_off, (void**)&c->d_pvoff, (void**)&c->d_cd[0], (void**)&c->d_cd[1], (void**)&c->d_kind,
+                     (void**)&c->d_cdoff[0], (void**)&c->d_cdoff[1], (void**)&c->d_len, (void**)&c->d_pvlen, (void**)&c->d_st_all,
+                     (void**)&c->d_rv_all, (void**)&c->d_inst, (void**)&c->d_inst_idx};
+    for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    for (int k = 0; k < 6; k++) { if (c->hb[k]) (void)hipFree(c->hb[k]); c->hb[k] = nullptr; c->hb_cap[k] = 0; }
+    for (int k = 0; k < 20; k++) { if (c->mx[k]) (void)hipFree(c->mx[k]); c->mx[k] = nullptr; c->mx_cap[k] = 0; }
+    c->ws.cap = 0; c->blob_cap = c->pv_cap = 0; c->cd_cap[0] = c->cd_cap[1] = c->st_all_cap = c->rv_all_cap = 0;
+    hipEvent_t* evs[] = {&c->ev[0], &c->ev[1], &c->ev[2], &c->ev[3], &c->ev[4], &c->ev[5], &c->ev_wire[0], &c->ev_wire[1], &c->ev_done,
+                         &c->ev_copied[0], &c->ev_copied[1], &c->ev_decoded[0], &c->ev_decoded[1], &c->ev_fork, &c->ev_join, &c->ev_seg[0], &c->ev_seg[1]};
+    for (hipEvent_t* e : evs) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+    c->has_done = false; c->wire_timed = false;
+    hipStream_t* streams[] = {&c->copy_stream, &c->side, &c->stream};
+    for (hipStream_t* st : streams) { if (*st) (void)hipStreamDestroy(*st); *st = nullptr; }
+    c->dev_ready = false;
 }
 
-// Lazily creates the stream, the VK tables (set-up kernels) and the per-chunk workspace.
-static int ctx_device_init(zkv_ctx* c) {
-    if (c->dev_ready) return hipSetDevice(c->device) == hipSuccess ? ZKV_OK : ZKV_ERR_HIP;
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return ZKV_ERR_NO_DEVICE; }
-    if (c->device < 0 || c->device >= n || !device_is_gfx950(c->device)) return ZKV_ERR_NO_DEVICE;
-    HIP_TRY(hipSetDevice(c->device));
+// Lazily creates the streams, the VK tables (set-up kernels) and the events; the per-chunk workspace comes from ctx_reserve().
+static int ctx_device_setup(zkv_ctx* c) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->ev_wire) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    if (c->vm != ZKV_VM_BN254) {
+    for (auto& e : c->ev_seg) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (int b = 0; b < 2; b++) {
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_copied[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_decoded[b], hipEventDisableTiming));
+    }
+    if (c->vm != ZKV_VM_BN254 && c->vm != ZKV_VM_MIXED) {
         VkRaw raw;
         if (c->vm == ZKV_VM_RISC0 || c->vm == ZKV_VM_RISC0_SET) host::fill_vk_risc0(raw, c->control_root_0, c->control_root_1, c->control_id);
         else if (c->vm == ZKV_VM_GROTH16) host::fill_vk_generic(raw, c->gvk, c->g_n_ic);
         else host::fill_vk_sp1(raw);
         if (c->id_ge_r) memset(raw.fixed_scalar[5], 0, 32);      // never used: every proof fails the range check first
-        VkRaw* d_raw = nullptr;
-        HIP_TRY(hipMalloc(&d_raw, sizeof(VkRaw)));
+        // the raw key and the instance parameters are only read by the set-up kernels; mx[0] / mx[1] hold them until those are done
+        HIP_TRY(hipMalloc(&c->mx[0], sizeof(VkRaw)));
+        VkRaw* d_raw = (VkRaw*)c->mx[0];
         HIP_TRY(hipMalloc(&c->d_tab, sizeof(VkTables)));
         HIP_TRY(hipMemsetAsync(c->d_tab, 0, sizeof(VkTables), c->stream));
         HIP_TRY(hipMemcpyAsync(d_raw, &raw, sizeof raw, hipMemcpyHostToDevice, c->stream));
@@ -149,26 +157,34 @@ static int ctx_device_init(zkv_ctx* c) {
         HIP_TRY(hipGetLastError());
         if (c->vm == ZKV_VM_RISC0_SET) {
             const size_t k = c->inst_raw.size();
-            InstRaw* d_in = nullptr;
             InstConsts ic;
             host::sha256_host((const uint8_t*)"risc0.Groth16ReceiptVerifierParameters", 38, ic.tag);
             host::risc0_vk_digest(ic.vk_digest);
-            HIP_TRY(hipMalloc(&d_in, sizeof(InstRaw) * k));
+            HIP_TRY(hipMalloc(&c->mx[1], sizeof(InstRaw) * k));
+            InstRaw* d_in = (InstRaw*)c->mx[1];
             HIP_TRY(hipMalloc(&c->d_inst, sizeof(InstTab) * k));
             HIP_TRY(hipMemcpyAsync(d_in, c->inst_raw.data(), sizeof(InstRaw) * k, hipMemcpyHostToDevice, c->stream));
             launch_setup_instances(d_raw, ic, d_in, c->d_inst, (uint32_t)k, c->stream);
             HIP_TRY(hipGetLastError());
             c->inst_host.resize(k);
             HIP_TRY(hipMemcpyAsync(c->inst_host.data(), c->d_inst, sizeof(InstTab) * k, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            (void)hipFree(d_in);
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
-        (void)hipFree(d_raw);
+        for (int k = 0; k < 2; k++) { if (c->mx[k]) (void)hipFree(c->mx[k]); c->mx[k] = nullptr; }
         uint32_t valid = 0;
         HIP_TRY(hipMemcpy(&valid, &c->d_tab->vk_valid, sizeof valid, hipMemcpyDeviceToHost));
         c->vk_invalid = valid == 0;
     }
+    return ZKV_OK;
+}
+static int ctx_device_init(zkv_ctx* c) {
+    if (c->dev_ready) return hipSetDevice(c->device) == hipSuccess ? ZKV_OK : ZKV_ERR_HIP;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return ZKV_ERR_NO_DEVICE; }
+    if (c->device < 0 || c->device >= n || !device_is_gfx950(c->device)) return ZKV_ERR_NO_DEVICE;
+    HIP_TRY(hipSetDevice(c->device));
+    const int rc = ctx_device_setup(c);
+    if (rc != ZKV_OK) { ctx_free_device(c); return rc; }       // a failed set-up leaves nothing behind; the next call starts over
     c->ws.cap = 0;                                       // per-chunk buffers: ctx_reserve()
     c->dev_ready = true;
     return ZKV_OK;
@@ -283,9 +299,21 @@ static bool offsets_ok(const uint64_t* off, size_t n) {
 static uint32_t be32_of(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
 // Host-pointer batch driver shared by risc0 verify / verify_integrity / sp1 verify_proof.
+//
+// The whole batch (at most 2^22 proofs per pass) is staged in HBM; the copies run on the context's copy stream SEGMENT BY SEGMENT
+// while the previous segment is being verified: a short first segment (2^16 proofs: its 25 MB cross PCIe in about a millisecond),
+// then segments of up to one workspace (2^20 proofs) whose H2D time hides behind the kernels of the segment before.  Statuses
+// stay on the device until the pass is done.  Only the first segment's copy and the status D2H are exposed.
+static size_t host_first_segment(size_t n, size_t cap) {
+    const char* e = getenv("ZKV_HOST_FIRST_SEGMENT");
+    size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 16;
+    if (v < 64) v = 64;
+    if (n <= 2 * v) v = n;
+    return v < cap ? v : cap;
+}
 static int run_host_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const uint64_t* off, const uint8_t* in_a, const uint8_t* in_b,
                           const uint8_t* pv_blob, const uint64_t* pv_off, uint8_t* status, uint8_t* recv) {
-    if (!c || (n && (!blob || !off || !status))) return ZKV_ERR_INVALID_ARG;
+    if (!c || (n && (!blob || !off || !status || !in_a))) return ZKV_ERR_INVALID_ARG;
     if (n && (!offsets_ok(off, n) || (pv_off && !offsets_ok(pv_off, n)))) return ZKV_ERR_INVALID_ARG;
     if (recv) memset(recv, 0, 4 * n);
     if (c->vm == ZKV_VM_RISC0 && !c->initialized) {              // risc0/verifier.rs:84-86, 99-101
@@ -296,41 +324,56 @@ static int run_host_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const uint6
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_ready(c, n);
     if (rc != ZKV_OK) return rc;
-    size_t cap = c->ws.cap;
-    std::vector<uint64_t> rel(cap + 1);
+    const size_t cap = c->ws.cap, pass_max = (size_t)1 << 22;
+    const bool sp1 = c->vm == ZKV_VM_SP1;
     if ((rc = order_after_previous(c, c->stream)) != ZKV_OK) return rc;
-    for (size_t base = 0; base < n; base += cap) {
-        size_t m = n - base < cap ? n - base : cap;
-        uint64_t b0 = off[base], bytes = off[base + m] - b0;
-        if ((rc = grow(&c->d_blob, &c->blob_cap, (size_t)bytes + 8)) != ZKV_OK) return rc;
-        for (size_t i = 0; i <= m; i++) rel[i] = off[base + i] - b0;
-        HIP_TRY(hipMemcpyAsync(c->d_off, rel.data(), sizeof(uint64_t) * (m + 1), hipMemcpyHostToDevice, c->stream));
-        if (bytes) HIP_TRY(hipMemcpyAsync(c->d_blob, blob + b0, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));            // rel[] is reused below
-        HIP_TRY(hipMemcpyAsync(c->d_a, in_a + 32 * base, 32 * m, hipMemcpyHostToDevice, c->stream));
-        if (in_b) HIP_TRY(hipMemcpyAsync(c->d_b, in_b + 32 * base, 32 * m, hipMemcpyHostToDevice, c->stream));
-        PrepArgs a;
-        memset(&a, 0, sizeof a);
-        a.n = m; a.blob = c->d_blob; a.off = c->d_off; a.stride = 0;
-        a.in32_a = c->d_a; a.in32_b = in_b ? c->d_b : nullptr;
-        if (c->vm == ZKV_VM_SP1) {
-            uint64_t p0 = pv_off[base], pbytes = pv_off[base + m] - p0;
-            if ((rc = grow(&c->d_pv, &c->pv_cap, (size_t)pbytes + 8)) != ZKV_OK) return rc;
-            for (size_t i = 0; i <= m; i++) rel[i] = pv_off[base + i] - p0;
-            HIP_TRY(hipMemcpyAsync(c->d_pvoff, rel.data(), sizeof(uint64_t) * (m + 1), hipMemcpyHostToDevice, c->stream));
-            if (pbytes) HIP_TRY(hipMemcpyAsync(c->d_pv, pv_blob + p0, (size_t)pbytes, hipMemcpyHostToDevice, c->stream));
-            a.pv_blob = c->d_pv; a.pv_off = c->d_pvoff;
-            a.selector_be = be32_of(host::SP1_VERIFIER_HASH);
-        } else {
-            a.selector_be = be32_of(c->selector);
-            a.force_fail = c->id_ge_r ? 1u : 0u;
+    std::vector<uint64_t> rel, prel;
+    for (size_t p0 = 0; p0 < n; p0 += pass_max) {
+        const size_t pn = n - p0 < pass_max ? n - p0 : pass_max;
+        const uint64_t s0 = off[p0], sbytes = off[p0 + pn] - s0;
+        const uint64_t v0 = sp1 ? pv_off[p0] : 0, vbytes = sp1 ? pv_off[p0 + pn] - v0 : 0;
+        // growing a buffer frees the old one, which synchronises the device: everything is sized before the first copy
+        if ((rc = grow(&c->hb[0], &c->hb_cap[0], (size_t)sbytes + 8)) != ZKV_OK || (rc = grow(&c->hb[1], &c->hb_cap[1], 8 * (pn + 1))) != ZKV_OK ||
+            (rc = grow(&c->hb[2], &c->hb_cap[2], 32 * pn)) != ZKV_OK || (in_b && (rc = grow(&c->hb[3], &c->hb_cap[3], 32 * pn)) != ZKV_OK) ||
+            (sp1 && ((rc = grow(&c->hb[4], &c->hb_cap[4], (size_t)vbytes + 8)) != ZKV_OK || (rc = grow(&c->hb[5], &c->hb_cap[5], 8 * (pn + 1))) != ZKV_OK)) ||
+            (rc = grow(&c->d_st_all, &c->st_all_cap, pn)) != ZKV_OK || (rc = grow(&c->d_rv_all, &c->rv_all_cap, 4 * pn)) != ZKV_OK) return rc;
+        // offsets relative to the pass (the caller's array is used as it is when the pass starts at offset 0)
+        const uint64_t* o = off + p0; const uint64_t* po = sp1 ? pv_off + p0 : nullptr;
+        if (s0) { rel.resize(pn + 1); for (size_t i = 0; i <= pn; i++) rel[i] = off[p0 + i] - s0; o = rel.data(); }
+        if (sp1 && v0) { prel.resize(pn + 1); for (size_t i = 0; i <= pn; i++) prel[i] = pv_off[p0 + i] - v0; po = prel.data(); }
+        const size_t first = host_first_segment(pn, cap);
+        for (size_t base = 0, k = 0; base < pn; k++) {
+            const size_t m = k == 0 ? first : (pn - base < cap ? pn - base : cap);
+            hipStream_t cs = c->copy_stream;
+            HIP_TRY(hipMemcpyAsync(c->hb[1] + 8 * base, o + base, 8 * (m + 1), hipMemcpyHostToDevice, cs));
+            if (o[base + m] > o[base]) HIP_TRY(hipMemcpyAsync(c->hb[0] + o[base], blob + s0 + o[base], (size_t)(o[base + m] - o[base]), hipMemcpyHostToDevice, cs));
+            HIP_TRY(hipMemcpyAsync(c->hb[2] + 32 * base, in_a + 32 * (p0 + base), 32 * m, hipMemcpyHostToDevice, cs));
+            if (in_b) HIP_TRY(hipMemcpyAsync(c->hb[3] + 32 * base, in_b + 32 * (p0 + base), 32 * m, hipMemcpyHostToDevice, cs));
+            if (sp1) {
+                HIP_TRY(hipMemcpyAsync(c->hb[5] + 8 * base, po + base, 8 * (m + 1), hipMemcpyHostToDevice, cs));
+                if (po[base + m] > po[base]) HIP_TRY(hipMemcpyAsync(c->hb[4] + po[base], pv_blob + v0 + po[base], (size_t)(po[base + m] - po[base]), hipMemcpyHostToDevice, cs));
+            }
+            HIP_TRY(hipEventRecord(c->ev_seg[k & 1], cs));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_seg[k & 1], 0));
+            PrepArgs a;
+            memset(&a, 0, sizeof a);
+            a.n = m; a.blob = c->hb[0]; a.off = (const uint64_t*)c->hb[1] + base; a.stride = 0;
+            a.in32_a = c->hb[2] + 32 * base; a.in32_b = in_b ? c->hb[3] + 32 * base : nullptr;
+            if (sp1) {
+                a.pv_blob = c->hb[4]; a.pv_off = (const uint64_t*)c->hb[5] + base;
+                a.selector_be = be32_of(host::SP1_VERIFIER_HASH);
+            } else {
+                a.selector_be = be32_of(c->selector);
+                a.force_fail = c->id_ge_r ? 1u : 0u;
+            }
+            a.status = c->d_st_all + base; a.recv = c->d_rv_all + 4 * base;
+            base += m;
+            enqueue_chunk(c, a, c->stream, base >= pn);
+            HIP_TRY(hipGetLastError());
         }
-        a.status = c->d_status; a.recv = c->d_recv;
-        enqueue_chunk(c, a, c->stream, true);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(status + base, c->d_status, m, hipMemcpyDeviceToHost, c->stream));
-        if (recv) HIP_TRY(hipMemcpyAsync(recv + 4 * base, c->d_recv, 4 * m, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpyAsync(status + p0, c->d_st_all, pn, hipMemcpyDeviceToHost, c->stream));
+        if (recv) HIP_TRY(hipMemcpyAsync(recv + 4 * p0, c->d_rv_all, 4 * pn, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));            // also: the staging buffers are free for the next pass
     }
     return ZKV_OK;
 }
@@ -370,6 +413,134 @@ static int run_dev_batch(zkv_ctx* c, size_t n, const uint8_t* d_blob, const uint
     return n ? mark_done(c, s) : ZKV_OK;
 }
 
+// Stage pipeline over m compact records that a device-side front end produced (fixed 260-byte stride plus the true length,
+// 32-byte inputs, public values as (start, length) into one blob): the output format of the calldata decoder and of the
+// mixed-batch demultiplexer.  Asynchronous on `s`.
+static int run_records(zkv_ctx* c, size_t m_total, const uint8_t* seals, const uint32_t* len, const uint8_t* in_a, const uint8_t* in_b,
+                       const uint8_t* pv_blob, const uint64_t* pv_start, const uint32_t* pv_len, uint8_t* st, uint8_t* rv, hipStream_t s) {
+    if (!m_total) return ZKV_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ctx_ready(c, m_total);
+    if (rc != ZKV_OK) return rc;
+    if ((rc = order_after_previous(c, s)) != ZKV_OK) return rc;
+    const size_t cap = c->ws.cap;
+    for (size_t base = 0; base < m_total; base += cap) {
+        const size_t m = m_total - base < cap ? m_total - base : cap;
+        PrepArgs a;
+        memset(&a, 0, sizeof a);
+        a.n = m; a.blob = seals + base * ZKV_SEAL_BYTES; a.stride = ZKV_SEAL_BYTES; a.len = len + base;
+        a.in32_a = in_a + 32 * base;
+        if (c->vm == ZKV_VM_SP1) {
+            a.pv_blob = pv_blob; a.pv_off = pv_start + base; a.pv_len = pv_len + base;
+            a.selector_be = be32_of(host::SP1_VERIFIER_HASH);
+        } else {
+            a.in32_b = in_b + 32 * base;
+            a.selector_be = be32_of(c->selector);
+            a.force_fail = c->id_ge_r ? 1u : 0u;
+        }
+        a.status = st + base; a.recv = rv ? rv + 4 * base : nullptr;
+        enqueue_chunk(c, a, s, base + cap >= m_total);
+    }
+    HIP_TRY(hipGetLastError());
+    return mark_done(c, s);
+}
+
+// ------------------------------------------------------------------ mixed batches: per-proof VMType (common/types.rs:24-26)
+ZKV_EXPORT zkv_ctx* zkv_mixed_ctx_create(const uint8_t control_root[32], const uint8_t bn254_control_id[32], int device) {
+    if (!control_root || !bn254_control_id) return nullptr;
+    zkv_ctx* c = new (std::nothrow) zkv_ctx();
+    if (!c) return nullptr;
+    c->vm = ZKV_VM_MIXED; c->device = device; c->initialized = true;
+    memset(&c->consts, 0, sizeof c->consts);
+    c->kid[0] = zkv_risc0_ctx_create(control_root, bn254_control_id, device);
+    c->kid[1] = zkv_sp1_ctx_create(device);
+    if (!c->kid[0] || !c->kid[1]) { zkv_ctx_destroy(c); return nullptr; }
+    return c;
+}
+ZKV_EXPORT zkv_ctx* zkv_mixed_ctx_risc0(zkv_ctx* c) { return c && c->vm == ZKV_VM_MIXED ? c->kid[0] : nullptr; }
+ZKV_EXPORT zkv_ctx* zkv_mixed_ctx_sp1(zkv_ctx* c) { return c && c->vm == ZKV_VM_MIXED ? c->kid[1] : nullptr; }
+
+enum { MX_CNT = 0, MX_TOT, MX_POS, MX_IDX, MX_SEALS, MX_LEN, MX_A, MX_B, MX_PVOFF, MX_PVLEN, MX_ST, MX_RV,
+       MX_H_VM, MX_H_SEALS, MX_H_SOFF, MX_H_A, MX_H_B, MX_H_BOFF, MX_H_ST, MX_H_RV };
+// Everything device-resident; `seal_off` / `b_off` select the ragged layout, otherwise fixed strides.  Synchronises `s` once, after
+// the partition, to learn the two sub-batch sizes.
+static int run_mixed(zkv_ctx* c, size_t n, const uint8_t* d_vm, const uint8_t* d_seals, const uint64_t* d_seal_off, uint32_t seal_stride,
+                     const uint8_t* d_a, const uint8_t* d_b, const uint64_t* d_b_off, uint32_t b_stride, uint32_t pv_len,
+                     uint8_t* d_status, uint8_t* d_recv, hipStream_t s) {
+    int rc;
+    const size_t blocks = (n + 255) / 256;
+    const size_t need[12] = {8 * blocks, 8, 4 * n, 4 * n, (size_t)ZKV_SEAL_BYTES * n, 4 * n, 32 * n, 32 * n, 8 * n, 4 * n, n, 4 * n};
+    for (int k = 0; k < 12; k++) if ((rc = grow(&c->mx[k], &c->mx_cap[k], need[k])) != ZKV_OK) return rc;
+    if ((rc = order_after_previous(c, s)) != ZKV_OK) return rc;
+    MixedArgs a;
+    memset(&a, 0, sizeof a);
+    a.n = n; a.vm = d_vm; a.seals = d_seals; a.seal_off = d_seal_off; a.seal_stride = seal_stride;
+    a.in_a = d_a; a.in_b = d_b; a.b_off = d_b_off; a.b_stride = b_stride; a.pv_len = pv_len;
+    a.cnt = (uint32_t*)c->mx[MX_CNT]; a.totals = (uint32_t*)c->mx[MX_TOT]; a.pos = (uint32_t*)c->mx[MX_POS]; a.idx = (uint32_t*)c->mx[MX_IDX];
+    a.c_seals = c->mx[MX_SEALS]; a.c_len = (uint32_t*)c->mx[MX_LEN]; a.c_a = c->mx[MX_A]; a.c_b = c->mx[MX_B];
+    a.c_pvoff = (uint64_t*)c->mx[MX_PVOFF]; a.c_pvlen = (uint32_t*)c->mx[MX_PVLEN];
+    a.status = d_status; a.recv = d_recv;
+    launch_mixed_partition(a, (uint32_t*)c->mx[MX_CNT], (uint32_t*)c->mx[MX_TOT], s);
+    HIP_TRY(hipGetLastError());
+    uint32_t tot[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(tot, c->mx[MX_TOT], sizeof tot, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const size_t n0 = tot[0], n1 = tot[1];
+    if (n0 + n1 > n) return ZKV_ERR_HIP;
+    uint8_t *st = c->mx[MX_ST], *rv = c->mx[MX_RV];
+    if ((rc = run_records(c->kid[0], n0, a.c_seals, a.c_len, a.c_a, a.c_b, nullptr, nullptr, nullptr, st, rv, s)) != ZKV_OK) return rc;
+    if ((rc = run_records(c->kid[1], n1, a.c_seals + ZKV_SEAL_BYTES * n0, a.c_len + n0, a.c_a + 32 * n0, nullptr, d_b, a.c_pvoff + n0, a.c_pvlen + n0,
+                          st + n0, rv + 4 * n0, s)) != ZKV_OK) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    launch_mixed_return(n0 + n1, a.idx, st, rv, d_status, d_recv, s);
+    HIP_TRY(hipGetLastError());
+    return mark_done(c, s);
+}
+ZKV_EXPORT int zkv_mixed_verify_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d_vm, const uint8_t* d_seals, const uint8_t* d_in_a, const uint8_t* d_in_b,
+                                          size_t b_stride, size_t pv_len, uint8_t* d_status, uint8_t* d_recv, void* stream) {
+    if (!c || c->vm != ZKV_VM_MIXED) return ZKV_ERR_WRONG_CTX;
+    if (n && (!d_vm || !d_seals || !d_in_a || !d_in_b || !d_status || b_stride < 32 || pv_len > b_stride || b_stride > 0xFFFFFFFFu)) return ZKV_ERR_INVALID_ARG;
+    if (!n) return ZKV_OK;
+    if (n > 0xFFFFFFF0u) return ZKV_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ctx_device_init(c);
+    if (rc != ZKV_OK) return rc;
+    return run_mixed(c, n, d_vm, d_seals, nullptr, ZKV_SEAL_BYTES, d_in_a, d_in_b, nullptr, (uint32_t)b_stride, (uint32_t)pv_len, d_status, d_recv,
+                     stream ? (hipStream_t)stream : c->stream);
+}
+ZKV_EXPORT int zkv_mixed_verify_batch(zkv_ctx* c, size_t n, const uint8_t* vm, const uint8_t* seal_blob, const uint64_t* seal_off, const uint8_t* in_a,
+                                      const uint8_t* in_b_blob, const uint64_t* in_b_off, uint8_t* status, uint8_t* recv) {
+    if (!c || c->vm != ZKV_VM_MIXED) return ZKV_ERR_WRONG_CTX;
+    if (n && (!vm || !seal_blob || !seal_off || !in_a || !in_b_blob || !in_b_off || !status)) return ZKV_ERR_INVALID_ARG;
+    if (!n) return ZKV_OK;
+    if (n > 0xFFFFFFF0u || !offsets_ok(seal_off, n) || !offsets_ok(in_b_off, n)) return ZKV_ERR_INVALID_ARG;
+    for (size_t i = 0; i < n; i++)                   // journal_digest is a B256 in the reference (risc0/verifier.rs:82)
+        if (vm[i] == ZKV_VM_RISC0 && in_b_off[i + 1] - in_b_off[i] != 32) return ZKV_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = ctx_device_init(c);
+    if (rc != ZKV_OK) return rc;
+    const uint64_t s0 = seal_off[0], sbytes = seal_off[n] - s0, b0 = in_b_off[0], bbytes = in_b_off[n] - b0;
+    const size_t need[8] = {n, (size_t)sbytes + 8, 8 * (n + 1), 32 * n, (size_t)bbytes + 8, 8 * (n + 1), n, 4 * n};
+    for (int k = 0; k < 8; k++) if ((rc = grow(&c->mx[MX_H_VM + k], &c->mx_cap[MX_H_VM + k], need[k])) != ZKV_OK) return rc;
+    hipStream_t s = c->stream;
+    if ((rc = order_after_previous(c, s)) != ZKV_OK) return rc;
+    std::vector<uint64_t> so(seal_off, seal_off + n + 1), bo(in_b_off, in_b_off + n + 1);
+    for (auto& v : so) v -= s0;
+    for (auto& v : bo) v -= b0;
+    HIP_TRY(hipMemcpyAsync(c->mx[MX_H_VM], vm, n, hipMemcpyHostToDevice, s));
+    if (sbytes) HIP_TRY(hipMemcpyAsync(c->mx[MX_H_SEALS], seal_blob + s0, (size_t)sbytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->mx[MX_H_SOFF], so.data(), 8 * (n + 1), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->mx[MX_H_A], in_a, 32 * n, hipMemcpyHostToDevice, s));
+    if (bbytes) HIP_TRY(hipMemcpyAsync(c->mx[MX_H_B], in_b_blob + b0, (size_t)bbytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->mx[MX_H_BOFF], bo.data(), 8 * (n + 1), hipMemcpyHostToDevice, s));
+    if ((rc = run_mixed(c, n, c->mx[MX_H_VM], c->mx[MX_H_SEALS], (const uint64_t*)c->mx[MX_H_SOFF], 0, c->mx[MX_H_A], c->mx[MX_H_B],
+                        (const uint64_t*)c->mx[MX_H_BOFF], 0, 0, c->mx[MX_H_ST], c->mx[MX_H_RV], s)) != ZKV_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(status, c->mx[MX_H_ST], n, hipMemcpyDeviceToHost, s));
+    if (recv) HIP_TRY(hipMemcpyAsync(recv, c->mx[MX_H_RV], 4 * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return ZKV_OK;
+}
+
 // ------------------------------------------------------------------ RISC Zero
 ZKV_EXPORT zkv_ctx* zkv_risc0_ctx_new(int device) {
     zkv_ctx* c = new (std::nothrow) zkv_ctx();
@@ -401,6 +572,7 @@ ZKV_EXPORT zkv_ctx* zkv_risc0_ctx_create(const uint8_t control_root[32], const u
 }
 ZKV_EXPORT void zkv_ctx_destroy(zkv_ctx* c) {
     if (!c) return;
+    for (auto& k : c->kid) { if (k) zkv_ctx_destroy(k); k = nullptr; }
     ctx_free_device(c);
     delete c;
 }
@@ -438,12 +610,14 @@ ZKV_EXPORT int zkv_risc0_verify(zkv_ctx* c, const uint8_t* seal, size_t seal_len
                                 uint8_t* status, uint8_t recv[4]) {
     uint64_t off[2] = {0, seal_len};
     uint8_t dummy = 0;
+    if (!seal && seal_len) return ZKV_ERR_INVALID_ARG;
     return zkv_risc0_verify_batch(c, 1, seal ? seal : &dummy, off, image_id, journal_digest, status, recv);
 }
 ZKV_EXPORT int zkv_risc0_verify_integrity(zkv_ctx* c, const uint8_t* seal, size_t seal_len, const uint8_t claim_digest[32], uint8_t* status,
                                           uint8_t recv[4]) {
     uint64_t off[2] = {0, seal_len};
     uint8_t dummy = 0;
+    if (!seal && seal_len) return ZKV_ERR_INVALID_ARG;
     return zkv_risc0_verify_integrity_batch(c, 1, seal ? seal : &dummy, off, claim_digest, status, recv);
 }
 ZKV_EXPORT int zkv_risc0_verify_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d_seals, const uint8_t* d_image_ids,
@@ -577,6 +751,7 @@ ZKV_EXPORT int zkv_sp1_verify_proof(zkv_ctx* c, const uint8_t vkey[32], const ui
                                     uint8_t* status, uint8_t recv[4]) {
     uint64_t poff[2] = {0, proof_len}, voff[2] = {0, pv_len};
     uint8_t dummy = 0;
+    if ((!pv && pv_len) || (!proof && proof_len)) return ZKV_ERR_INVALID_ARG;
     return zkv_sp1_verify_batch(c, 1, vkey, pv ? pv : &dummy, voff, proof ? proof : &dummy, poff, status, recv);
 }
 ZKV_EXPORT int zkv_sp1_verify_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d_vkeys, const uint8_t* d_pv, size_t pv_len, const uint8_t* d_proofs,
@@ -705,15 +880,7 @@ static int enqueue_wire_chunk(zkv_ctx* c, size_t m, const uint8_t* d_cd, const u
     enqueue_chunk(c, a, s, timed);
     return ZKV_OK;
 }
-static int wire_buffers(zkv_ctx* c) {
-    if (c->copy_stream) return ZKV_OK;
-    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    for (int b = 0; b < 2; b++) {
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_copied[b], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_decoded[b], hipEventDisableTiming));
-    }
-    return ZKV_OK;
-}
+static int wire_buffers(zkv_ctx*) { return ZKV_OK; }          // the copy stream and its events are created with the context
 
 // Host calldata: 8-12 KB per proof cross PCIe, as much time as the verification itself.  Chunks of at most 2^16 requests
 // (enough lanes to fill the chip) are double-buffered: the H2D copy of chunk k+1 runs on its own stream while chunk k is
@@ -910,10 +1077,12 @@ ZKV_EXPORT int zkv_groth16_verify_batch(zkv_ctx* c, size_t n, const uint8_t* pro
 
 // ------------------------------------------------------------------ Groth16 core pieces
 ZKV_EXPORT int zkv_ctx_vk_x_batch(zkv_ctx* c, size_t n, const uint8_t* var_signals, uint8_t* out) {
-    if (!c || c->vm == ZKV_VM_BN254 || c->vm == ZKV_VM_RISC0_SET) return ZKV_ERR_WRONG_CTX;
+    if (!c || c->vm == ZKV_VM_BN254 || c->vm == ZKV_VM_RISC0_SET || c->vm == ZKV_VM_MIXED) return ZKV_ERR_WRONG_CTX;
     if (c->vm == ZKV_VM_RISC0 && !c->initialized) return ZKV_ERR_INVALID_ARG;
     if (n && (!var_signals || !out)) return ZKV_ERR_INVALID_ARG;
     if (!n) return ZKV_OK;
+    // per-proof signals: two for the RISC Zero / SP1 keys, all n_ic - 1 for a generic key (k_vk_x reads n_var x 32 bytes per proof)
+    const size_t sig = 32 * (size_t)(c->vm == ZKV_VM_GROTH16 ? c->g_n_ic - 1 : 2);
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_ready(c, n);
     if (rc != ZKV_OK) return rc;
@@ -921,15 +1090,51 @@ ZKV_EXPORT int zkv_ctx_vk_x_batch(zkv_ctx* c, size_t n, const uint8_t* var_signa
     if ((rc = order_after_previous(c, c->stream)) != ZKV_OK) return rc;
     for (size_t base = 0; base < n; base += cap) {
         size_t m = n - base < cap ? n - base : cap;
-        if ((rc = grow(&c->d_blob, &c->blob_cap, m * 64 + 8)) != ZKV_OK) return rc;
+        if ((rc = grow(&c->d_blob, &c->blob_cap, m * sig + 8)) != ZKV_OK) return rc;
         if ((rc = grow(&c->d_pv, &c->pv_cap, m * 64 + 8)) != ZKV_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(c->d_blob, var_signals + 64 * base, 64 * m, hipMemcpyHostToDevice, c->stream));
+        if (sig) HIP_TRY(hipMemcpyAsync(c->d_blob, var_signals + sig * base, sig * m, hipMemcpyHostToDevice, c->stream));
         launch_vk_x(m, c->d_tab, nullptr, nullptr, c->d_blob, c->d_pv, c->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(out + 64 * base, c->d_pv, 64 * m, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     return ZKV_OK;
+}
+
+// ------------------------------------------------------------------ diagnostics: multiplication-rate microbenchmark
+ZKV_EXPORT int zkv_diag_mulmod_rate(int device, int kind, int waves_per_simd, uint32_t iters, double* mulmods_per_s, double* shader_clock_ghz) {
+    if ((kind != 0 && kind != 1) || waves_per_simd < 1 || waves_per_simd > 8 || !iters || !mulmods_per_s) return ZKV_ERR_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return ZKV_ERR_NO_DEVICE; }
+    if (device < 0 || device >= n || !device_is_gfx950(device)) return ZKV_ERR_NO_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    const unsigned blocks = (unsigned)p.multiProcessorCount * 4u * (unsigned)waves_per_simd;      // one 64-lane workgroup per wave slot
+    uint32_t* d_out = nullptr; unsigned long long* d_clk = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = ZKV_ERR_HIP;
+    float ms = 0;
+    unsigned long long clk[2] = {0, 0};
+    if (hipMalloc(&d_out, (size_t)blocks * 64 * 4) != hipSuccess || hipMalloc(&d_clk, 16) != hipSuccess) goto done;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) goto done;
+    launch_diag_mulmod(kind, blocks, iters / 8 + 1, d_out, d_clk, nullptr);               // warm-up (code fetch, clocks)
+    if (hipDeviceSynchronize() != hipSuccess) goto done;
+    if (hipEventRecord(e0, nullptr) != hipSuccess) goto done;
+    launch_diag_mulmod(kind, blocks, iters, d_out, d_clk, nullptr);
+    if (hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) goto done;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipMemcpy(clk, d_clk, 16, hipMemcpyDeviceToHost) != hipSuccess) goto done;
+    // four primitive calls per iteration and lane; kind 1 counts two multiplications per call
+    *mulmods_per_s = (double)blocks * 64.0 * 4.0 * (kind ? 2.0 : 1.0) * (double)iters / ((double)ms * 1e-3);
+    if (shader_clock_ghz) *shader_clock_ghz = clk[1] ? 0.1 * (double)clk[0] / (double)clk[1] : 0.0;     // s_memrealtime ticks at 100 MHz
+    rc = ZKV_OK;
+done:
+    if (rc != ZKV_OK) (void)hipGetLastError();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (d_out) (void)hipFree(d_out);
+    if (d_clk) (void)hipFree(d_clk);
+    return rc;
 }
 
 // ------------------------------------------------------------------ shared
@@ -942,6 +1147,13 @@ ZKV_EXPORT int zkv_ctx_set_lanes_per_proof(zkv_ctx* c, int lanes) {
 }
 ZKV_EXPORT int zkv_ctx_reserve(zkv_ctx* c, size_t n) {
     if (!c) return ZKV_ERR_INVALID_ARG;
+    if (c->vm == ZKV_VM_MIXED) {                         // either VM may own the whole batch
+        int rc = zkv_ctx_reserve(c->kid[0], n);
+        if (rc == ZKV_OK) rc = zkv_ctx_reserve(c->kid[1], n);
+        if (rc != ZKV_OK) return rc;
+        std::lock_guard<std::mutex> lk(c->mu);
+        return ctx_device_init(c);
+    }
     std::lock_guard<std::mutex> lk(c->mu);
     return ctx_ready(c, n);
 }
@@ -954,6 +1166,14 @@ ZKV_EXPORT int zkv_ctx_synchronize(zkv_ctx* c) {
 }
 ZKV_EXPORT int zkv_ctx_last_stage_ms(zkv_ctx* c, float out_ms[5]) {
     if (!c || !out_ms) return ZKV_ERR_INVALID_ARG;
+    if (c->vm == ZKV_VM_MIXED) {                         // the two sub-batches run one after the other: stage times add up
+        float a[5], b[5];
+        int rc = zkv_ctx_last_stage_ms(c->kid[0], a);
+        if (rc == ZKV_OK) rc = zkv_ctx_last_stage_ms(c->kid[1], b);
+        if (rc != ZKV_OK) return rc;
+        for (int i = 0; i < 5; i++) out_ms[i] = a[i] + b[i];
+        return ZKV_OK;
+    }
     if (!c->dev_ready) return ZKV_ERR_NO_DEVICE;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(c->ev[5]));

@@ -20,7 +20,7 @@
 #endif
 
 #if defined(ZKV_COUNT_FP_MUL)
-static unsigned long long zkv_fp_mul_counter = 0;
+static thread_local unsigned long long zkv_fp_mul_counter = 0;      // per thread: the lane-pair host emulation runs two
 #endif
 
 namespace zkv {

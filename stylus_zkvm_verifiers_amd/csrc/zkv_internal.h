@@ -90,6 +90,24 @@ void launch_finalexp2(size_t n, const Workspace& ws, uint8_t* status, hipStream_
 void launch_miller_w(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
 void launch_finalexp_w(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
 
+// mixed batches (k_mixed.hip): per-proof VM tag, device-side demultiplexing into two homogeneous sub-batches
+struct MixedArgs {
+    size_t n;
+    const uint8_t* vm;
+    const uint8_t* seals; const uint64_t* seal_off; uint32_t seal_stride;     // ragged (off) or fixed stride
+    const uint8_t* in_a;                                                       // n x 32
+    const uint8_t* in_b; const uint64_t* b_off; uint32_t b_stride, pv_len;     // ragged (off) or fixed stride + fixed SP1 length
+    const uint32_t* cnt; const uint32_t* totals;
+    uint32_t* pos; uint32_t* idx;                                              // pos[i] = slot (0xFFFFFFFF: unknown VM); idx[slot] = i
+    uint8_t* c_seals; uint32_t* c_len; uint8_t* c_a; uint8_t* c_b; uint64_t* c_pvoff; uint32_t* c_pvlen;   // compact records
+    uint8_t* status; uint8_t* recv;                                            // caller's outputs (unknown-VM proofs are answered here)
+};
+void launch_mixed_partition(const MixedArgs& a, uint32_t* cnt, uint32_t* totals, hipStream_t s);
+void launch_mixed_return(size_t m, const uint32_t* idx, const uint8_t* c_status, const uint8_t* c_recv, uint8_t* status, uint8_t* recv, hipStream_t s);
+
+// multiplication-rate microbenchmark (k_diag.hip)
+void launch_diag_mulmod(int kind, unsigned blocks, uint32_t iters, uint32_t* out, unsigned long long* clk, hipStream_t s);
+
 // precompile-level batches (k_precompile.hip)
 void launch_ecadd(size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok, hipStream_t s);
 void launch_ecmul(size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok, hipStream_t s);

@@ -38,6 +38,8 @@ class Groth16Verifier:
     def verify_batch(self, proofs, signals):
         """proofs: list of 256-byte (a, b, c) word blocks; signals: list of lists of 32-byte big-endian values -> bool array."""
         n = len(proofs)
+        if len(signals) != n:
+            raise ValueError('signals has %d entries for a batch of %d proofs' % (len(signals), n))
         for p in proofs:
             if len(p) != 256:
                 raise ValueError('a proof is 8 x 32 bytes')
@@ -49,6 +51,18 @@ class Groth16Verifier:
         out = np.zeros(max(n, 1), dtype=np.uint8)
         _lib.check(self._L.zkv_groth16_verify_batch(self._h, n, pb, sb, out.ctypes.data), 'zkv_groth16_verify_batch')
         return out[:n].astype(bool)
+
+    def vk_x_batch(self, signals):
+        """Groth16Verifier::compute_vk_x (common/groth16.rs:51-58): signals = list of n_ic - 1 32-byte big-endian values per proof
+        (each < R); returns the 64-byte affine vk_x per proof ((0,0) = infinity)."""
+        n = len(signals)
+        for s in signals:
+            if len(s) != self.n_ic - 1:
+                raise ValueError('expected %d signals per proof' % (self.n_ic - 1))
+        sb = b''.join(b''.join(bytes(x) for x in s) for s in signals) + b'\0'
+        out = np.zeros(max(64 * n, 1), dtype=np.uint8)
+        _lib.check(self._L.zkv_ctx_vk_x_batch(self._h, n, sb, out.ctypes.data), 'zkv_ctx_vk_x_batch')
+        return [out[64 * i:64 * i + 64].tobytes() for i in range(n)]
 
     def verify_proof_with_key(self, a, b, c, public_signals):
         """Single call with the reference's argument shapes: a [x, y], b [[x0, x1], [y0, y1]], c [x, y], signals as ints."""

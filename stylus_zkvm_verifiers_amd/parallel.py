@@ -1,7 +1,8 @@
 """Multi-GPU sharding of a proof batch: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm).
 
-Proofs are independent units: the batch shards by contiguous ranges after a seeded permutation, the
-verify path itself contains NO collective.  The only communication is distribution and collection around it:
+Proofs are independent units: the batch shards by contiguous ranges after a seeded permutation
+(`seeded_permutation`, `interleave`: RISC Zero and SP1 proofs end up evenly mixed in every shard, and so do the rejects
+that leave the pipeline early), the verify path itself contains NO collective.  The only communication is distribution and collection around it:
   * broadcast of the 64-byte verifier parameters (control_root, bn254_control_id) from rank 0 -- every rank derives
     the same selector and device tables from them (the VK itself is a compiled-in constant, as in the reference);
   * scatter of seal / input rows from rank 0 (point-to-point sends, one direct xGMI link per peer);
@@ -89,3 +90,98 @@ def gather_status(local_status, n_total, device, dst=0):
     if local_status.numel():
         dist.send(local_status.contiguous(), dst=dst)
     return None
+
+
+def gather_rows(local, n_total, device, dst=0):
+    """Collect contiguous row shards (uint8 [k, w], split as shard_bounds) on rank `dst`; returns [n_total, w] there, None elsewhere."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    w = local.shape[1]
+    if rank == dst:
+        out = torch.empty((n_total, w), dtype=torch.uint8, device=device)
+        for peer in range(world):
+            plo, phi = shard_bounds(n_total, world, peer)
+            if peer == dst:
+                out[plo:phi].copy_(local)
+            elif phi > plo:
+                buf = torch.empty((phi - plo, w), dtype=torch.uint8, device=device)
+                dist.recv(buf, src=peer)
+                out[plo:phi].copy_(buf)
+        return out
+    if local.numel():
+        dist.send(local.contiguous(), dst=dst)
+    return None
+
+
+# ---------------------------------------------------------------- BASELINE config 4: mixed RISC Zero + SP1 batch on the root
+def splitmix64(x):
+    """Vectorised SplitMix64 finaliser on uint64 arrays (counter-based: element i depends on x[i] only)."""
+    import numpy as np
+    x = (np.asarray(x, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15))
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def seeded_permutation(n, seed):
+    """Permutation of range(n) that depends on (n, seed) only: stable argsort of the SplitMix64 keys of seed + i."""
+    import numpy as np
+    with np.errstate(over='ignore'):
+        keys = splitmix64(np.arange(n, dtype=np.uint64) + np.uint64(seed & 0xFFFFFFFFFFFFFFFF))
+    return np.argsort(keys, kind='stable')
+
+
+def interleave(parts, seed):
+    """parts: list of (vm_tag, seals uint8[k,260], in_a uint8[k,32], in_b uint8[k,w]) -- one entry per VM, any widths w >= 32.
+    Returns (vm uint8[n], seals, in_a, in_b uint8[n, max w] zero-padded, perm) with row i = row perm[i] of the VM-major
+    concatenation: the mixed batch of SURVEY.md 8(d) config 4 ("interleaved by seeded permutation")."""
+    import numpy as np
+    width = max(p[3].shape[1] for p in parts)
+    vm = np.concatenate([np.full(len(p[1]), p[0], dtype=np.uint8) for p in parts])
+    seals = np.concatenate([p[1] for p in parts])
+    in_a = np.concatenate([p[2] for p in parts])
+    in_b = np.zeros((len(vm), width), dtype=np.uint8)
+    at = 0
+    for p in parts:
+        in_b[at:at + len(p[1]), :p[3].shape[1]] = p[3]
+        at += len(p[1])
+    perm = seeded_permutation(len(vm), seed)
+    return vm[perm], seals[perm], in_a[perm], in_b[perm], perm
+
+
+def mixed_step(params, root, n_total, verify_fn, dev, cdev, sync=lambda: None):
+    """One pass of config 4: rank 0 holds the mixed batch `root` = (vm [n], seals [n,260], in_a [n,32], in_b [n,w]) as uint8
+    tensors on `cdev`; the 64 bytes of verifier parameters are broadcast, the four row arrays are scattered (contiguous
+    shards, one direct link per peer), every rank verifies its shard with `verify_fn(params, vm, seals, in_a, in_b)` (tensors on
+    `dev`; returns the shard's status tensor) and the status bytes are gathered in the original order.
+    Returns (status on rank 0 / None elsewhere, {'distribute','verify','collect'} seconds on this rank)."""
+    import time
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    t0 = time.perf_counter()
+    widths = (1, 260, 32, None)
+    if world > 1:
+        params = broadcast_bytes(params, 64, cdev)
+        w = torch.zeros(1, dtype=torch.int64, device=cdev)
+        if rank == 0:
+            w[0] = root[3].shape[1]
+        dist.broadcast(w, src=0)
+        shard = []
+        for k, wid in enumerate(widths):
+            wid = int(w.item()) if wid is None else wid
+            full = root[k].reshape(n_total, wid) if rank == 0 else None
+            shard.append(scatter_rows(full, n_total, wid, cdev))
+    else:
+        shard = [root[0].reshape(n_total, 1), root[1], root[2], root[3]]
+    local = [t if t.device == dev else t.to(dev) for t in shard]
+    sync()
+    t1 = time.perf_counter()
+    st = verify_fn(params, local[0].reshape(-1), local[1], local[2], local[3])
+    sync()
+    t2 = time.perf_counter()
+    if world > 1:
+        out = gather_status(st if st.device == cdev else st.to(cdev), n_total, cdev)
+    else:
+        out = st
+    sync()
+    t3 = time.perf_counter()
+    return out, {'distribute': t1 - t0, 'verify': t2 - t1, 'collect': t3 - t2}

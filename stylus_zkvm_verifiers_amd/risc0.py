@@ -25,6 +25,13 @@ def _cat32(items, what):
     return b''.join(bytes(x) for x in items) + b'\0'
 
 
+def _same_len(n, **lists):
+    """Every per-proof list of a batch must have one entry per proof: the C side reads n rows from each."""
+    for name, v in lists.items():
+        if len(v) != n:
+            raise ValueError('%s has %d entries for a batch of %d proofs' % (name, len(v), n))
+
+
 class RiscZeroVerifier:
     def __init__(self, device=0):
         self._L = _lib.lib()
@@ -90,6 +97,7 @@ class RiscZeroVerifier:
     def verify_batch(self, seals, image_ids, journal_digests):
         """One status byte per proof (errors.STATUS_*), plus the received selector of mismatching seals."""
         n = len(seals)
+        _same_len(n, image_ids=image_ids, journal_digests=journal_digests)
         blob, off = _blob(seals)
         st = np.zeros(n, dtype=np.uint8); rv = np.zeros((n, 4), dtype=np.uint8)
         _lib.check(self._L.zkv_risc0_verify_batch(self._h, n, blob, off.ctypes.data, _cat32(image_ids, 'image_id'),
@@ -99,6 +107,7 @@ class RiscZeroVerifier:
 
     def verify_integrity_batch(self, seals, claim_digests):
         n = len(seals)
+        _same_len(n, claim_digests=claim_digests)
         blob, off = _blob(seals)
         st = np.zeros(n, dtype=np.uint8); rv = np.zeros((n, 4), dtype=np.uint8)
         _lib.check(self._L.zkv_risc0_verify_integrity_batch(self._h, n, blob, off.ctypes.data, _cat32(claim_digests, 'claim_digest'),
@@ -166,6 +175,7 @@ class RiscZeroVerifierSet:
 
     def verify_batch(self, instances, seals, image_ids, journal_digests):
         n = len(seals)
+        _same_len(n, instances=instances, image_ids=image_ids, journal_digests=journal_digests)
         blob, off = _blob(seals)
         idx = np.ascontiguousarray(instances, dtype=np.uint32)
         st = np.zeros(n, dtype=np.uint8); rv = np.zeros((n, 4), dtype=np.uint8)
@@ -180,6 +190,7 @@ class RiscZeroVerifierSet:
 
     def vk_x_batch(self, instances, var_signals):
         n = len(var_signals)
+        _same_len(n, instances=instances)
         idx = np.ascontiguousarray(instances, dtype=np.uint32)
         blob = b''.join(bytes(a) + bytes(b) for a, b in var_signals) + b'\0'
         out = np.zeros(max(64 * n, 1), dtype=np.uint8)

@@ -6,7 +6,7 @@ import numpy as np
 
 from . import _lib
 from .errors import STATUS_OK, STATUS_SELECTOR_MISMATCH, VM_SP1, VerifierError
-from .risc0 import _blob, _cat32
+from .risc0 import _blob, _cat32, _same_len
 
 
 class Sp1Verifier:
@@ -44,6 +44,7 @@ class Sp1Verifier:
     # ---- batch
     def verify_batch(self, program_vkeys, public_values, proofs):
         n = len(proofs)
+        _same_len(n, program_vkeys=program_vkeys, public_values=public_values)
         pblob, poff = _blob(proofs)
         vblob, voff = _blob(public_values)
         st = np.zeros(n, dtype=np.uint8); rv = np.zeros((n, 4), dtype=np.uint8)

@@ -202,6 +202,58 @@ def make_batch(vm, base_seal, n, seed, pool=16, mutate_every=64, classes=MUTATIO
     return seals, mutated, mclass, flip_input
 
 
+def _lane(args):
+    vm, base_seal, n, seed, pool, mutate_every, classes = args
+    return make_batch(vm, base_seal, n, seed, pool=pool, mutate_every=mutate_every, classes=classes)
+
+
+def make_batch_parallel(vm, base_seal, n, seed, pool=16, mutate_every=64, classes=MUTATION_CLASSES, lanes=16, workers=None, cache=True):
+    """make_batch for large n: the batch is the concatenation of `lanes` independent generator lanes (lane j = make_batch of its
+    slice with seed + j), run in worker processes.  The result depends on (n, seed, lanes) only, never on the worker count.
+    Workers are forked BEFORE the caller touches the GPU (pure Python big-int work; they never call into HIP).  Batches of
+    2^16 proofs and more are kept in ZKV_SYNTH_CACHE (default /tmp/zkv_synth_cache) so that repeated runs on one box -- bench,
+    then the rocprofv3 passes of the same command -- do not regenerate them."""
+    import hashlib
+    import os
+    if n < 4096 or lanes <= 1:
+        return make_batch(vm, base_seal, n, seed, pool=pool, mutate_every=mutate_every, classes=classes)
+    cache_file = None
+    if cache and n >= (1 << 16):
+        d = os.environ.get('ZKV_SYNTH_CACHE', '/tmp/zkv_synth_cache')
+        key = hashlib.sha256(repr((vm, bytes(base_seal).hex(), n, seed, pool, mutate_every, tuple(classes), lanes, 1)).encode()).hexdigest()[:24]
+        cache_file = os.path.join(d, 'batch_%s.npz' % key)
+        try:
+            z = np.load(cache_file)                      # our own file: plain arrays, no pickle
+            return z['seals'], z['mutated'], z['mclass'], z['flip']
+        except (OSError, ValueError, KeyError):
+            pass
+    q, r = divmod(n, lanes)
+    sizes = [q + (1 if j < r else 0) for j in range(lanes)]
+    if mutate_every:                                     # keep every lane a multiple of the mutation period (same global pattern)
+        per = ((n // lanes) // mutate_every) * mutate_every
+        if per:
+            sizes = [per] * (lanes - 1) + [n - per * (lanes - 1)]
+    jobs = [(vm, bytes(base_seal), sz, seed + 0x9E3779B1 * j, pool, mutate_every, tuple(classes)) for j, sz in enumerate(sizes) if sz]
+    if workers is None:
+        workers = int(os.environ.get('ZKV_SYNTH_WORKERS', '0')) or min(len(jobs), len(os.sched_getaffinity(0)))
+    if workers <= 1:
+        parts = [_lane(j) for j in jobs]
+    else:
+        import multiprocessing as mp
+        with mp.get_context('fork').Pool(workers) as ex:
+            parts = ex.map(_lane, jobs, chunksize=1)
+    out = tuple(np.concatenate([p[k] for p in parts]) for k in range(4))
+    if cache_file:
+        try:
+            os.makedirs(os.path.dirname(cache_file), exist_ok=True)
+            tmp = cache_file + '.%d.tmp.npz' % os.getpid()
+            np.savez(tmp, seals=out[0], mutated=out[1], mclass=out[2], flip=out[3])
+            os.replace(tmp, cache_file)
+        except OSError:
+            pass
+    return out
+
+
 # ---------------------------------------------------------------- eth_call calldata of a batch (wire layer)
 def _u8_array_words(dst, col0, data):
     """dst[:, col0:] receives the ABI encoding of uint8[] `data` (n x L): length word + one 32-byte word per byte."""

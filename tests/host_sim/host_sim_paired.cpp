@@ -2,6 +2,7 @@
 // GPU runs, with the two lanes of a pair played by two threads and the DPP operand exchange by a shared slot and a
 // barrier.  TEST ONLY.
 #define ZKV_PAIRED 1
+#define ZKV_COUNT_FP_MUL 1
 #include <atomic>
 #include <stdint.h>
 #include <string.h>
@@ -26,7 +27,7 @@ uint32_t zkv_partner_u32(uint32_t x) {
 }
 using namespace zkv;
 
-struct Job { const VkTables* t; uint32_t flags; const uint32_t* norm48; const uint32_t* b32; int sub_ok[2]; int accept[2]; };
+struct Job { const VkTables* t; uint32_t flags; const uint32_t* norm48; const uint32_t* b32; int sub_ok[2]; int accept[2]; unsigned long long muls[2][3]; };
 
 static void lane(Job* j, uint32_t par) {
     tl_par = par;
@@ -34,7 +35,10 @@ static void lane(Job* j, uint32_t par) {
     for (int k = 0; k < 6; k++) memcpy(nf[k]->v, j->norm48 + 8 * k, 32);
     Fp2 bx, by;
     memcpy(bx.h.v, j->b32 + 8 * par, 32); memcpy(by.h.v, j->b32 + 16 + 8 * par, 32);
+    unsigned long long c0 = zkv_fp_mul_counter;
+    j->muls[par][0] = j->muls[par][1] = j->muls[par][2] = 0;
     bool sub = (j->flags & FL_B_INF) ? true : g2_in_subgroup(bx, by);
+    j->muls[par][0] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
     j->sub_ok[par] = sub ? 1 : 0;
     if (!sub) { j->accept[par] = 0; return; }
     // lane-private half slots (f2w = 8) for f, T and the accumulator; full-layout slots (f2w = 16) for the cold values
@@ -45,8 +49,14 @@ static void lane(Job* j, uint32_t par) {
     MRef ab = m_ref((uint32_t*)j->t->f_alpha_beta + 8 * par, 1, 16);
     MRef F = m_ref(full + 8 * par, 1, 16), E = m_ref(full + 96 + 8 * par, 1, 16);
     f12m_mul(F, fm, ab);
+    j->muls[par][1] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
     j->accept[par] = final_exp_is_one_m(F, E, m_off(E, 96), m_off(E, 192), m_off(E, 288), m_off(E, 384), fm) ? 1 : 0;
+    j->muls[par][2] = zkv_fp_mul_counter - c0;
 }
+// Fp multiplications (a lane's Fp2 product counts 2, fp_mul 1) spent by BOTH lanes of the pair in g2chk, miller, finalexp
+// during the last hs2_pairing call: the work unit of the secondary roofline (bench.py, roofline.mulmod).
+static unsigned long long g_pair_muls[3];
+extern "C" void hs2_stage_muls(unsigned long long* out) { for (int k = 0; k < 3; k++) out[k] = g_pair_muls[k]; }
 
 extern "C" int hs2_pairing(const void* tables, uint32_t flags, const uint32_t* norm48, const uint32_t* b32, int* sub_ok) {
     Job j; j.t = (const VkTables*)tables; j.flags = flags; j.norm48 = norm48; j.b32 = b32;
@@ -54,6 +64,7 @@ extern "C" int hs2_pairing(const void* tables, uint32_t flags, const uint32_t* n
     std::thread t1(lane, &j, 1u);
     lane(&j, 0u);
     t1.join();
+    for (int k = 0; k < 3; k++) g_pair_muls[k] = j.muls[0][k] + j.muls[1][k];
     if (j.sub_ok[0] != j.sub_ok[1] || j.accept[0] != j.accept[1]) return -1;     // the pair must agree
     *sub_ok = j.sub_ok[0];
     return j.accept[0];

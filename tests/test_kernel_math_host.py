@@ -302,3 +302,39 @@ def test_one_proof_per_lane_multipliers_at_the_edge_of_their_contract(hs):
                 run(a0, a1, b0, b1)
     for _ in range(300):
         run(*(rng.randrange(4 * P) for _ in range(4)))
+
+
+def _stage_mul_counts(hs, hs_pair, real_proofs):
+    """Fp multiplications per stage for the two real proofs: one-proof-per-lane counts (hs_stage_muls: an Fp2 product = 3) and
+    lane-pair counts (hs2_stage_muls: both lanes, a lane's Fp2 product = 2)."""
+    r0, s = real_proofs['risc0'], real_proofs['sp1']
+    cr, cid = H(r0['control_root']), H(r0['bn254_control_id'])
+    v = m.Risc0Verifier(); v.initialize(cr, cid)
+    sig = v.signals(m.receipt_claim_ok_digest(H(r0['image_id']), H(r0['journal_digest'])))
+    cases = {'risc0': (0, cr, cid, H(r0['seal'])[4:], m.be32(sig[2]), m.be32(sig[3])),
+             'sp1': (1, None, None, H(s['proof'])[4:], H(s['vkey']), m.be32(m.sp1_hash_public_values(H(s['public_values']))))}
+    out = {}
+    for vm, args in cases.items():
+        assert hs.hs_groth16(*args) == 1
+        lane = (C.c_ulonglong * 5)(); hs.hs_stage_muls(lane)
+        fl = C.c_uint32(0); norm = (C.c_uint32 * 48)(); b = (C.c_uint32 * 32)(); sub = C.c_int(0)
+        t = hs.hs_prepare(*args, C.byref(fl), norm, b)
+        assert hs_pair.hs2_pairing(t, fl.value, norm, b, C.byref(sub)) == 1
+        pair = (C.c_ulonglong * 3)(); hs_pair.hs2_stage_muls(pair)
+        out[vm] = {'lane': dict(zip(['prep', 'msm', 'g2chk', 'miller', 'finalexp'], [int(x) for x in lane])),
+                   'pair': dict(zip(['g2chk', 'miller', 'finalexp'], [int(x) for x in pair]))}
+        out[vm]['total_lane_pipeline'] = sum(out[vm]['lane'].values())
+        out[vm]['total_pair_pipeline'] = out[vm]['lane']['prep'] + out[vm]['lane']['msm'] + sum(out[vm]['pair'].values())
+    return out
+
+
+def test_paired_stage_mul_counts(hs, hs_pair, real_proofs):
+    """The work figure of the secondary roofline (bench.py roofline.mulmod): tests/golden/stage_mul_counts.json must be what
+    the op counters of the host builds report for the two real proofs (regenerate with ZKV_WRITE_MUL_COUNTS=1)."""
+    import json
+    got = _stage_mul_counts(hs, hs_pair, real_proofs)
+    path = os.path.join(HERE, 'golden', 'stage_mul_counts.json')
+    if os.environ.get('ZKV_WRITE_MUL_COUNTS'):
+        with open(path, 'w') as f:
+            json.dump(got, f, indent=1, sort_keys=True)
+    assert json.load(open(path)) == got
