@@ -47,6 +47,7 @@ def lib():
         L.zkvo_sp1_version.restype = C.c_char_p
         L.zkvo_groth16_vk_x.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_char_p]
         L.zkvo_groth16_verify_vk.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
+        L.zkvo_groth16_vk_x_vk.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p]
         L.zkvo_status_abi_encode.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
         L.zkvo_count_enable.argtypes = [C.c_int]
         L.zkvo_count_read.restype = C.c_uint64
@@ -175,6 +176,13 @@ def sp1_hash_public_values(pv):
 def groth16_vk_x(vm, signals):
     o = _buf(64)
     ok = lib().zkvo_groth16_vk_x(vm, b''.join(signals), len(signals), o)
+    return o.raw if ok else None
+
+
+def groth16_vk_x_vk(vk_words, n_ic, signals):
+    """compute_vk_x (groth16.rs:51-58) for an arbitrary key: 64-byte affine point, None when a precompile call fails."""
+    o = _buf(64)
+    ok = lib().zkvo_groth16_vk_x_vk(bytes(vk_words), n_ic, b''.join(signals) + b'\0', len(signals), o)
     return o.raw if ok else None
 
 

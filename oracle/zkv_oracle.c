@@ -622,44 +622,15 @@ static void hex32(uint8_t out[32], const char *h) {
 /* ------------------------------------------------------------------ common/groth16.rs */
 enum { ST_OK = 0, ST_VERIFICATION_FAILED = 1, ST_INVALID_INITIALIZATION = 2, ST_ALREADY_INITIALIZED = 3, ST_INVALID_PROOF_DATA = 4, ST_SELECTOR_MISMATCH = 5 };
 
-/* groth16.rs:23-49.  words: a[2], b[4] (x0,x1,y0,y1 as stored), c[2]; signals n x 32 bytes BE.  vm: 0 risc0 (A negated), 1 sp1 */
-static int groth16_verify(int vm, const vk_hex *vk, const uint8_t *proof_words /*8x32*/, const uint8_t *signals, int n_sig) {
-    if (n_sig + 1 != vk->n_ic) return 0;
-    for (int i = 0; i < n_sig; i++) { uint64_t s[4]; u256_from_be(s, signals + 32 * i); if (u256_geq(s, RM)) return 0; }
-    /* compute_vk_x: groth16.rs:51-58 */
-    uint8_t vkx[64], buf[128], mul[64];
-    hex32(vkx, vk->ic[0][0]); hex32(vkx + 32, vk->ic[0][1]);
-    for (int i = 0; i < n_sig; i++) {
-        hex32(buf, vk->ic[i + 1][0]); hex32(buf + 32, vk->ic[i + 1][1]); memcpy(buf + 64, signals + 32 * i, 32);
-        if (!zkvo_ecmul(buf, 96, mul)) return 0;
-        memcpy(buf, vkx, 64); memcpy(buf + 64, mul, 64);
-        if (!zkvo_ecadd(buf, 128, vkx)) return 0;
-    }
-    /* verify_pairing: groth16.rs:86-107 */
-    uint8_t cd[768], a[64];
-    memcpy(a, proof_words, 64);
-    if (vm == 0) {                                   /* negate_g1: groth16.rs:75-84, Q.wrapping_sub(y) */
-        uint64_t x[4], y[4]; u256_from_be(x, a); u256_from_be(y, a + 32);
-        if (!(u256_is_zero(x) && u256_is_zero(y))) { uint64_t ny[4]; u256_sub(ny, PM, y); u256_to_be(a + 32, ny); }
-    }
-    uint8_t *p = cd;
-    memcpy(p, a, 64); memcpy(p + 64, proof_words + 64, 128); p += 192;
-    hex32(p, vk->alpha[0]); hex32(p + 32, vk->alpha[1]); for (int k = 0; k < 4; k++) hex32(p + 64 + 32 * k, vk->beta[k]); p += 192;
-    memcpy(p, vkx, 64); for (int k = 0; k < 4; k++) hex32(p + 64 + 32 * k, vk->gamma[k]); p += 192;
-    memcpy(p, proof_words + 192, 64); for (int k = 0; k < 4; k++) hex32(p + 64 + 32 * k, vk->delta[k]);
-    uint8_t out[32];
-    if (!zkvo_ecpairing(cd, 768, out)) return 0;
-    for (int i = 0; i < 32; i++) if (out[i]) return 1;
-    return 0;
-}
 /* Groth16Verifier::verify_proof_with_key for an ARBITRARY verification key (groth16.rs:23-49 is generic over `vk`).
  * vk_words: alpha1.x alpha1.y | beta2 x[0] x[1] y[0] y[1] | gamma2 (4) | delta2 (4) | ic[i].x ic[i].y ..., 32-byte big-endian.
+ * proof_words: a[2], b[4] (x0,x1,y0,y1 as stored), c[2]; signals n x 32 bytes BE.
  * vm: 0 = VMType::Risc0 (A negated), 1 = VMType::Sp1.  Returns the function's bool. */
-ZKVO_API int zkvo_groth16_verify_vk(int vm, const uint8_t *vk_words, int n_ic, const uint8_t *proof_words, const uint8_t *signals, int n_sig) {
+/* compute_vk_x: groth16.rs:51-58 -- one ecMul and one ecAdd precompile call per signal */
+ZKVO_API int zkvo_groth16_vk_x_vk(const uint8_t *vk_words, int n_ic, const uint8_t *signals, int n_sig, uint8_t vkx[64]) {
     if (n_sig + 1 != n_ic) return 0;
-    for (int i = 0; i < n_sig; i++) { uint64_t sv[4]; u256_from_be(sv, signals + 32 * i); if (u256_geq(sv, RM)) return 0; }
     const uint8_t *ic = vk_words + 448;
-    uint8_t vkx[64], buf[128], mul[64];
+    uint8_t buf[128], mul[64];
     memcpy(vkx, ic, 64);
     for (int i = 0; i < n_sig; i++) {
         memcpy(buf, ic + 64 * (i + 1), 64); memcpy(buf + 64, signals + 32 * i, 32);
@@ -667,13 +638,21 @@ ZKVO_API int zkvo_groth16_verify_vk(int vm, const uint8_t *vk_words, int n_ic, c
         memcpy(buf, vkx, 64); memcpy(buf + 64, mul, 64);
         if (!zkvo_ecadd(buf, 128, vkx)) return 0;
     }
+    return 1;
+}
+ZKVO_API int zkvo_groth16_verify_vk(int vm, const uint8_t *vk_words, int n_ic, const uint8_t *proof_words, const uint8_t *signals, int n_sig) {
+    if (n_sig + 1 != n_ic) return 0;                                            /* groth16.rs:32 */
+    for (int i = 0; i < n_sig; i++) { uint64_t sv[4]; u256_from_be(sv, signals + 32 * i); if (u256_geq(sv, RM)) return 0; }
+    uint8_t vkx[64];
+    if (!zkvo_groth16_vk_x_vk(vk_words, n_ic, signals, n_sig, vkx)) return 0;   /* :36-39 */
+    /* verify_pairing: groth16.rs:86-107 */
     uint8_t cd[768], a[64];
     memcpy(a, proof_words, 64);
-    if (vm == 0) {
+    if (vm == 0) {                                   /* negate_g1: groth16.rs:75-84, Q.wrapping_sub(y) */
         uint64_t x[4], y[4]; u256_from_be(x, a); u256_from_be(y, a + 32);
         if (!(u256_is_zero(x) && u256_is_zero(y))) { uint64_t ny[4]; u256_sub(ny, PM, y); u256_to_be(a + 32, ny); }
     }
-    uint8_t *p = cd;
+    uint8_t *p = cd;                                 /* pairing_check: groth16.rs:109-128, 4 x 192 bytes */
     memcpy(p, a, 64); memcpy(p + 64, proof_words + 64, 128); p += 192;
     memcpy(p, vk_words, 64); memcpy(p + 64, vk_words + 64, 128); p += 192;
     memcpy(p, vkx, 64); memcpy(p + 64, vk_words + 192, 128); p += 192;
@@ -683,18 +662,22 @@ ZKVO_API int zkvo_groth16_verify_vk(int vm, const uint8_t *vk_words, int n_ic, c
     for (int i = 0; i < 32; i++) if (out[i]) return 1;
     return 0;
 }
+/* the two hard-coded keys in the word layout above */
+static int vk_words_of(const vk_hex *vk, uint8_t w[448 + 64 * 6]) {
+    hex32(w, vk->alpha[0]); hex32(w + 32, vk->alpha[1]);
+    for (int k = 0; k < 4; k++) { hex32(w + 64 + 32 * k, vk->beta[k]); hex32(w + 192 + 32 * k, vk->gamma[k]); hex32(w + 320 + 32 * k, vk->delta[k]); }
+    for (int i = 0; i < vk->n_ic; i++) { hex32(w + 448 + 64 * i, vk->ic[i][0]); hex32(w + 480 + 64 * i, vk->ic[i][1]); }
+    return vk->n_ic;
+}
+static int groth16_verify(int vm, const vk_hex *vk, const uint8_t *proof_words /*8x32*/, const uint8_t *signals, int n_sig) {
+    uint8_t w[448 + 64 * 6];
+    const int n_ic = vk_words_of(vk, w);
+    return zkvo_groth16_verify_vk(vm, w, n_ic, proof_words, signals, n_sig);
+}
 ZKVO_API int zkvo_groth16_vk_x(int vm, const uint8_t *signals, int n_sig, uint8_t out[64]) {
-    const vk_hex *vk = vm == 0 ? &RISC0_VK : &SP1_VK;
-    uint8_t buf[128], mul[64];
-    if (n_sig + 1 != vk->n_ic) return 0;
-    hex32(out, vk->ic[0][0]); hex32(out + 32, vk->ic[0][1]);
-    for (int i = 0; i < n_sig; i++) {
-        hex32(buf, vk->ic[i + 1][0]); hex32(buf + 32, vk->ic[i + 1][1]); memcpy(buf + 64, signals + 32 * i, 32);
-        if (!zkvo_ecmul(buf, 96, mul)) return 0;
-        memcpy(buf, out, 64); memcpy(buf + 64, mul, 64);
-        if (!zkvo_ecadd(buf, 128, out)) return 0;
-    }
-    return 1;
+    uint8_t w[448 + 64 * 6];
+    const int n_ic = vk_words_of(vm == 0 ? &RISC0_VK : &SP1_VK, w);
+    return zkvo_groth16_vk_x_vk(w, n_ic, signals, n_sig, out);
 }
 
 /* ------------------------------------------------------------------ risc0 */

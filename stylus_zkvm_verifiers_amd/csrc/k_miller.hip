@@ -21,7 +21,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_miller(size_t n, const VkTables* 
     by.c0 = ws_ld(ws.prep, ws.cap, 48, i); by.c1 = ws_ld(ws.prep, ws.cap, 56, i);
     LRef fm = l_ref(lds + threadIdx.x);
     LRef tm = l_ref(lds + 96 * ZKV_BLOCK + threadIdx.x);
-    miller_loop_m(*vk, flags, nm, bx, by, true, fm, tm);
+    miller_loop_m(vk, flags, nm, bx, by, fm, tm);
     MRef ab = m_ref((uint32_t*)(vk->f_alpha_beta), 1);
     MRef out = m_ref(ws.f + i, (uint32_t)ws.cap);
     f12m_mul(out, fm, ab);

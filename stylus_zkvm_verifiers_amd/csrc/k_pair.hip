@@ -39,7 +39,7 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller2(size_t n, const VkTabl
     Fp2 bx = ld_b(ws, 32, i), by = ld_b(ws, 48, i);
     LRef fm = l_ref(lds + threadIdx.x);
     LRef tm = l_ref(lds + 48 * ZKV_BLOCK + threadIdx.x);
-    miller_loop_m(*vk, flags, nm, bx, by, true, fm, tm);
+    miller_loop_m(vk, flags, nm, bx, by, fm, tm);
     MRef ab = m_ref((uint32_t*)(vk->f_alpha_beta) + 8 * par, 1, 16);
     MRef out = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, (uint32_t)ws.cap, 16);
     f12m_mul(out, fm, ab);

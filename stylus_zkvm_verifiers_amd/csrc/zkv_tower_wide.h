@@ -34,10 +34,16 @@ ZKV_HD void wide_fence() {
     zkv_wide_host_barrier();
 #endif
 }
-// On the device the lanes of a group run in lockstep, so every load of a routine has been issued when the first store is;
-// the host emulation needs a rendezvous at that point.
+// Between the loads of a routine and its stores ("all loads before any store": pair q reads every coefficient of a slot that
+// another pair is about to overwrite).  On the device the lanes of a group share one wavefront and run in lockstep, but nothing
+// stops the COMPILER from sinking a load below another lane group's store, so the point is pinned with a scheduling barrier
+// (no instruction is emitted, no code motion across it) plus a work-group fence that orders the memory operations themselves;
+// the host emulation needs a real rendezvous here.
 ZKV_HD void wide_sync() {
-#if !defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#else
     zkv_wide_host_barrier();
 #endif
 }

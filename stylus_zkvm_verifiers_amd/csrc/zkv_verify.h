@@ -208,11 +208,15 @@ template <class RF> ZKV_HD void var_line_mul(RF fm, const Fp2& l0, const Fp2& l1
     Fp2 c3 = f2_mul_fp(l1, xs), c4 = f2_mul_fp(l3, ys);
     f12m_mul_by_034(fm, &l0, &c3, &c4);
 }
+// vkp: the context's tables, or nullptr for a single variable pair without fixed pairs (the ecPairing seam, e(alpha, beta) at set-up).
 template <class RF, class RT>
-ZKV_HD void miller_loop_m(const VkTables& vk, uint32_t flags, const G1Norm& n, const Fp2& bx, const Fp2& by,
-                          bool with_fixed, RF fm, RT tm) {
+ZKV_HD void miller_loop_m(const VkTables* vkp, uint32_t flags, const G1Norm& n, const Fp2& bx, const Fp2& by, RF fm, RT tm) {
+    const bool with_fixed = vkp != nullptr;
+    const VkTables* vkq = with_fixed ? vkp : nullptr;
     bool do_ab = !(flags & (FL_A_INF | FL_B_INF));
-    bool do_l = with_fixed && !(flags & FL_L_INF) && !vk.skip_fixed[0], do_c = with_fixed && !(flags & FL_C_INF) && !vk.skip_fixed[1];
+    bool do_l = with_fixed && !(flags & FL_L_INF) && !vkq->skip_fixed[0], do_c = with_fixed && !(flags & FL_C_INF) && !vkq->skip_fixed[1];
+    const LineAffC* lines0 = with_fixed ? vkq->lines[0] : nullptr;
+    const LineAffC* lines1 = with_fixed ? vkq->lines[1] : nullptr;
     f12m_set_one(fm);
     m_st_f2(tm, 0, bx); m_st_f2(tm, 1, by); m_st_f2(tm, 2, f2_one());
     Fp2 nby = f2_neg(by);
@@ -225,8 +229,8 @@ ZKV_HD void miller_loop_m(const VkTables& vk, uint32_t flags, const G1Norm& n, c
             g2m_line_dbl(tm, &l0, &l1, &l3);
             var_line_mul(fm, l0, l1, l3, n.axs, n.ays);
         }
-        if (do_l) fixed_line_mul(fm, vk.lines[0][li], n.lxs, n.lys);
-        if (do_c) fixed_line_mul(fm, vk.lines[1][li], n.cxs, n.cys);
+        if (do_l) fixed_line_mul(fm, lines0[li], n.lxs, n.lys);
+        if (do_c) fixed_line_mul(fm, lines1[li], n.cxs, n.cys);
         li++;
         int d = ate_naf(i);
         if (d != 0) {
@@ -235,8 +239,8 @@ ZKV_HD void miller_loop_m(const VkTables& vk, uint32_t flags, const G1Norm& n, c
                 g2m_line_add(tm, &bx, &qy, &l0, &l1, &l3);
                 var_line_mul(fm, l0, l1, l3, n.axs, n.ays);
             }
-            if (do_l) fixed_line_mul(fm, vk.lines[0][li], n.lxs, n.lys);
-            if (do_c) fixed_line_mul(fm, vk.lines[1][li], n.cxs, n.cys);
+            if (do_l) fixed_line_mul(fm, lines0[li], n.lxs, n.lys);
+            if (do_c) fixed_line_mul(fm, lines1[li], n.cxs, n.cys);
             li++;
         }
     }
@@ -250,8 +254,8 @@ ZKV_HD void miller_loop_m(const VkTables& vk, uint32_t flags, const G1Norm& n, c
             g2m_line_add(tm, &qx[s], &qy[s], &l0, &l1, &l3);
             var_line_mul(fm, l0, l1, l3, n.axs, n.ays);
         }
-        if (do_l) fixed_line_mul(fm, vk.lines[0][li], n.lxs, n.lys);
-        if (do_c) fixed_line_mul(fm, vk.lines[1][li], n.cxs, n.cys);
+        if (do_l) fixed_line_mul(fm, lines0[li], n.lxs, n.lys);
+        if (do_c) fixed_line_mul(fm, lines1[li], n.cxs, n.cys);
         li++;
     }
 }
@@ -472,7 +476,7 @@ ZKV_HD void setup_alpha_beta(const VkRaw& vk, VkTables& t, MRef fm, MRef tm) {
     Fp2 bx, by;
     bx.c0 = fp_from_raw(vk.beta[0]); bx.c1 = fp_from_raw(vk.beta[1]);
     by.c0 = fp_from_raw(vk.beta[2]); by.c1 = fp_from_raw(vk.beta[3]);
-    miller_loop_m(t, 0, n, bx, by, false, fm, tm);
+    miller_loop_m((const VkTables*)nullptr, 0, n, bx, by, fm, tm);
     for (int k = 0; k < 96; k++) t.f_alpha_beta[k] = fm.p[(size_t)k * fm.stride];
 }
 

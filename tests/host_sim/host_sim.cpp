@@ -56,7 +56,7 @@ int hs_groth16(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* wor
     // same slot structure as the kernels: f and T in one buffer (LDS on the device), 5 Fp12 slots for the final exp
     static thread_local uint32_t buf[96 + 48], slots[8 * 96];
     MRef fm = m_ref(buf, 1), tm = m_ref(buf + 96, 1);
-    miller_loop_m(*t, fl, n, p.bx, p.by, true, fm, tm);
+    miller_loop_m(t, fl, n, p.bx, p.by, fm, tm);
     g_stage_muls[3] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
     MRef F = m_ref(slots, 1), E = m_ref(slots + 96, 1), Y1 = m_ref(slots + 192, 1), Y3 = m_ref(slots + 288, 1), Y4 = m_ref(slots + 384, 1);
     for (int k = 0; k < 96; k++) slots[k] = t->f_alpha_beta[k];
@@ -120,7 +120,7 @@ int hs_groth16_generic(const uint8_t* vk_words, int n_ic, int negate_a, const ui
     msm_normalize(*t, p, fl, n);
     static thread_local uint32_t buf[96 + 48], slots[8 * 96];
     MRef fm = m_ref(buf, 1), tm = m_ref(buf + 96, 1);
-    miller_loop_m(*t, fl, n, p.bx, p.by, true, fm, tm);
+    miller_loop_m(t, fl, n, p.bx, p.by, fm, tm);
     MRef F = m_ref(slots, 1), E = m_ref(slots + 96, 1), Y1 = m_ref(slots + 192, 1), Y3 = m_ref(slots + 288, 1), Y4 = m_ref(slots + 384, 1);
     for (int k = 0; k < 96; k++) slots[k] = t->f_alpha_beta[k];
     f12m_mul(F, F, fm);

@@ -45,7 +45,7 @@ static void lane(Job* j, uint32_t par) {
     static thread_local uint32_t half[48 + 24];
     static uint32_t full[8 * 96];                    // shared by the two lanes like the HBM slots
     MRef fm = m_ref(half, 1, 8), tm = m_ref(half + 48, 1, 8);
-    miller_loop_m(*j->t, j->flags, n, bx, by, true, fm, tm);
+    miller_loop_m(j->t, j->flags, n, bx, by, fm, tm);
     MRef ab = m_ref((uint32_t*)j->t->f_alpha_beta + 8 * par, 1, 16);
     MRef F = m_ref(full + 8 * par, 1, 16), E = m_ref(full + 96 + 8 * par, 1, 16);
     f12m_mul(F, fm, ab);

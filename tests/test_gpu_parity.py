@@ -396,7 +396,7 @@ def test_dev_calls_on_different_streams_do_not_race(zkv, r0, real_proofs):
 
 
 def test_full_size_configs_through_properties(zkv, r0, sp1, real_proofs):
-    """BASELINE.json's single-GPU sizes (2^16 RISC Zero proofs, 2^20 SP1 proofs -- eight 2^17-proof chunks) checked through
+    """BASELINE.json's single-GPU sizes (2^16 RISC Zero proofs, 2^20 SP1 proofs -- one 2^20-proof chunk) checked through
     size-independent properties: accept <=> not mutated by construction for every proof, permutation equivariance (the batch
     is a seeded shuffle of copies of a 2^12 base batch whose statuses the oracle-pinned tests cover: status[i] must equal
     base_status[source[i]]), and idempotence (a second run returns the same bytes)."""
@@ -783,3 +783,58 @@ def test_last_small_chunk_switches_kernels_inside_one_batch(zkv, real_proofs):
         os.environ.pop('ZKV_CHUNK', None)
     assert ((st == 0) == ~mut[src]).all()
     assert len(set(st[16384:])) >= 2                             # the remainder holds accepted and rejected proofs
+
+
+def test_small_order_g2_points_through_the_pairing_kernels(zkv, r0, sp1, precompile_kats, real_proofs):
+    """The 14 G2 known-answer points (in-subgroup, random twist points, points with components of order 10069 and 5864401) go
+    through the GPU's subgroup checks where the reference would meet them (the ecPairing call, groth16.rs:121-125): as the G2 input of
+    `zkv_bn254_pairing_batch` (`ok` = the precompile succeeds) and as `B` of a RISC Zero seal and of an SP1 proof (lane-pair kernels
+    k_g2chk2 / k_miller2, and the 16-lane kernels for this small batch).  Expected: the fixture's flags, the C oracle, and the
+    oracle's verifiers."""
+    import oracle_lib as ol
+    pts = precompile_kats['g2_subgroup']
+    G1 = (1).to_bytes(32, 'big') + (2).to_bytes(32, 'big')
+    calls = [G1 + H(''.join(c['point'])) for c in pts]
+    pc = zkv.Bn254Precompiles()
+    got = pc.pairing(calls, 1)
+    for c, call, g in zip(pts, calls, got):
+        want = ol.ecpairing(call)
+        assert (g is not None) == (c['on_twist'] and c['in_subgroup']) == (want is not None), c['point'][0][:16]
+        if g is not None:
+            assert g == bool(want[-1])
+    # the same points paired with infinity on the G1 side: validation happens regardless of the skip (EIP-197)
+    got = pc.pairing([bytes(64) + H(''.join(c['point'])) for c in pts], 1)
+    assert [g is not None for g in got] == [c['on_twist'] and c['in_subgroup'] for c in pts]
+    pc.close()
+    r, s = real_proofs['risc0'], real_proofs['sp1']
+    orc = ol.Risc0Oracle(); orc.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    seal, proof = H(r['seal']), H(s['proof'])
+    seals = [seal[:68] + H(''.join(c['point'])) + seal[196:] for c in pts]
+    proofs = [proof[:68] + H(''.join(c['point'])) + proof[196:] for c in pts]
+    for lanes in (2, 16):
+        r0.set_lanes_per_proof(lanes); sp1.set_lanes_per_proof(lanes)
+        st, _ = r0.verify_batch(seals, [H(r['image_id'])] * len(pts), [H(r['journal_digest'])] * len(pts))
+        for x, got_st in zip(seals, st):
+            assert int(got_st) == orc.verify(x, H(r['image_id']), H(r['journal_digest']))[0] == 1      # a foreign B never verifies
+        st, _ = sp1.verify_batch([H(s['vkey'])] * len(pts), [H(s['public_values'])] * len(pts), proofs)
+        for x, got_st in zip(proofs, st):
+            assert int(got_st) == ol.sp1_verify_proof(H(s['vkey']), H(s['public_values']), x)[0] == 1
+    r0.set_lanes_per_proof(0); sp1.set_lanes_per_proof(0)
+
+
+def test_vk_x_on_generic_trapdoor_keys(zkv):
+    """zkv_ctx_vk_x_batch on ZKV_VM_GROTH16 contexts: all n_ic - 1 signals per proof (1..5), random and edge values, against the
+    oracle's ecMul / ecAdd chain (groth16.rs:51-58) on the same trapdoor key."""
+    import random
+    import oracle_lib as ol
+    import spec_model as m
+    rng = random.Random(4711)
+    for n_ic in (1, 2, 3, 4, 6):
+        vk, td = m.trapdoor_vk(rng, n_ic)
+        vkb = m.vk_to_words(vk)
+        v = zkv.Groth16Verifier(vkb, n_ic, zkv.errors.VM_SP1)
+        sigs = [[rng.choice([0, 1, m.R - 1, rng.randrange(m.R)]) for _ in range(n_ic - 1)] for _ in range(70)]
+        got = v.vk_x_batch([[m.be32(x) for x in sg] for sg in sigs])
+        for sg, g in zip(sigs, got):
+            assert g == ol.groth16_vk_x_vk(vkb, n_ic, [m.be32(x) for x in sg]), (n_ic, sg)
+        v.close()
