@@ -153,6 +153,30 @@ int zkv_mixed_verify_batch(zkv_ctx* ctx, size_t n, const uint8_t* vm, const uint
 int zkv_mixed_verify_batch_dev(zkv_ctx* ctx, size_t n, const uint8_t* d_vm, const uint8_t* d_seals, const uint8_t* d_in_a, const uint8_t* d_in_b,
                                size_t b_stride, size_t pv_len, uint8_t* d_status, uint8_t* d_recv_selector, void* stream);
 
+/* ------------------------------------------------------------------ SP1 PLONK verifier (BASELINE.json configs[4])
+ * `ISp1Verifier::verify_proof` (sp1/verifier.rs:16-29, 39-46, 58-111) with the PLONK proof system behind it -- the path the reference
+ * marks "in progress" (README.md:25, contracts/src/lib.rs:11) and for which it holds no code, key or proof: PARITY UNPINNED BY
+ * CONSTRUCTION.  The algorithm is gnark's BN254 PLONK verifier (v0.10-0.11: SHA-256 Fiat-Shamir transcript, one BSB22 commitment,
+ * linearised polynomial with the quotient folded in, batched KZG opening, one 2-pair pairing), restated in oracle/plonk_model.py;
+ * proof_bytes = 4-byte selector (first bytes of `verifier_hash`) + 27 words = ZKV_PLONK_PROOF_BYTES.  Check order and statuses are
+ * those of the Groth16 `verify_proof`: INVALID_PROOF_DATA (length < 4), SELECTOR_MISMATCH, INVALID_PROOF_DATA (length != 868),
+ * VERIFICATION_FAILED (program_vkey >= R, a scalar >= R, a point off the curve, the algebraic relation or the pairing failing), OK.
+ * The verifying key is supplied by the caller (no SP1 PLONK key exists in the reference): 32-byte big-endian words
+ *   size | size_inv | generator | coset_shift | nb_public (= 2) | n_qcp (0 or 1) | commitment_constraint_index |
+ *   S1 S2 S3 Ql Qr Qm Qo Qk [Qcp] (G1 x, y) | G2 generator | [tau]G2 (EIP-197 order x_im x_re y_im y_re)
+ * A key holding an invalid point fails every proof. */
+#define ZKV_VM_SP1_PLONK 6
+#define ZKV_PLONK_PROOF_BYTES 868
+zkv_ctx* zkv_sp1_plonk_ctx_create(const uint8_t* vk_bytes, size_t vk_len, const uint8_t verifier_hash[32], int device);
+int zkv_sp1_plonk_verifier_hash(const zkv_ctx* ctx, uint8_t out[32]);                       /* ISp1Verifier::verifier_hash */
+int zkv_sp1_plonk_verify_batch(zkv_ctx* ctx, size_t n, const uint8_t* program_vkeys, const uint8_t* pv_blob, const uint64_t* pv_off,
+                               const uint8_t* proof_blob, const uint64_t* proof_off, uint8_t* status, uint8_t* recv_selector);
+int zkv_sp1_plonk_verify_proof(zkv_ctx* ctx, const uint8_t program_vkey[32], const uint8_t* public_values, size_t pv_len,
+                               const uint8_t* proof, size_t proof_len, uint8_t* status, uint8_t recv_selector[4]);
+/* Fast path, device-resident: fixed-stride 868-byte proofs and fixed-length public values; asynchronous on `stream`. */
+int zkv_sp1_plonk_verify_batch_dev(zkv_ctx* ctx, size_t n, const uint8_t* d_program_vkeys, const uint8_t* d_public_values, size_t pv_len,
+                                   const uint8_t* d_proofs, uint8_t* d_status, uint8_t* d_recv_selector, void* stream);
+
 /* ------------------------------------------------------------------ on-chain wire layer: eth_call batches
  * What a client of the deployed example shells sends: calldata for the Solidity view of the two traits
  * (examples/risc0-verifier/examples/interact.rs:31-43, examples/sp1-verifier/examples/interact.rs:11-19; the shells are

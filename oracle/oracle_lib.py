@@ -48,6 +48,10 @@ def lib():
         L.zkvo_groth16_vk_x.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_char_p]
         L.zkvo_groth16_verify_vk.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
         L.zkvo_groth16_vk_x_vk.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p]
+        L.zkvo_plonk_verify.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_int]
+        L.zkvo_sp1_plonk_verify_proof.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p]
+        L.zkvo_sp1_plonk_verify_batch.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_int]
         L.zkvo_status_abi_encode.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
         L.zkvo_count_enable.argtypes = [C.c_int]
         L.zkvo_count_read.restype = C.c_uint64
@@ -189,6 +193,37 @@ def groth16_vk_x_vk(vk_words, n_ic, signals):
 def groth16_verify_vk(vm, vk_words, n_ic, proof_words, signals):
     """verify_proof_with_key for an arbitrary key: vk_words bytes, proof_words 256 bytes, signals list of 32-byte values."""
     return bool(lib().zkvo_groth16_verify_vk(vm, bytes(vk_words), n_ic, bytes(proof_words), b''.join(signals) + b'\0', len(signals)))
+
+
+def plonk_verify(vk_bytes, proof_words, public_inputs):
+    """gnark-style BN254 PLONK verification (zkv_plonk_oracle.inc): proof 27 x 32 bytes, public inputs as 32-byte values -> bool."""
+    return bool(lib().zkvo_plonk_verify(bytes(vk_bytes), len(vk_bytes), bytes(proof_words), len(proof_words), b''.join(public_inputs) + b'\0', len(public_inputs)))
+
+
+def sp1_plonk_verify_proof(vk_bytes, verifier_hash, vkey, public_values, proof):
+    recv = _buf(4)
+    st = lib().zkvo_sp1_plonk_verify_proof(bytes(vk_bytes), len(vk_bytes), bytes(verifier_hash), bytes(vkey), bytes(public_values) + b'\0', len(public_values),
+                                           bytes(proof) + b'\0', len(proof), recv)
+    return st, recv.raw
+
+
+def sp1_plonk_verify_batch(vk_bytes, verifier_hash, vkeys, public_values, proofs, threads=1):
+    import numpy as np
+    n = len(proofs)
+    pvb, pvo = _blob_np(public_values)
+    pb, po = _blob_np(proofs)
+    st = np.zeros(n, dtype=np.uint8); rv = np.zeros(4 * max(n, 1), dtype=np.uint8)
+    lib().zkvo_sp1_plonk_verify_batch(bytes(vk_bytes), len(vk_bytes), bytes(verifier_hash), n, b''.join(bytes(v) for v in vkeys) + b'\0', pvb, pvo.ctypes.data, pb,
+                                      po.ctypes.data, st.ctypes.data, rv.ctypes.data, threads)
+    return st, rv[:4 * n]
+
+
+def _blob_np(items):
+    import numpy as np
+    off = np.zeros(len(items) + 1, dtype=np.uint64)
+    if len(items):
+        off[1:] = np.cumsum([len(s) for s in items], dtype=np.uint64)
+    return b''.join(bytes(s) for s in items) + b'\0', off
 
 
 def status_abi_encode(vm, status, recv, exp):

@@ -1023,3 +1023,6 @@ ZKVO_API void zkvo_fp_mulmod(const uint8_t a[32], const uint8_t b[32], uint8_t o
     u256_from_be(av, a); u256_from_be(bv, b);
     fp_from_u256(&am, av); fp_from_u256(&bm, bv); fp_mul(&rm, &am, &bm); fp_to_u256(rv, &rm); u256_to_be(out, rv);
 }
+
+/* ------------------------------------------------------------------ SP1 PLONK path (parity unpinned by construction) */
+#include "zkv_plonk_oracle.inc"

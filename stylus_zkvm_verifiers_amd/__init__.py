@@ -6,13 +6,13 @@ Drop-in for the verify path of gnosisguild/stylus-zkvm-verifiers: `RiscZeroVerif
 from . import errors
 from .errors import VerifierError
 from .risc0 import RiscZeroVerifier, RiscZeroVerifierSet
-from .sp1 import Sp1Verifier
+from .sp1 import Sp1Verifier, Sp1PlonkVerifier
 from .bn254 import Bn254Precompiles
 from .groth16 import Groth16Verifier
 from .mixed import MixedVerifier
 from . import wire
 
-__all__ = ['RiscZeroVerifier', 'RiscZeroVerifierSet', 'Sp1Verifier', 'Bn254Precompiles', 'Groth16Verifier', 'MixedVerifier', 'VerifierError', 'errors', 'wire', 'device_count']
+__all__ = ['RiscZeroVerifier', 'RiscZeroVerifierSet', 'Sp1Verifier', 'Sp1PlonkVerifier', 'Bn254Precompiles', 'Groth16Verifier', 'MixedVerifier', 'VerifierError', 'errors', 'wire', 'device_count']
 
 
 def device_count():

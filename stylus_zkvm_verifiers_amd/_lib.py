@@ -46,6 +46,11 @@ SYMBOLS = {
     'zkv_mixed_ctx_sp1': (_vp, [_vp]),
     'zkv_mixed_verify_batch': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'zkv_mixed_verify_batch_dev': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    'zkv_sp1_plonk_ctx_create': (_vp, [_cp, _sz, _cp, _i]),
+    'zkv_sp1_plonk_verifier_hash': (_i, [_vp, _cp]),
+    'zkv_sp1_plonk_verify_batch': (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'zkv_sp1_plonk_verify_proof': (_i, [_vp, _cp, _cp, _sz, _cp, _sz, _u8p, _cp]),
+    'zkv_sp1_plonk_verify_batch_dev': (_i, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     'zkv_bn254_ctx_create': (_vp, [_i]),
     'zkv_bn254_ecadd_batch': (_i, [_vp, _sz, _vp, _vp, _vp]),
     'zkv_bn254_ecmul_batch': (_i, [_vp, _sz, _vp, _vp, _vp]),

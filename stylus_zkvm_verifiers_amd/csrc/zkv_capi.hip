@@ -12,6 +12,7 @@
 #include "zkv_host_abi.h"
 #include "zkv_host_vk.h"
 #include "zkv_internal.h"
+#include "zkv_plonk.h"
 
 using namespace zkv;
 
@@ -57,6 +58,9 @@ struct zkv_ctx {
     uint8_t* hb[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // seals, seal offsets, in_a, in_b, public values, pv offsets
     size_t hb_cap[6] = {0, 0, 0, 0, 0, 0};
     hipEvent_t ev_seg[2] = {nullptr, nullptr};
+    // ZKV_VM_SP1_PLONK: parsed verifying key, the SRS's two G2 points (reference word order) and the verifier hash
+    PlonkKeyRaw pk_raw; uint8_t pk_g2[256] = {0}, plonk_hash[32] = {0};
+    PlonkKey* d_pkey = nullptr;
     // ZKV_VM_MIXED: one RISC Zero and one SP1 verifier behind a per-proof VM tag; mx[] are the demultiplexing buffers
     zkv_ctx* kid[2] = {nullptr, nullptr};
     uint8_t* mx[20] = {nullptr};
@@ -112,7 +116,7 @@ static void ctx_free_device(zkv_ctx* c) {
                      (void**)&c->ws.g2bad, (void**)&c->d_blob, (void**)&c->d_a, (void**)&c->d_b, (void**)&c->d_pv, (void**)&c->d_status,
                      (void**)&c->d_recv, (void**)&c->d_off, (void**)&c->d_pvoff, (void**)&c->d_cd[0], (void**)&c->d_cd[1], (void**)&c->d_kind,
                      (void**)&c->d_cdoff[0], (void**)&c->d_cdoff[1], (void**)&c->d_len, (void**)&c->d_pvlen, (void**)&c->d_st_all,
-                     (void**)&c->d_rv_all, (void**)&c->d_inst, (void**)&c->d_inst_idx};
+                     (void**)&c->d_rv_all, (void**)&c->d_inst, (void**)&c->d_inst_idx, (void**)&c->d_pkey};
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     for (int k = 0; k < 6; k++) { if (c->hb[k]) (void)hipFree(c->hb[k]); c->hb[k] = nullptr; c->hb_cap[k] = 0; }
     for (int k = 0; k < 20; k++) { if (c->mx[k]) (void)hipFree(c->mx[k]); c->mx[k] = nullptr; c->mx_cap[k] = 0; }
@@ -145,6 +149,13 @@ static int ctx_device_setup(zkv_ctx* c) {
         VkRaw raw;
         if (c->vm == ZKV_VM_RISC0 || c->vm == ZKV_VM_RISC0_SET) host::fill_vk_risc0(raw, c->control_root_0, c->control_root_1, c->control_id);
         else if (c->vm == ZKV_VM_GROTH16) host::fill_vk_generic(raw, c->gvk, c->g_n_ic);
+        else if (c->vm == ZKV_VM_SP1_PLONK) {
+            // the pairing of a PLONK proof has two FIXED pairs: the SRS's [1]_2 and [tau]_2 take the line-table slots of gamma and
+            // delta; there is no (alpha, beta) pair (alpha = infinity contributes 1) and no IC points
+            memset(&raw, 0, sizeof raw);
+            const int perm[4] = {1, 0, 3, 2};
+            for (int k = 0; k < 4; k++) { host::be_to_limbs(raw.gamma[k], c->pk_g2 + 32 * perm[k]); host::be_to_limbs(raw.delta[k], c->pk_g2 + 128 + 32 * perm[k]); }
+        }
         else host::fill_vk_sp1(raw);
         if (c->id_ge_r) memset(raw.fixed_scalar[5], 0, 32);      // never used: every proof fails the range check first
         // the raw key and the instance parameters are only read by the set-up kernels; mx[0] / mx[1] hold them until those are done
@@ -168,6 +179,13 @@ static int ctx_device_setup(zkv_ctx* c) {
             HIP_TRY(hipGetLastError());
             c->inst_host.resize(k);
             HIP_TRY(hipMemcpyAsync(c->inst_host.data(), c->d_inst, sizeof(InstTab) * k, hipMemcpyDeviceToHost, c->stream));
+        }
+        if (c->vm == ZKV_VM_SP1_PLONK) {
+            HIP_TRY(hipMalloc(&c->mx[1], sizeof(PlonkKeyRaw)));
+            HIP_TRY(hipMalloc(&c->d_pkey, sizeof(PlonkKey)));
+            HIP_TRY(hipMemcpyAsync(c->mx[1], &c->pk_raw, sizeof(PlonkKeyRaw), hipMemcpyHostToDevice, c->stream));
+            launch_plonk_setup((const PlonkKeyRaw*)c->mx[1], c->d_pkey, c->stream);
+            HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
         for (int k = 0; k < 2; k++) { if (c->mx[k]) (void)hipFree(c->mx[k]); c->mx[k] = nullptr; }
@@ -254,6 +272,19 @@ static int mark_done(zkv_ctx* c, hipStream_t s) {
 // Enqueues the five stages for one chunk (all pointers device-resident).
 static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed) {
     if (timed) (void)hipEventRecord(c->ev[0], s);
+    if (c->vm == ZKV_VM_SP1_PLONK) {
+        // PLONK: the prep stage does everything up to the two G1 points of the final check (transcript, scalar algebra, MSMs);
+        // no per-proof G2 point, so no subgroup check, and no vk_x stage
+        launch_plonk_prep(a, c->d_pkey, c->ws, s);
+        if (timed) { (void)hipEventRecord(c->ev[1], s); (void)hipEventRecord(c->ev[2], s); (void)hipEventRecord(c->ev[3], s); }
+        const int pl = c->lanes ? c->lanes : 2;
+        const bool wide_p = pl == 16 || (c->lanes == 0 && a.n <= wide_below());
+        if (wide_p) launch_miller_w(a.n, c->d_tab, c->ws, s); else launch_miller2(a.n, c->d_tab, c->ws, s);
+        if (timed) (void)hipEventRecord(c->ev[4], s);
+        if (wide_p) launch_finalexp_w(a.n, c->ws, a.status, s); else launch_finalexp2(a.n, c->ws, a.status, s);
+        if (timed) (void)hipEventRecord(c->ev[5], s);
+        return;
+    }
     if (c->vm == ZKV_VM_RISC0 || c->vm == ZKV_VM_RISC0_SET) launch_prep_risc0(a, c->consts, c->ws, s);
     else if (c->vm == ZKV_VM_GROTH16) launch_prep_groth16(a, c->ws, s);
     else launch_prep_sp1(a, c->ws, s);
@@ -325,7 +356,7 @@ static int run_host_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const uint6
     int rc = ctx_ready(c, n);
     if (rc != ZKV_OK) return rc;
     const size_t cap = c->ws.cap, pass_max = (size_t)1 << 22;
-    const bool sp1 = c->vm == ZKV_VM_SP1;
+    const bool sp1 = c->vm == ZKV_VM_SP1 || c->vm == ZKV_VM_SP1_PLONK;
     if ((rc = order_after_previous(c, c->stream)) != ZKV_OK) return rc;
     std::vector<uint64_t> rel, prel;
     for (size_t p0 = 0; p0 < n; p0 += pass_max) {
@@ -361,7 +392,8 @@ static int run_host_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const uint6
             a.in32_a = c->hb[2] + 32 * base; a.in32_b = in_b ? c->hb[3] + 32 * base : nullptr;
             if (sp1) {
                 a.pv_blob = c->hb[4]; a.pv_off = (const uint64_t*)c->hb[5] + base;
-                a.selector_be = be32_of(host::SP1_VERIFIER_HASH);
+                a.selector_be = be32_of(c->vm == ZKV_VM_SP1_PLONK ? c->plonk_hash : host::SP1_VERIFIER_HASH);
+                a.force_fail = c->vm == ZKV_VM_SP1_PLONK && c->vk_invalid ? 1u : 0u;
             } else {
                 a.selector_be = be32_of(c->selector);
                 a.force_fail = c->id_ge_r ? 1u : 0u;
@@ -397,11 +429,13 @@ static int run_dev_batch(zkv_ctx* c, size_t n, const uint8_t* d_blob, const uint
         size_t m = n - base < cap ? n - base : cap;
         PrepArgs a;
         memset(&a, 0, sizeof a);
-        a.n = m; a.blob = d_blob + base * ZKV_SEAL_BYTES; a.off = nullptr; a.stride = ZKV_SEAL_BYTES;
+        const size_t rec = c->vm == ZKV_VM_SP1_PLONK ? (size_t)ZKV_PLONK_PROOF_BYTES : (size_t)ZKV_SEAL_BYTES;
+        a.n = m; a.blob = d_blob + base * rec; a.off = nullptr; a.stride = (uint32_t)rec;
         a.in32_a = d_a + 32 * base; a.in32_b = d_b ? d_b + 32 * base : nullptr;
-        if (c->vm == ZKV_VM_SP1) {
+        if (c->vm == ZKV_VM_SP1 || c->vm == ZKV_VM_SP1_PLONK) {
             a.pv_blob = d_pv + base * pv_len; a.pv_off = nullptr; a.pv_stride = (uint32_t)pv_len;
-            a.selector_be = be32_of(host::SP1_VERIFIER_HASH);
+            a.selector_be = be32_of(c->vm == ZKV_VM_SP1_PLONK ? c->plonk_hash : host::SP1_VERIFIER_HASH);
+            a.force_fail = c->vm == ZKV_VM_SP1_PLONK && c->vk_invalid ? 1u : 0u;
         } else {
             a.selector_be = be32_of(c->selector);
             a.force_fail = c->id_ge_r ? 1u : 0u;
@@ -761,6 +795,53 @@ ZKV_EXPORT int zkv_sp1_verify_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d_v
     return run_dev_batch(c, n, d_proofs, d_vkeys, nullptr, d_pv, pv_len, d_status, d_recv, stream);
 }
 
+// ------------------------------------------------------------------ SP1 PLONK (no reference code: parity unpinned)
+ZKV_EXPORT zkv_ctx* zkv_sp1_plonk_ctx_create(const uint8_t* vk, size_t vk_len, const uint8_t verifier_hash[32], int device) {
+    if (!vk || !verifier_hash || vk_len < 7 * 32) return nullptr;
+    uint32_t w[7][8];
+    for (int k = 0; k < 7; k++) host::be_to_limbs(w[k], vk + 32 * k);
+    auto small = [](const uint32_t* x) { for (int i = 1; i < 8; i++) if (x[i]) return false; return true; };
+    if (!small(w[4]) || !small(w[5]) || !small(w[6]) || w[5][0] > 1) return nullptr;
+    const size_t n_c = w[5][0];
+    if (vk_len != 7 * 32 + (8 + n_c) * 64 + 256) return nullptr;
+    zkv_ctx* c = new (std::nothrow) zkv_ctx();
+    if (!c) return nullptr;
+    c->vm = ZKV_VM_SP1_PLONK; c->device = device; c->initialized = true;
+    memset(&c->consts, 0, sizeof c->consts);
+    memset(&c->pk_raw, 0, sizeof c->pk_raw);
+    memcpy(c->pk_raw.size, w[0], 32); memcpy(c->pk_raw.size_inv, w[1], 32); memcpy(c->pk_raw.gen, w[2], 32); memcpy(c->pk_raw.coset, w[3], 32);
+    c->pk_raw.nb_public = w[4][0]; c->pk_raw.n_c = w[5][0]; c->pk_raw.cci = w[6][0];
+    for (size_t p = 0; p < 8 + n_c; p++) {
+        host::be_to_limbs(c->pk_raw.pts[p][0], vk + 224 + 64 * p); host::be_to_limbs(c->pk_raw.pts[p][1], vk + 256 + 64 * p);
+    }
+    memcpy(c->pk_g2, vk + 224 + 64 * (8 + n_c), 256);
+    memcpy(c->plonk_hash, verifier_hash, 32);
+    return c;
+}
+ZKV_EXPORT int zkv_sp1_plonk_verifier_hash(const zkv_ctx* c, uint8_t out[32]) {
+    if (!c || c->vm != ZKV_VM_SP1_PLONK) return ZKV_ERR_WRONG_CTX;
+    memcpy(out, c->plonk_hash, 32); return ZKV_OK;
+}
+ZKV_EXPORT int zkv_sp1_plonk_verify_batch(zkv_ctx* c, size_t n, const uint8_t* vkeys, const uint8_t* pv_blob, const uint64_t* pv_off,
+                                          const uint8_t* proof_blob, const uint64_t* proof_off, uint8_t* status, uint8_t* recv) {
+    if (!c || c->vm != ZKV_VM_SP1_PLONK) return ZKV_ERR_WRONG_CTX;
+    if (n && (!vkeys || !pv_blob || !pv_off)) return ZKV_ERR_INVALID_ARG;
+    return run_host_batch(c, n, proof_blob, proof_off, vkeys, nullptr, pv_blob, pv_off, status, recv);
+}
+ZKV_EXPORT int zkv_sp1_plonk_verify_proof(zkv_ctx* c, const uint8_t vkey[32], const uint8_t* pv, size_t pv_len, const uint8_t* proof, size_t proof_len,
+                                          uint8_t* status, uint8_t recv[4]) {
+    uint64_t poff[2] = {0, proof_len}, voff[2] = {0, pv_len};
+    uint8_t dummy = 0;
+    if ((!pv && pv_len) || (!proof && proof_len)) return ZKV_ERR_INVALID_ARG;
+    return zkv_sp1_plonk_verify_batch(c, 1, vkey, pv ? pv : &dummy, voff, proof ? proof : &dummy, poff, status, recv);
+}
+ZKV_EXPORT int zkv_sp1_plonk_verify_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d_vkeys, const uint8_t* d_pv, size_t pv_len, const uint8_t* d_proofs,
+                                              uint8_t* d_status, uint8_t* d_recv, void* stream) {
+    if (!c || c->vm != ZKV_VM_SP1_PLONK) return ZKV_ERR_WRONG_CTX;
+    if (n && !d_pv) return ZKV_ERR_INVALID_ARG;
+    return run_dev_batch(c, n, d_proofs, d_vkeys, nullptr, d_pv, pv_len, d_status, d_recv, stream);
+}
+
 // ------------------------------------------------------------------ on-chain wire layer (eth_call batches)
 ZKV_EXPORT int zkv_abi_function_selector(const char* signature, uint8_t out[4]) {
     if (!signature || !out) return ZKV_ERR_INVALID_ARG;
@@ -1077,7 +1158,7 @@ ZKV_EXPORT int zkv_groth16_verify_batch(zkv_ctx* c, size_t n, const uint8_t* pro
 
 // ------------------------------------------------------------------ Groth16 core pieces
 ZKV_EXPORT int zkv_ctx_vk_x_batch(zkv_ctx* c, size_t n, const uint8_t* var_signals, uint8_t* out) {
-    if (!c || c->vm == ZKV_VM_BN254 || c->vm == ZKV_VM_RISC0_SET || c->vm == ZKV_VM_MIXED) return ZKV_ERR_WRONG_CTX;
+    if (!c || c->vm == ZKV_VM_BN254 || c->vm == ZKV_VM_RISC0_SET || c->vm == ZKV_VM_MIXED || c->vm == ZKV_VM_SP1_PLONK) return ZKV_ERR_WRONG_CTX;
     if (c->vm == ZKV_VM_RISC0 && !c->initialized) return ZKV_ERR_INVALID_ARG;
     if (n && (!var_signals || !out)) return ZKV_ERR_INVALID_ARG;
     if (!n) return ZKV_OK;
@@ -1184,6 +1265,7 @@ ZKV_EXPORT int zkv_status_abi_encode(int vm, uint8_t status, const uint8_t recei
     // keccak-256 selectors of the reference's Solidity custom errors
     static const uint8_t sel[5][4] = {{0, 0, 0, 0}, {0x43, 0x9c, 0xc0, 0xcd}, {0xf9, 0x2e, 0xe8, 0xa9}, {0x0d, 0xc1, 0x49, 0xf0}, {0xe3, 0xe9, 0x43, 0x26}};
     static const uint8_t mism[2][4] = {{0xb8, 0xb3, 0x8d, 0x4c}, {0x98, 0x80, 0x66, 0xa1}};
+    if (vm == ZKV_VM_SP1_PLONK) vm = ZKV_VM_SP1;           // same ISp1Verifier errors
     if (!out || (vm != ZKV_VM_RISC0 && vm != ZKV_VM_SP1)) return ZKV_ERR_INVALID_ARG;
     if (status == ZKV_STATUS_OK) return 0;
     if (status == ZKV_STATUS_SELECTOR_MISMATCH) {

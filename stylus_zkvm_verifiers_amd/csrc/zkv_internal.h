@@ -105,6 +105,14 @@ struct MixedArgs {
 void launch_mixed_partition(const MixedArgs& a, uint32_t* cnt, uint32_t* totals, hipStream_t s);
 void launch_mixed_return(size_t m, const uint32_t* idx, const uint8_t* c_status, const uint8_t* c_recv, uint8_t* status, uint8_t* recv, hipStream_t s);
 
+// SP1 PLONK path (k_plonk.hip, zkv_plonk.h)
+#ifndef ZKV_PLONK_PROOF_BYTES
+#define ZKV_PLONK_PROOF_BYTES 868    /* selector + the 27 words of gnark's MarshalSolidity with one BSB22 commitment */
+#endif
+struct PlonkKeyRaw; struct PlonkKey;
+void launch_plonk_setup(const PlonkKeyRaw* d_raw, PlonkKey* d_key, hipStream_t s);
+void launch_plonk_prep(const PrepArgs& a, const PlonkKey* d_key, const Workspace& ws, hipStream_t s);
+
 // multiplication-rate microbenchmark (k_diag.hip)
 void launch_diag_mulmod(int kind, unsigned blocks, uint32_t iters, uint32_t* out, unsigned long long* clk, hipStream_t s);
 

@@ -1,0 +1,383 @@
+// SP1 PLONK path (BASELINE.json configs[4]): everything of a gnark-style BN254 PLONK verification that comes
+// BEFORE the pairing -- proof parsing, scalar / point validation, the SHA-256 Fiat-Shamir transcript, the scalar-field
+// algebra, the linearised-polynomial and KZG folding MSMs -- one proof per lane.  The result is the two G1 points of the final
+// check  e(D, [1]_2) * e(-Q, [tau]_2) == 1,  which then take the ordinary lane-pair Miller loop and final exponentiation with the
+// SRS's two G2 points as FIXED pairs (precomputed line tables: the same slots gamma and delta use in the Groth16 contexts).
+//
+// PARITY UNPINNED BY CONSTRUCTION: the reference has no PLONK code, key or proof (/root/reference/README.md:25,
+// /root/reference/contracts/src/lib.rs:11); the entry-point shape is sp1/verifier.rs:16-29, 58-111, the algorithm gnark's published
+// verifier (backend/plonk/bn254/verify.go, gnark-crypto kzg / fiat-shamir / hash_to_field), restated in oracle/plonk_model.py.
+#pragma once
+#include "zkv_verify.h"
+
+namespace zkv {
+
+// ---------------------------------------------------------------- scalar field Fr: 8 x 32-bit Montgomery form (R = 2^256), canonical
+struct Fr { uint32_t v[8]; };
+ZKV_HD Fr fr_zero() { Fr r; for (int i = 0; i < 8; i++) r.v[i] = 0; return r; }
+ZKV_HD Fr fr_one() { Fr r = ZKV_FR_ONE; return r; }
+ZKV_HD bool fr_is_zero(const Fr& a) { uint32_t o = 0; for (int i = 0; i < 8; i++) o |= a.v[i]; return o == 0; }
+ZKV_HD Fr fr_add(const Fr& a, const Fr& b) {
+    const uint32_t M[8] = ZKV_FR_R_LIMBS;
+    Fr t, s; uint32_t c = 0, br = 0;
+    for (int i = 0; i < 8; i++) t.v[i] = addc(a.v[i], b.v[i], c);          // < 2r < 2^255: no carry out
+    for (int i = 0; i < 8; i++) s.v[i] = subb(t.v[i], M[i], br);
+    for (int i = 0; i < 8; i++) t.v[i] = br ? t.v[i] : s.v[i];
+    return t;
+}
+ZKV_HD Fr fr_sub(const Fr& a, const Fr& b) {
+    const uint32_t M[8] = ZKV_FR_R_LIMBS;
+    Fr t; uint32_t br = 0, c = 0;
+    for (int i = 0; i < 8; i++) t.v[i] = subb(a.v[i], b.v[i], br);
+    const uint32_t mask = 0u - br;
+    for (int i = 0; i < 8; i++) t.v[i] = addc(t.v[i], M[i] & mask, c);
+    return t;
+}
+ZKV_HD Fr fr_neg(const Fr& a) { return fr_sub(fr_zero(), a); }
+// CIOS Montgomery product on 32-bit limbs (a few hundred of these per proof: not worth the column form of fp_mul)
+ZKV_HD_NI Fr fr_mul(Fr a, Fr b) {
+    const uint32_t M[8] = ZKV_FR_R_LIMBS;
+    uint32_t t[10];
+    for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll 1
+    for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+        for (int j = 0; j < 8; j++) { c += (uint64_t)a.v[j] * b.v[i] + t[j]; t[j] = (uint32_t)c; c >>= 32; }
+        c += t[8]; t[8] = (uint32_t)c; t[9] = (uint32_t)(c >> 32);
+        const uint32_t m = t[0] * ZKV_FR_INV32;
+        c = (uint64_t)m * M[0] + t[0]; c >>= 32;
+        for (int j = 1; j < 8; j++) { c += (uint64_t)m * M[j] + t[j]; t[j - 1] = (uint32_t)c; c >>= 32; }
+        c += t[8]; t[7] = (uint32_t)c; t[8] = t[9] + (uint32_t)(c >> 32);
+    }
+    Fr r, s; uint32_t br = 0;
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    for (int i = 0; i < 8; i++) s.v[i] = subb(r.v[i], M[i], br);
+    const bool keep = br && !t[8];
+    for (int i = 0; i < 8; i++) r.v[i] = keep ? r.v[i] : s.v[i];
+    return r;
+}
+ZKV_HD Fr fr_from_raw(const uint32_t* limbs) {               // canonical value < r -> Montgomery form
+    Fr t, r2 = ZKV_FR_R2;
+    for (int i = 0; i < 8; i++) t.v[i] = limbs[i];
+    return fr_mul(t, r2);
+}
+ZKV_HD void fr_to_raw(uint32_t* limbs, const Fr& a) {
+    Fr one = fr_zero(); one.v[0] = 1;
+    Fr t = fr_mul(a, one);
+    for (int i = 0; i < 8; i++) limbs[i] = t.v[i];
+}
+// any 256-bit value mod r (challenges are raw SHA-256 outputs): r > 2^253, so at most five subtractions
+ZKV_HD Fr fr_from_raw_reduce(const uint32_t* limbs) {
+    const uint32_t M[8] = ZKV_FR_R_LIMBS;
+    uint32_t t[8];
+    for (int i = 0; i < 8; i++) t[i] = limbs[i];
+#pragma unroll 1
+    for (int k = 0; k < 5; k++) {
+        uint32_t s[8], br = 0;
+        for (int i = 0; i < 8; i++) s[i] = subb(t[i], M[i], br);
+        if (!br) for (int i = 0; i < 8; i++) t[i] = s[i];
+    }
+    return fr_from_raw(t);
+}
+ZKV_HD Fr fr_pow(const Fr& a, const uint32_t* e, int bits) {   // left to right
+    Fr acc = fr_one();
+#pragma unroll 1
+    for (int i = bits - 1; i >= 0; i--) {
+        acc = fr_mul(acc, acc);
+        if ((e[i >> 5] >> (i & 31)) & 1u) acc = fr_mul(acc, a);
+    }
+    return acc;
+}
+ZKV_HD Fr fr_inv(const Fr& a) { const uint32_t E[8] = ZKV_FR_RM2_LIMBS; return fr_pow(a, E, 254); }     // inv(0) = 0
+
+// ---------------------------------------------------------------- streaming SHA-256 for the transcripts (byte granular)
+struct ShaStream {
+    uint32_t h[8], w[16]; uint32_t n;
+    ZKV_HD void init() { sha256_init(h); n = 0; for (int i = 0; i < 16; i++) w[i] = 0; }
+    ZKV_HD void byte(uint32_t b) {
+        const uint32_t k = (n >> 2) & 15u;
+        w[k] = (w[k] << 8) | (b & 255u);
+        n++;
+        if ((n & 63u) == 0) { sha256_compress(h, w); for (int i = 0; i < 16; i++) w[i] = 0; }
+    }
+    ZKV_HD void word_be(uint32_t v) {                      // four bytes, most significant first
+        if ((n & 3u) == 0) {
+            w[(n >> 2) & 15u] = v; n += 4;
+            if ((n & 63u) == 0) { sha256_compress(h, w); for (int i = 0; i < 16; i++) w[i] = 0; }
+        } else { byte(v >> 24); byte(v >> 16); byte(v >> 8); byte(v); }
+    }
+    ZKV_HD void limbs_be(const uint32_t* l) {               // a 256-bit value as 32 big-endian bytes
+#pragma unroll 1
+        for (int i = 7; i >= 0; i--) word_be(l[i]);
+    }
+    ZKV_HD void finish(uint32_t out[8]) {
+        const uint64_t bits = (uint64_t)n * 8u;
+        byte(0x80u);
+        while ((n & 63u) != 56u) byte(0);
+        word_be((uint32_t)(bits >> 32)); word_be((uint32_t)bits);
+        for (int i = 0; i < 8; i++) out[i] = h[i];
+    }
+};
+ZKV_HD void digest_to_limbs(const uint32_t h[8], uint32_t l[8]) { for (int i = 0; i < 8; i++) l[7 - i] = h[i]; }     // big-endian digest as an integer
+
+// ---------------------------------------------------------------- verifying key on the device
+constexpr int PK_S1 = 0, PK_S2 = 1, PK_S3 = 2, PK_QL = 3, PK_QR = 4, PK_QM = 5, PK_QO = 6, PK_QK = 7, PK_QCP = 8, PK_POINTS = 9;
+struct PlonkKeyRaw {                // what zkv_sp1_plonk_ctx_create parsed out of the key bytes (canonical little-endian limbs)
+    uint32_t size[8], size_inv[8], gen[8], coset[8];
+    uint32_t nb_public, n_c, cci, pad;
+    uint32_t pts[PK_POINTS][2][8];
+};
+struct PlonkKey {
+    uint32_t size[8];               // domain size (exponent)
+    uint32_t size_p2[8];            // size + 2
+    Fr size_inv, gen, coset, gen_cci;       // gen_cci = generator^(nb_public + cci)
+    uint32_t nb_public, n_c, valid, pad;
+    G1A pts[PK_POINTS]; uint32_t inf[PK_POINTS];
+    uint32_t raw[PK_POINTS][2][8];  // the same points as canonical integers, for the transcripts
+};
+// A G1 point as the precompiles take it: coordinates < P, on the curve or (0,0) = infinity.  Returns false when invalid.
+ZKV_HD bool plonk_g1(const uint32_t x[8], const uint32_t y[8], G1A& out, uint32_t& inf) {
+    if (!raw_lt_p(x) || !raw_lt_p(y)) return false;
+    if (raw_is_zero(x) && raw_is_zero(y)) { inf = 1; out.x = fp_zero(); out.y = fp_zero(); return true; }
+    out.x = fp_from_raw(x); out.y = fp_from_raw(y); inf = 0;
+    return g1_on_curve(out.x, out.y);
+}
+ZKV_HD void plonk_setup_key(const PlonkKeyRaw& r, PlonkKey& k) {
+    bool ok = raw_lt_r(r.size_inv) && raw_lt_r(r.gen) && raw_lt_r(r.coset) && r.n_c <= 1 && r.nb_public == 2;
+    for (int i = 0; i < 8; i++) { k.size[i] = r.size[i]; k.size_p2[i] = r.size[i]; }
+    uint32_t c = 2;
+    for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)k.size_p2[i] + c; k.size_p2[i] = (uint32_t)t; c = (uint32_t)(t >> 32); }
+    k.size_inv = fr_from_raw(r.size_inv); k.gen = fr_from_raw(r.gen); k.coset = fr_from_raw(r.coset);
+    uint32_t e[8] = {r.nb_public + r.cci, 0, 0, 0, 0, 0, 0, 0};
+    k.gen_cci = fr_pow(k.gen, e, 32);
+    k.nb_public = r.nb_public; k.n_c = r.n_c; k.pad = 0;
+    for (int p = 0; p < PK_POINTS; p++) {
+        for (int j = 0; j < 8; j++) { k.raw[p][0][j] = r.pts[p][0][j]; k.raw[p][1][j] = r.pts[p][1][j]; }
+        if (p == PK_QCP && !r.n_c) { k.pts[p].x = fp_zero(); k.pts[p].y = fp_zero(); k.inf[p] = 1; continue; }
+        ok = plonk_g1(r.pts[p][0], r.pts[p][1], k.pts[p], k.inf[p]) && ok;
+    }
+    k.valid = ok ? 1u : 0u;
+}
+
+// ---------------------------------------------------------------- G1 helpers
+ZKV_HD G1J g1j_add(const G1J& p, const G1J& q) {             // complete Jacobian + Jacobian
+    if (fp_is_zero(p.z)) return q;
+    if (fp_is_zero(q.z)) return p;
+    Fp z1z1 = fp_sqr(p.z), z2z2 = fp_sqr(q.z);
+    Fp u1 = fp_mul(p.x, z2z2), u2 = fp_mul(q.x, z1z1);
+    Fp s1 = fp_mul(fp_mul(p.y, q.z), z2z2), s2 = fp_mul(fp_mul(q.y, p.z), z1z1);
+    Fp h = fp_sub(u2, u1), rr = fp_sub(s2, s1);
+    if (fp_is_zero(h)) {
+        if (fp_is_zero(rr)) return g1j_dbl(p);
+        return g1j_infinity();
+    }
+    Fp hh = fp_sqr(h), hhh = fp_mul(hh, h), v = fp_mul(u1, hh);
+    G1J r;
+    r.x = fp_sub(fp_sub(fp_sqr(rr), hhh), fp_dbl(v));
+    r.y = fp_sub(fp_mul(rr, fp_sub(v, r.x)), fp_mul(s1, hhh));
+    r.z = fp_mul(fp_mul(p.z, q.z), h);
+    return r;
+}
+// One term of a multi-scalar multiplication: an affine point (or infinity) and a canonical 256-bit scalar.
+struct MsmTerm { Fp x, y; uint32_t inf; uint32_t k[8]; };
+// acc0 + sum k_i P_i with shared doublings (Straus, one bit per step; the scalars are Fiat-Shamir outputs: ~127 set bits each)
+template <int N> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&t)[N], int n) {
+    G1J acc = g1j_infinity();
+#pragma unroll 1
+    for (int bit = 255; bit >= 0; bit--) {
+        acc = g1j_dbl(acc);
+#pragma unroll 1
+        for (int i = 0; i < n; i++)
+            if (!t[i].inf && ((t[i].k[bit >> 5] >> (bit & 31)) & 1u)) acc = g1j_add_affine(acc, t[i].x, t[i].y);
+    }
+    return g1j_add(acc, start);
+}
+ZKV_HD void plonk_term(MsmTerm& t, const G1A& p, uint32_t inf, const Fr& k) { t.x = p.x; t.y = p.y; t.inf = inf; fr_to_raw(t.k, k); }
+// affine form + canonical coordinates for the transcripts
+struct G1Bytes { uint32_t x[8], y[8]; };
+ZKV_HD void plonk_affine(const G1J& p, G1A& a, uint32_t& inf, G1Bytes& raw) {
+    g1j_to_affine(p, a, inf);
+    if (inf) { for (int i = 0; i < 8; i++) { raw.x[i] = 0; raw.y[i] = 0; } return; }
+    fp_to_raw(raw.x, a.x); fp_to_raw(raw.y, a.y);
+}
+
+// RFC 9380 expand_message_xmd(SHA-256, DST "BSB22-Plonk", 48 bytes) of a 64-byte point, reduced mod r
+ZKV_HD Fr plonk_hash_to_field(const uint32_t x[8], const uint32_t y[8]) {
+    const uint8_t DST[12] = {'B', 'S', 'B', '2', '2', '-', 'P', 'l', 'o', 'n', 'k', 11};
+    uint32_t b0[8], b1[8], b2[8];
+    ShaStream s;
+    s.init();
+    for (int i = 0; i < 16; i++) s.word_be(0);               // Z_pad: one block of zeros
+    s.limbs_be(x); s.limbs_be(y);
+    s.byte(0); s.byte(48); s.byte(0);                        // l_i_b_str = 48, then I2OSP(0, 1)
+    for (int i = 0; i < 12; i++) s.byte(DST[i]);
+    s.finish(b0);
+    s.init();
+    for (int i = 0; i < 8; i++) s.word_be(b0[i]);
+    s.byte(1);
+    for (int i = 0; i < 12; i++) s.byte(DST[i]);
+    s.finish(b1);
+    s.init();
+    for (int i = 0; i < 8; i++) s.word_be(b0[i] ^ b1[i]);
+    s.byte(2);
+    for (int i = 0; i < 12; i++) s.byte(DST[i]);
+    s.finish(b2);
+    uint32_t hi[8], lo[8], sh[8] = {0, 0, 0, 0, 1, 0, 0, 0};             // 2^128
+    digest_to_limbs(b1, hi);
+    for (int i = 0; i < 4; i++) { lo[i] = b2[3 - i]; lo[4 + i] = 0; }   // the first 16 bytes of b2 as a 128-bit integer
+    return fr_add(fr_mul(fr_from_raw_reduce(hi), fr_from_raw(sh)), fr_from_raw(lo));
+}
+
+// ---------------------------------------------------------------- the verifier up to the pairing
+// words: the 27 proof words as canonical limbs.  pub: the two public inputs (program vkey unreduced, public-values hash).
+// Returns false => VerificationFailed.  On success D and Q are the pairing's G1 inputs (Q already negated), either may be infinity.
+struct PlonkOut { G1A d, q; uint32_t d_inf, q_inf; };
+ZKV_HD_NI bool plonk_prepare(const PlonkKey& key, const uint32_t (&w)[27][8], const uint32_t (&pub)[2][8], PlonkOut& out) {
+    if (!key.valid) return false;
+    if (!raw_lt_r(pub[0]) || !raw_lt_r(pub[1])) return false;
+    const int SC[7] = {12, 13, 14, 15, 16, 19, 24};
+    for (int i = 0; i < 7; i++) if (!raw_lt_r(w[SC[i]])) return false;
+    // proof points: L R O H0 H1 H2 Z Hz Hzw BSB
+    const int PT[10] = {0, 2, 4, 6, 8, 10, 17, 20, 22, 25};
+    G1A pp[10]; uint32_t pinf[10];
+    const int n_pts = key.n_c ? 10 : 9;
+#pragma unroll 1
+    for (int i = 0; i < n_pts; i++) if (!plonk_g1(w[PT[i]], w[PT[i] + 1], pp[i], pinf[i])) return false;
+    const uint32_t n_c = key.n_c;
+    // ---- challenges
+    ShaStream s;
+    uint32_t cg[8], cb[8], ca[8], cz[8], lim[8];
+    s.init();
+    s.byte('g'); s.byte('a'); s.byte('m'); s.byte('m'); s.byte('a');
+#pragma unroll 1
+    for (int p = 0; p < 8; p++) { s.limbs_be(key.raw[p][0]); s.limbs_be(key.raw[p][1]); }
+    if (n_c) { s.limbs_be(key.raw[PK_QCP][0]); s.limbs_be(key.raw[PK_QCP][1]); }
+    s.limbs_be(pub[0]); s.limbs_be(pub[1]);
+#pragma unroll 1
+    for (int i = 0; i < 6; i++) s.limbs_be(w[i]);
+    s.finish(cg);
+    s.init(); s.byte('b'); s.byte('e'); s.byte('t'); s.byte('a');
+    for (int i = 0; i < 8; i++) s.word_be(cg[i]);
+    s.finish(cb);
+    s.init(); s.byte('a'); s.byte('l'); s.byte('p'); s.byte('h'); s.byte('a');
+    for (int i = 0; i < 8; i++) s.word_be(cb[i]);
+    if (n_c) { s.limbs_be(w[25]); s.limbs_be(w[26]); }
+    s.limbs_be(w[17]); s.limbs_be(w[18]);
+    s.finish(ca);
+    s.init(); s.byte('z'); s.byte('e'); s.byte('t'); s.byte('a');
+    for (int i = 0; i < 8; i++) s.word_be(ca[i]);
+#pragma unroll 1
+    for (int i = 6; i < 12; i++) s.limbs_be(w[i]);
+    s.finish(cz);
+    digest_to_limbs(cg, lim); const Fr gamma = fr_from_raw_reduce(lim);
+    digest_to_limbs(cb, lim); const Fr beta = fr_from_raw_reduce(lim);
+    digest_to_limbs(ca, lim); const Fr alpha = fr_from_raw_reduce(lim);
+    digest_to_limbs(cz, lim); const Fr zeta = fr_from_raw_reduce(lim);
+    // ---- public-input polynomial at zeta
+    const Fr one = fr_one();
+    const Fr zeta_n = fr_pow(zeta, key.size, 64);
+    const Fr zh = fr_sub(zeta_n, one);
+    Fr den = fr_sub(zeta, one);
+    if (fr_is_zero(den)) return false;
+    // the three denominators zeta - 1, zeta - w, zeta - w^(nb_public + cci) share one inversion
+    const Fr d1 = fr_sub(zeta, key.gen), d2 = fr_sub(zeta, key.gen_cci);
+    if (fr_is_zero(d1) || (n_c && fr_is_zero(d2))) return false;
+    const Fr d2e = n_c ? d2 : one;
+    const Fr p01 = fr_mul(den, d1);
+    const Fr inv_all = fr_inv(fr_mul(p01, d2e));
+    const Fr i2 = fr_mul(inv_all, p01);                    // 1 / d2
+    const Fr i01 = fr_mul(inv_all, d2e);                   // 1 / (den d1)
+    const Fr i0 = fr_mul(i01, d1), i1 = fr_mul(i01, den);
+    const Fr zn = fr_mul(zh, key.size_inv);                // (zeta^n - 1) / n
+    const Fr lag0 = fr_mul(zn, i0);
+    Fr pi = fr_mul(lag0, fr_from_raw(pub[0]));
+    pi = fr_add(pi, fr_mul(fr_mul(fr_mul(zn, i1), key.gen), fr_from_raw(pub[1])));
+    if (n_c) pi = fr_add(pi, fr_mul(fr_mul(fr_mul(zn, i2), key.gen_cci), plonk_hash_to_field(w[25], w[26])));
+    const Fr l = fr_from_raw(w[12]), r = fr_from_raw(w[13]), o = fr_from_raw(w[14]), s1 = fr_from_raw(w[15]), s2 = fr_from_raw(w[16]);
+    const Fr zu = fr_from_raw(w[19]), qcpz = fr_from_raw(w[24]);
+    // ---- opening of the linearised polynomial and the scalars of its digest
+    const Fr a2l0 = fr_mul(fr_mul(lag0, alpha), alpha);
+    const Fr t1 = fr_add(fr_add(fr_mul(beta, s1), l), gamma), t2 = fr_add(fr_add(fr_mul(beta, s2), r), gamma);
+    const Fr at = fr_mul(fr_mul(alpha, t1), t2);
+    const Fr lin_eval = fr_neg(fr_sub(fr_add(fr_mul(fr_mul(at, fr_add(o, gamma)), zu), pi), a2l0));
+    const Fr _s1 = fr_mul(fr_mul(at, beta), zu);
+    const Fr bz = fr_mul(beta, zeta), bzu = fr_mul(bz, key.coset), bzu2 = fr_mul(bzu, key.coset);
+    const Fr _s2 = fr_neg(fr_mul(fr_mul(fr_mul(alpha, fr_add(fr_add(bz, l), gamma)), fr_add(fr_add(bzu, r), gamma)), fr_add(fr_add(bzu2, o), gamma)));
+    const Fr coeff_z = fr_add(a2l0, _s2);
+    const Fr zn2 = fr_pow(zeta, key.size_p2, 64);
+    const Fr k0 = fr_neg(zh), k1 = fr_mul(zn2, k0), k2 = fr_mul(zn2, k1);
+    // ---- linearised polynomial digest: qcp Pi2 + l Ql + r Qr + lr Qm + o Qo + Qk + _s1 S3 + coeff_z Z + k0 H0 + k1 H1 + k2 H2
+    G1J qk = g1j_infinity();
+    if (!key.inf[PK_QK]) { qk.x = key.pts[PK_QK].x; qk.y = key.pts[PK_QK].y; qk.z = fp_one(); }
+    G1A lin_a, fold_a; uint32_t lin_inf, fold_inf; G1Bytes lin_b, fold_b;
+    {
+        MsmTerm t[10];
+        plonk_term(t[0], key.pts[PK_QL], key.inf[PK_QL], l); plonk_term(t[1], key.pts[PK_QR], key.inf[PK_QR], r);
+        plonk_term(t[2], key.pts[PK_QM], key.inf[PK_QM], fr_mul(l, r)); plonk_term(t[3], key.pts[PK_QO], key.inf[PK_QO], o);
+        plonk_term(t[4], key.pts[PK_S3], key.inf[PK_S3], _s1); plonk_term(t[5], pp[6], pinf[6], coeff_z);
+        plonk_term(t[6], pp[3], pinf[3], k0); plonk_term(t[7], pp[4], pinf[4], k1); plonk_term(t[8], pp[5], pinf[5], k2);
+        if (n_c) plonk_term(t[9], pp[9], pinf[9], qcpz);
+        plonk_affine(plonk_msm(qk, t, n_c ? 10 : 9), lin_a, lin_inf, lin_b);
+    }
+    // ---- fold the openings at zeta: gamma_kzg = H("gamma" || zeta || digests || values || zu)
+    uint32_t zr[8], ch[8];
+    s.init(); s.byte('g'); s.byte('a'); s.byte('m'); s.byte('m'); s.byte('a');
+    fr_to_raw(zr, zeta); s.limbs_be(zr);
+    s.limbs_be(lin_b.x); s.limbs_be(lin_b.y);
+#pragma unroll 1
+    for (int i = 0; i < 6; i++) s.limbs_be(w[i]);
+    s.limbs_be(key.raw[PK_S1][0]); s.limbs_be(key.raw[PK_S1][1]); s.limbs_be(key.raw[PK_S2][0]); s.limbs_be(key.raw[PK_S2][1]);
+    if (n_c) { s.limbs_be(key.raw[PK_QCP][0]); s.limbs_be(key.raw[PK_QCP][1]); }
+    uint32_t lr8[8]; fr_to_raw(lr8, lin_eval); s.limbs_be(lr8);
+    s.limbs_be(w[12]); s.limbs_be(w[13]); s.limbs_be(w[14]); s.limbs_be(w[15]); s.limbs_be(w[16]);
+    if (n_c) s.limbs_be(w[24]);
+    s.limbs_be(w[19]);
+    s.finish(ch);
+    digest_to_limbs(ch, lim); const Fr g = fr_from_raw_reduce(lim);
+    Fr folded_eval;
+    {
+        const Fr g2 = fr_mul(g, g), g3 = fr_mul(g2, g), g4 = fr_mul(g3, g), g5 = fr_mul(g4, g), g6 = fr_mul(g5, g);
+        folded_eval = fr_add(lin_eval, fr_add(fr_add(fr_mul(g, l), fr_mul(g2, r)), fr_add(fr_mul(g3, o), fr_add(fr_mul(g4, s1), fr_mul(g5, s2)))));
+        if (n_c) folded_eval = fr_add(folded_eval, fr_mul(g6, qcpz));
+        MsmTerm t[6];
+        plonk_term(t[0], pp[0], pinf[0], g); plonk_term(t[1], pp[1], pinf[1], g2); plonk_term(t[2], pp[2], pinf[2], g3);
+        plonk_term(t[3], key.pts[PK_S1], key.inf[PK_S1], g4); plonk_term(t[4], key.pts[PK_S2], key.inf[PK_S2], g5);
+        if (n_c) plonk_term(t[5], key.pts[PK_QCP], key.inf[PK_QCP], g6);
+        G1J linj = g1j_infinity();
+        if (!lin_inf) { linj.x = lin_a.x; linj.y = lin_a.y; linj.z = fp_one(); }
+        plonk_affine(plonk_msm(linj, t, n_c ? 6 : 5), fold_a, fold_inf, fold_b);
+    }
+    // ---- batch the two openings: lambda = H(folded digest || H_zeta || Z || H_zeta_omega || zeta || gamma_kzg) mod r
+    s.init();
+    s.limbs_be(fold_b.x); s.limbs_be(fold_b.y);
+    s.limbs_be(w[20]); s.limbs_be(w[21]); s.limbs_be(w[17]); s.limbs_be(w[18]); s.limbs_be(w[22]); s.limbs_be(w[23]);
+    s.limbs_be(zr);
+    uint32_t gr[8]; fr_to_raw(gr, g); s.limbs_be(gr);
+    s.finish(ch);
+    digest_to_limbs(ch, lim); const Fr lam = fr_from_raw_reduce(lim);
+    const Fr evals = fr_add(folded_eval, fr_mul(lam, zu));
+    G1J dj, qj;
+    {
+        const Fp gx = fp_one(); Fp two = fp_zero(); two.v[0] = 2;
+        G1A gen; gen.x = gx; gen.y = fp_from_raw(two.v);
+        MsmTerm t[4];
+        plonk_term(t[0], pp[6], pinf[6], lam);
+        plonk_term(t[1], gen, 0, fr_neg(evals));
+        plonk_term(t[2], pp[7], pinf[7], zeta);
+        plonk_term(t[3], pp[8], pinf[8], fr_mul(lam, fr_mul(zeta, key.gen)));
+        G1J fj = g1j_infinity();
+        if (!fold_inf) { fj.x = fold_a.x; fj.y = fold_a.y; fj.z = fp_one(); }
+        dj = plonk_msm(fj, t, 4);
+        MsmTerm u1[1];
+        plonk_term(u1[0], pp[8], pinf[8], lam);
+        G1J hz = g1j_infinity();
+        if (!pinf[7]) { hz.x = pp[7].x; hz.y = pp[7].y; hz.z = fp_one(); }
+        qj = plonk_msm(hz, u1, 1);
+        qj.y = fp_neg(qj.y);
+    }
+    g1j_to_affine(dj, out.d, out.d_inf);
+    g1j_to_affine(qj, out.q, out.q_inf);
+    return true;
+}
+
+}  // namespace zkv

@@ -1,0 +1,53 @@
+// Host build of the PLONK pre-pairing stage (stylus_zkvm_verifiers_amd/csrc/zkv_plonk.h) for CPU-side tests.  TEST ONLY: the
+// shipped library never runs this on the host; it lets `-m "not gpu"` tests check the exact function k_plonk_prep executes
+// (transcript, scalar algebra, MSMs) against oracle/plonk_model.py.
+#include <stdint.h>
+#include <string.h>
+#include "../../stylus_zkvm_verifiers_amd/csrc/zkv_host_vk.h"
+#include "../../stylus_zkvm_verifiers_amd/csrc/zkv_plonk.h"
+
+using namespace zkv;
+
+static void wr_be(uint8_t* p, const uint32_t l[8]) { for (int i = 0; i < 8; i++) for (int k = 0; k < 4; k++) p[31 - 4 * i - k] = (uint8_t)(l[i] >> (8 * k)); }
+
+extern "C" {
+// vk: the serialisation of include/zkv.h (7 words, 8 + n_c points, 256 bytes of G2); proof: 27 x 32 bytes; pub: 2 x 32 bytes.
+// Returns -1 for a malformed key, 0 when the stage rejects, 1 when it produced the pairing inputs: out = D.x D.y Q.x Q.y (128 bytes,
+// (0,0) = infinity).
+int hsp_prepare(const uint8_t* vk, size_t vk_len, const uint8_t* proof, const uint8_t* pub, uint8_t* out128) {
+    if (vk_len < 7 * 32) return -1;
+    uint32_t w7[7][8];
+    for (int k = 0; k < 7; k++) host::be_to_limbs(w7[k], vk + 32 * k);
+    const size_t n_c = w7[5][0];
+    if (n_c > 1 || vk_len != 7 * 32 + (8 + n_c) * 64 + 256) return -1;
+    static PlonkKeyRaw raw; static PlonkKey key;
+    memset(&raw, 0, sizeof raw);
+    memcpy(raw.size, w7[0], 32); memcpy(raw.size_inv, w7[1], 32); memcpy(raw.gen, w7[2], 32); memcpy(raw.coset, w7[3], 32);
+    raw.nb_public = w7[4][0]; raw.n_c = w7[5][0]; raw.cci = w7[6][0];
+    for (size_t p = 0; p < 8 + n_c; p++) { host::be_to_limbs(raw.pts[p][0], vk + 224 + 64 * p); host::be_to_limbs(raw.pts[p][1], vk + 256 + 64 * p); }
+    plonk_setup_key(raw, key);
+    uint32_t w[27][8], pb[2][8];
+    for (int k = 0; k < 27; k++) host::be_to_limbs(w[k], proof + 32 * k);
+    host::be_to_limbs(pb[0], pub); host::be_to_limbs(pb[1], pub + 32);
+    PlonkOut o;
+    if (!plonk_prepare(key, w, pb, o)) return 0;
+    memset(out128, 0, 128);
+    uint32_t r[8];
+    if (!o.d_inf) { fp_to_raw(r, o.d.x); wr_be(out128, r); fp_to_raw(r, o.d.y); wr_be(out128 + 32, r); }
+    if (!o.q_inf) { fp_to_raw(r, o.q.x); wr_be(out128 + 64, r); fp_to_raw(r, o.q.y); wr_be(out128 + 96, r); }
+    return 1;
+}
+// Fr product through the device code (Montgomery in, Montgomery out) on canonical inputs: a * b mod r
+void hsp_fr_mulmod(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    uint32_t x[8], y[8], r[8];
+    host::be_to_limbs(x, a); host::be_to_limbs(y, b);
+    fr_to_raw(r, fr_mul(fr_from_raw_reduce(x), fr_from_raw_reduce(y)));
+    wr_be(out, r);
+}
+void hsp_fr_inv(const uint8_t* a, uint8_t* out) {
+    uint32_t x[8], r[8];
+    host::be_to_limbs(x, a);
+    fr_to_raw(r, fr_inv(fr_from_raw_reduce(x)));
+    wr_be(out, r);
+}
+}
