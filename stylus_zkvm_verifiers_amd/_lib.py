@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libzkv_mi355x.so')
+LIB_PATH = os.environ.get('ZKV_LIB_PATH') or os.path.join(HERE, 'libzkv_mi355x.so')     # ZKV_LIB_PATH: A/B builds of the same library (tools/)
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_WRONG_CTX = 0, -1, -2, -3, -4, -5
 _ERR_NAMES = {ERR_INVALID_ARG: 'ZKV_ERR_INVALID_ARG', ERR_NO_DEVICE: 'ZKV_ERR_NO_DEVICE (no usable gfx950 device; there is no CPU fallback)',

@@ -75,13 +75,6 @@ static size_t chunk_capacity() {
     return (c + 63) & ~(size_t)63;
 }
 
-// Kernel mapping of the Fp2-heavy stages: 2 = one proof per lane pair (default), 1 = one proof per lane.
-static int lanes_per_proof() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("ZKV_LANES_PER_PROOF"); v = (e && e[0] == '1') ? 1 : 2; }
-    return v;
-}
-
 // Chunks of at most this many proofs take the coefficient-parallel kernels (one proof per 16 lanes).  Measured: 5.3-5.6 ms
 // against 11.6 ms up to 4,096 proofs (one wavefront per SIMD), 7.7 against 11.7 ms at 8,192, 10.8 against 11.9 ms at 12,288,
 // 13.2 against 11.9 ms at 16,384: above the threshold the lane-pair kernels win because they do a third of the work per proof.
@@ -289,8 +282,7 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     else if (c->vm == ZKV_VM_GROTH16) launch_prep_groth16(a, c->ws, s);
     else launch_prep_sp1(a, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[1], s);
-    const int lanes = c->lanes ? c->lanes : lanes_per_proof();
-    const bool pair = lanes == 2 || lanes == 16;
+    const int lanes = c->lanes ? c->lanes : 2;       // 2 = one proof per lane pair; 16 = one proof per 16 lanes (small chunks)
     // The subgroup check of B only needs the PREP output and only its verdict (ws.g2bad; the MSM owns ws.flags) is needed, by the
     // final exponentiation: it runs on a second stream beside the MSM and the Miller loop, which is computed speculatively for
     // the rare proof whose B fails the check.  Small chunks leave most of the chip idle, so the check disappears (-0.7 ms); at
@@ -299,7 +291,7 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     if (fork) {
         (void)hipEventRecord(c->ev_fork, s);
         (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
-        if (pair) launch_g2chk2(a.n, c->ws, a.status, c->side); else launch_g2chk(a.n, c->ws, a.status, c->side);
+        launch_g2chk2(a.n, c->ws, a.status, c->side);
         (void)hipEventRecord(c->ev_join, c->side);
     }
     launch_msm(a.n, c->d_tab, a.inst ? c->d_inst : nullptr, c->ws, s);
@@ -307,18 +299,16 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     // Up to 2^16 proofs (one resident set of Miller wavefronts) the check may also run beside the Miller loop; with more, its
     // second round of wavefronts displaces Miller wavefronts and the batch gets slower (measured -11 % at 2^17), so join here.
     const bool late_join = fork && a.n <= ((size_t)1 << 16);
-    if (!fork) { if (pair) launch_g2chk2(a.n, c->ws, a.status, s); else launch_g2chk(a.n, c->ws, a.status, s); }
+    if (!fork) launch_g2chk2(a.n, c->ws, a.status, s);
     else if (!late_join) (void)hipStreamWaitEvent(s, c->ev_join, 0);
     if (timed) (void)hipEventRecord(c->ev[3], s);
-    const bool wide = lanes == 16 || (pair && c->lanes == 0 && a.n <= wide_below());
+    const bool wide = lanes == 16 || (c->lanes == 0 && a.n <= wide_below());
     if (wide) launch_miller_w(a.n, c->d_tab, c->ws, s);
-    else if (pair) launch_miller2(a.n, c->d_tab, c->ws, s);
-    else launch_miller(a.n, c->d_tab, c->ws, s);
+    else launch_miller2(a.n, c->d_tab, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[4], s);
     if (late_join) (void)hipStreamWaitEvent(s, c->ev_join, 0); // the final exponentiation reads the verdict of the subgroup check
     if (wide) launch_finalexp_w(a.n, c->ws, a.status, s);
-    else if (pair) launch_finalexp2(a.n, c->ws, a.status, s);
-    else launch_finalexp(a.n, c->ws, a.status, s);
+    else launch_finalexp2(a.n, c->ws, a.status, s);
     if (timed) (void)hipEventRecord(c->ev[5], s);
 }
 
@@ -1221,7 +1211,7 @@ done:
 // ------------------------------------------------------------------ shared
 ZKV_EXPORT int zkv_ctx_vm(const zkv_ctx* c) { return c ? c->vm : ZKV_ERR_INVALID_ARG; }
 ZKV_EXPORT int zkv_ctx_set_lanes_per_proof(zkv_ctx* c, int lanes) {
-    if (!c || (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 16)) return ZKV_ERR_INVALID_ARG;
+    if (!c || (lanes != 0 && lanes != 2 && lanes != 16)) return ZKV_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     c->lanes = lanes;
     return ZKV_OK;

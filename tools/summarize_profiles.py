@@ -19,7 +19,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main(src, tag):
+def main(src, tag, workload='sp1_2p20'):
     out_dir = os.path.join(ROOT, 'profiles')
     os.makedirs(out_dir, exist_ok=True)
     ks = glob.glob(os.path.join(src, 'ktrace', '*_kernel_stats.csv'))
@@ -42,9 +42,9 @@ def main(src, tag):
     # average per dispatch (one counter row per dispatch per counter; dimensions are already summed by rocprofv3 csv)
     per = {k: {c: v / max(1, calls[k][c]) for c, v in d.items()} for k, d in data.items()}
     cols = ['FETCH_SIZE', 'WRITE_SIZE', 'SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_INST_ANY', 'SQ_BUSY_CYCLES']
-    lines = ['# %s - rocprofv3 PMC summary (MI355X, default bench.py workload)\n' % tag,
+    lines = ['# %s - rocprofv3 PMC summary (MI355X, bench.py workload %s)\n' % (tag, workload),
              'Each counter set was collected in its own pass with --kernel-trace only:',
-             '    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline',
+             '    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-wire --no-mulmod',
              '    rocprofv3 --pmc WRITE_SIZE --kernel-trace ...      rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES ... --kernel-trace ...\n',
              'FETCH_SIZE / WRITE_SIZE in KiB per dispatch as rocprofv3 reports them.  The gfx950 x2 FETCH_SIZE correction of',
              'MI355X_MICROARCH.md applies to wide (16 B/lane) streaming reads; these kernels issue 4 B/lane struct-of-arrays and scratch',
@@ -64,10 +64,10 @@ def main(src, tag):
     lines.append('')
     lines.append('HBM traffic per launch = (FETCH_SIZE + WRITE_SIZE) KiB: ' + ', '.join('%s %.3g GB' % (k, v / 1e9) for k, v in sorted(traffic.items())))
     open(os.path.join(out_dir, tag + '_rocprofv3_pmc_summary.md'), 'w').write('\n'.join(lines) + '\n')
-    json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes per launch', 'bytes_per_launch': traffic},
+    json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes per launch', 'workload': workload, 'bytes_per_launch': traffic},
               open(os.path.join(out_dir, tag + '_pmc_traffic.json'), 'w'), indent=1)
     print('\n'.join(lines[-6:]))
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
