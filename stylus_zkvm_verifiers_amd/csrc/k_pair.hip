@@ -32,17 +32,14 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller2(size_t n, const VkTabl
     uint32_t flags = ws.flags[i];
     if (!(flags & FL_ALIVE)) return;        // the subgroup check of B may still be running: its verdict is read by k_finalexp2
     const uint32_t par = threadIdx.x & 1u;
-    G1Norm nm;                                             // Fp values: both lanes of the pair hold them
-    nm.axs = ws_ld(ws.norm, ws.cap, 0, i); nm.ays = ws_ld(ws.norm, ws.cap, 8, i);
-    nm.lxs = ws_ld(ws.norm, ws.cap, 16, i); nm.lys = ws_ld(ws.norm, ws.cap, 24, i);
-    nm.cxs = ws_ld(ws.norm, ws.cap, 32, i); nm.cys = ws_ld(ws.norm, ws.cap, 40, i);
-    Fp2 bx = ld_b(ws, 32, i), by = ld_b(ws, 48, i);
     LRef fm = l_ref(lds + threadIdx.x);
     LRef tm = l_ref(lds + 48 * ZKV_BLOCK + threadIdx.x);
-    miller_loop_m(vk, flags, nm, bx, by, fm, tm);
+    SoaRef norm = {ws.norm + i, ws.cap};                                        // Fp values: both lanes of the pair read them
+    SoaRef bsrc = {ws.prep + (size_t)(32 + 8 * par) * ws.cap + i, ws.cap};      // this lane's component of B.x (B.y 16 words on)
+    miller_loop_p(vk, flags, norm, bsrc, fm, tm);
     MRef ab = m_ref((uint32_t*)(vk->f_alpha_beta) + 8 * par, 1, 16);
     MRef out = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, (uint32_t)ws.cap, 16);
-    f12m_mul(out, fm, ab);
+    f12m_mul_body(out, fm, ab, false);
 }
 
 __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_finalexp2(size_t n, Workspace ws, uint8_t* __restrict__ status) {
@@ -56,8 +53,8 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_finalexp2(size_t n, Workspace 
     LRef acc = l_ref(lds + threadIdx.x);
     MRef F = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, st, 16);
     MRef E = m_ref(ws.fe + (size_t)(8 * par) * ws.cap + i, st, 16);
-    MRef Y1 = m_off(E, 96), Y3 = m_off(E, 192), Y4 = m_off(E, 288);
-    bool one = final_exp_is_one_m(F, E, Y1, Y3, Y4, m_off(E, 384), acc);
+    MRef accm = m_ref(lds + threadIdx.x, 64, 8);          // the accumulator's LDS words through a flat pointer, for the rare generic operations
+    bool one = final_exp_prog_p(F, E, acc, accm);
     if (!par) status[i] = one ? ST_OK : ST_VERIFICATION_FAILED;
 }
 

@@ -23,6 +23,13 @@
 static thread_local unsigned long long zkv_fp_mul_counter = 0;      // per thread: the lane-pair host emulation runs two
 #endif
 
+// constant tables that are indexed at run time: namespace-scope device constants (a function-local array would be built on the stack)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZKV_TABLE static __device__ const
+#else
+#define ZKV_TABLE static const
+#endif
+
 namespace zkv {
 
 struct Fp { uint32_t v[8]; };

@@ -85,13 +85,14 @@ template <class RA> ZKV_HD bool f12m_is_one(RA a) {
 }
 
 // f <- f^2 (complex squaring, 12 Fp2 products)
-template <class RF> ZKV_HD_NI void f12m_sqr(RF f) {
+template <class RF> ZKV_HD void f12m_sqr_body(RF f) {
     Fp6 g = m_ld_f6(f, 0), h = m_ld_f6(f, 3);
     Fp6 t = f6_mul(g, h);
     Fp6 s = f6_mul(f6_add(g, h), f6_add(g, f6_mul_v(h)));
     m_st_f6(f, 0, f6_sub(f6_sub(s, t), f6_mul_v(t)));
     m_st_f6(f, 3, f6_add(t, t));
 }
+template <class RF> ZKV_HD_NI void f12m_sqr(RF f) { f12m_sqr_body(f); }
 // f <- f^2 for f in the cyclotomic subgroup (after the easy part of the final exponentiation):
 // Granger-Scott, three Fp4 squarings = 6 Fp2 products instead of 12.
 ZKV_HD void fp4_sqr(const Fp2& a, const Fp2& b, Fp2& t0, Fp2& t1) {     // (a + b y)^2, y^2 = xi
@@ -99,7 +100,7 @@ ZKV_HD void fp4_sqr(const Fp2& a, const Fp2& b, Fp2& t0, Fp2& t1) {     // (a + 
     t0 = f2_sub(f2_sub(f2_mul(f2_add(a, b), f2_add(f2_mul_xi(b), a)), tmp), f2_mul_xi(tmp));
     t1 = f2_dbl(tmp);
 }
-template <class RF> ZKV_HD_NI void f12m_cyclo_sqr(RF f) {
+template <class RF> ZKV_HD void f12m_cyclo_sqr_body(RF f) {
     // memory order g0 g1 g2 h0 h1 h2; pairs (g0,h1), (h0,g2), (g1,h2)
     Fp2 z0 = m_ld_f2(f, 0), z1 = m_ld_f2(f, 4), t0, t1;
     fp4_sqr(z0, z1, t0, t1);
@@ -117,56 +118,54 @@ template <class RF> ZKV_HD_NI void f12m_cyclo_sqr(RF f) {
     z5 = f2_add(t3, z5); z5 = f2_add(f2_dbl(z5), t3);           // 3 t3 + 2 z5
     m_st_f2(f, 3, z2); m_st_f2(f, 2, z3); m_st_f2(f, 1, z4); m_st_f2(f, 5, z5);
 }
-// d <- a * b (d may alias a or b)
-template <class RD, class RA, class RB> ZKV_HD_NI void f12m_mul(RD d, RA a, RB b) {
+template <class RF> ZKV_HD_NI void f12m_cyclo_sqr(RF f) { f12m_cyclo_sqr_body(f); }
+// d <- a * b, or a * conj(b) (conj(b) = b^-1 for b in the cyclotomic subgroup); d may alias a or b
+template <class RD, class RA, class RB> ZKV_HD void f12m_mul_body(RD d, RA a, RB b, bool conj_b) {
     Fp6 ag = m_ld_f6(a, 0), bg = m_ld_f6(b, 0);
     Fp6 t0 = f6_mul(ag, bg);
     Fp6 ah = m_ld_f6(a, 3), bh = m_ld_f6(b, 3);
+    if (conj_b) bh = f6_neg(bh);
     Fp6 t1 = f6_mul(ah, bh);
     Fp6 m = f6_mul(f6_add(ag, ah), f6_add(bg, bh));
     m_st_f6(d, 3, f6_sub(f6_sub(m, t0), t1));
     m_st_f6(d, 0, f6_add(t0, f6_mul_v(t1)));
 }
-// d <- a * conj(b)  (conj(b) = b^-1 for b in the cyclotomic subgroup)
-template <class RD, class RA, class RB> ZKV_HD_NI void f12m_mul_conj(RD d, RA a, RB b) {
-    Fp6 ag = m_ld_f6(a, 0), bg = m_ld_f6(b, 0);
-    Fp6 t0 = f6_mul(ag, bg);
-    Fp6 ah = m_ld_f6(a, 3), bh = f6_neg(m_ld_f6(b, 3));
-    Fp6 t1 = f6_mul(ah, bh);
-    Fp6 m = f6_mul(f6_add(ag, ah), f6_add(bg, bh));
-    m_st_f6(d, 3, f6_sub(f6_sub(m, t0), t1));
-    m_st_f6(d, 0, f6_add(t0, f6_mul_v(t1)));
-}
+template <class RD, class RA, class RB> ZKV_HD_NI void f12m_mul(RD d, RA a, RB b) { f12m_mul_body(d, a, b, false); }
+template <class RD, class RA, class RB> ZKV_HD_NI void f12m_mul_conj(RD d, RA a, RB b) { f12m_mul_body(d, a, b, true); }
 // f <- f * (c0 + (c3 + c4 v) w)
-template <class RF> ZKV_HD_NI void f12m_mul_by_034(RF f, const Fp2* c0, const Fp2* c3, const Fp2* c4) {
+template <class RF> ZKV_HD void f12m_mul_by_034_body(RF f, const Fp2& c0, const Fp2& c3, const Fp2& c4) {
     Fp6 g = m_ld_f6(f, 0), h = m_ld_f6(f, 3);
-    Fp6 t0 = f6_mul_fp2(g, *c0);
-    Fp6 t1 = f6_mul_by_01(h, *c3, *c4);
-    Fp6 t2 = f6_mul_by_01(f6_add(g, h), f2_add(*c0, *c3), *c4);
+    Fp6 t0 = f6_mul_fp2(g, c0);
+    Fp6 t1 = f6_mul_by_01(h, c3, c4);
+    Fp6 t2 = f6_mul_by_01(f6_add(g, h), f2_add(c0, c3), c4);
     m_st_f6(f, 3, f6_sub(f6_sub(t2, t0), t1));
     m_st_f6(f, 0, f6_add(t0, f6_mul_v(t1)));
 }
+template <class RF> ZKV_HD_NI void f12m_mul_by_034(RF f, const Fp2* c0, const Fp2* c3, const Fp2* c4) { f12m_mul_by_034_body(f, *c0, *c3, *c4); }
 // f <- f * (1 + (c3 + c4 v) w)
-template <class RF> ZKV_HD_NI void f12m_mul_by_134(RF f, const Fp2* c3, const Fp2* c4) {
+template <class RF> ZKV_HD void f12m_mul_by_134_body(RF f, const Fp2& c3, const Fp2& c4) {
     Fp6 g = m_ld_f6(f, 0), h = m_ld_f6(f, 3);
-    Fp6 hs = f6_mul_by_01(h, *c3, *c4);
-    Fp6 gs = f6_mul_by_01(g, *c3, *c4);
+    Fp6 hs = f6_mul_by_01(h, c3, c4);
+    Fp6 gs = f6_mul_by_01(g, c3, c4);
     m_st_f6(f, 0, f6_add(g, f6_mul_v(hs)));
     m_st_f6(f, 3, f6_add(h, gs));
 }
+template <class RF> ZKV_HD_NI void f12m_mul_by_134(RF f, const Fp2* c3, const Fp2* c4) { f12m_mul_by_134_body(f, *c3, *c4); }
 // d <- a^-1
-template <class RD, class RA> ZKV_HD_NI void f12m_inv(RD d, RA a) {
+template <class RD, class RA> ZKV_HD void f12m_inv_body(RD d, RA a) {
     Fp6 g = m_ld_f6(a, 0), h = m_ld_f6(a, 3);
     Fp6 t = f6_sub(f6_mul(g, g), f6_mul_v(f6_mul(h, h)));
     t = f6_inv(t);
     m_st_f6(d, 0, f6_mul(g, t));
     m_st_f6(d, 3, f6_neg(f6_mul(h, t)));
 }
+template <class RD, class RA> ZKV_HD_NI void f12m_inv(RD d, RA a) { f12m_inv_body(d, a); }
 // d <- pi^k(a), k = 1, 2, 3 (d may alias a)
-template <class RD, class RA> ZKV_HD_NI void f12m_frob(RD d, RA a, int k) {
-    const Fp2C G1[6] = ZKV_FROB1;
-    const Fp G2[6] = ZKV_FROB2;
-    const Fp2C G3[6] = ZKV_FROB3;
+ZKV_TABLE Fp2C ZKV_FROB1_TAB[6] = ZKV_FROB1;
+ZKV_TABLE Fp ZKV_FROB2_TAB[6] = ZKV_FROB2;
+ZKV_TABLE Fp2C ZKV_FROB3_TAB[6] = ZKV_FROB3;
+template <class RD, class RA> ZKV_HD void f12m_frob_body(RD d, RA a, int k) {
+    const Fp2C* G1 = ZKV_FROB1_TAB; const Fp* G2 = ZKV_FROB2_TAB; const Fp2C* G3 = ZKV_FROB3_TAB;
     // memory order g0 g1 g2 h0 h1 h2 <-> w-powers 0 2 4 1 3 5
     const int wp[6] = {0, 2, 4, 1, 3, 5};
 #pragma unroll 1
@@ -181,6 +180,7 @@ template <class RD, class RA> ZKV_HD_NI void f12m_frob(RD d, RA a, int k) {
         m_st_f2(d, i, c);
     }
 }
+template <class RD, class RA> ZKV_HD_NI void f12m_frob(RD d, RA a, int k) { f12m_frob_body(d, a, k); }
 
 // T <- 2T with tangent-line coefficients (T is 3 Fp2 in memory)
 template <class RT> ZKV_HD_NI void g2m_line_dbl(RT Tm, Fp2* l0, Fp2* l1, Fp2* l3) {

@@ -260,6 +260,62 @@ ZKV_HD void miller_loop_m(const VkTables* vkp, uint32_t flags, const G1Norm& n, 
     }
 }
 
+#if defined(ZKV_PAIRED)
+// The same loop for the lane-pair kernel, as ONE flat sequence of 88 line steps in which every Fp12-level routine is inlined at
+// exactly one place.  Why: a non-inlined Fp12 routine keeps its cross-call values in callee-saved VGPRs and must save / restore them
+// around its body (27 dwords per f12m_sqr call, about 5,000 scratch accesses per proof and lane, every one of which reaches HBM: 3.4 GB
+// per 2^16-proof launch, profiles/round1_pair_pmc_traffic.json).  Inlined into the kernel -- which has no caller to preserve anything
+// for -- the routines need no frame; only fp_mul / f2_mul_lane stay calls (leaf functions inside the caller-saved registers).
+// Per-proof constants (x/y and 1/y of the three G1 points, B) are re-read from their workspace rows where they are used instead of
+// being held in registers across the whole loop.
+struct SoaRef {                         // word k of this proof's (this lane's) value at p[k * stride]
+    const uint32_t* p; size_t stride;
+    ZKV_HD Fp fp(int word0) const {
+        Fp r;
+#pragma unroll
+        for (int k = 0; k < 8; k++) r.v[k] = p[(size_t)(word0 + k) * stride];
+        return r;
+    }
+};
+// norm: axs ays lxs lys cxs cys at words 0 8 16 24 32 40; bsrc: this lane's component of B.x at word 0 and of B.y at word 16.
+template <class RF, class RT>
+ZKV_HD void miller_loop_p(const VkTables* vkp, uint32_t flags, SoaRef norm, SoaRef bsrc, RF fm, RT tm) {
+    const uint8_t KIND[ZKV_MILLER_STEPS] = ZKV_MILLER_STEP_KIND;
+    const bool with_fixed = vkp != nullptr;
+    const bool do_ab = !(flags & (FL_A_INF | FL_B_INF));
+    const bool do_l = with_fixed && !(flags & FL_L_INF) && !vkp->skip_fixed[0], do_c = with_fixed && !(flags & FL_C_INF) && !vkp->skip_fixed[1];
+    f12m_set_one(fm);
+    { Fp2 bx, by; bx.h = bsrc.fp(0); by.h = bsrc.fp(16); m_st_f2(tm, 0, bx); m_st_f2(tm, 1, by); m_st_f2(tm, 2, f2_one()); }
+#pragma unroll 1
+    for (int li = 0; li < ZKV_MILLER_STEPS; li++) {
+        const int kind = KIND[li];
+        if (kind == 0 && li != 0) f12m_sqr_body(fm);
+        if (do_ab) {
+            Fp2 l0, l1, l3;
+            G2H T; T.x = m_ld_f2(tm, 0); T.y = m_ld_f2(tm, 1); T.z = m_ld_f2(tm, 2);
+            if (kind == 0) line_dbl(T, l0, l1, l3);
+            else {
+                Fp2 qx, qy; qx.h = bsrc.fp(0); qy.h = bsrc.fp(16);
+                if (kind == 2) qy = f2_neg(qy);
+                else if (kind == 3) { Fp2 x, y; g2_frob_affine(x, y, qx, qy); qx = x; qy = y; }
+                else if (kind == 4) { Fp2 x, y; g2_frob2_affine(x, y, qx, qy); qx = x; qy = f2_neg(y); }
+                line_add(T, qx, qy, l0, l1, l3);
+            }
+            m_st_f2(tm, 0, T.x); m_st_f2(tm, 1, T.y); m_st_f2(tm, 2, T.z);
+            const Fp2 c3 = f2_mul_fp(l1, norm.fp(0)), c4 = f2_mul_fp(l3, norm.fp(8));
+            f12m_mul_by_034_body(fm, l0, c3, c4);
+        }
+#pragma unroll 1
+        for (int j = 0; j < 2; j++) {
+            if (j == 0 ? !do_l : !do_c) continue;
+            const LineAffC& L = vkp->lines[j][li];
+            const Fp2 c3 = f2_mul_fp(f2_const(L.nl), norm.fp(16 + 16 * j)), c4 = f2_mul_fp(f2_const(L.c), norm.fp(24 + 16 * j));
+            f12m_mul_by_134_body(fm, c3, c4);
+        }
+    }
+}
+#endif  // ZKV_PAIRED
+
 // ---------------------------------------------------------------- stage FINALEXP
 // acc <- x^u  (acc and x are different slots; x in the cyclotomic subgroup).  Width-3 signed sliding window: x^3, x^5, x^7
 // go to the three scratch slots at W (one cyclotomic squaring + 3 multiplications), then 62 cyclotomic squarings and 13
@@ -317,6 +373,37 @@ template <class RA> ZKV_HD bool final_exp_is_one_m(MRef F, MRef E, MRef Y1, MRef
     f12m_mul(acc, E, acc);
     return f12m_is_one(acc);
 }
+
+#if defined(ZKV_PAIRED)
+// The same final exponentiation for the lane-pair kernel as a PROGRAM of Fp12-level operations (ZKV_FE_PROG, generated from the chain
+// above by gen_constants.py: 275 entries) run by one loop in which every operation body is inlined exactly once -- no Fp12-level calls,
+// hence no callee-saved-register frames (see miller_loop_p).  The two hot operations keep the typed-LDS accumulator: the cyclotomic
+// squaring of ACC (186 entries) and ACC <- ACC * S / ACC * conj(S) with S in an HBM slot (49 entries); everything else (40 entries)
+// goes through one generic body in which ACC is addressed through `accm`, a flat view of the same LDS words.
+// slots: 0 ACC, 1 F, 2.. = E, Y1, Y3, Y4, X3, X5, X7 (consecutive 96-word slots from E).
+ZKV_HD MRef fe_slot(int s, MRef accm, MRef F, MRef E) { return s == 0 ? accm : s == 1 ? F : m_off(E, 96 * (s - 2)); }
+template <class RA> ZKV_HD bool final_exp_prog_p(MRef F, MRef E, RA acc, MRef accm) {
+    const uint32_t PROG[ZKV_FE_PROG_LEN] = ZKV_FE_PROG;
+    bool one = false;
+#pragma unroll 1
+    for (int pc = 0; pc < ZKV_FE_PROG_LEN; pc++) {
+        const uint32_t e = PROG[pc];
+        const int op = (int)(e & 255u), d = (int)((e >> 8) & 255u), a = (int)((e >> 16) & 255u), b = (int)(e >> 24);
+        if (op == 6) f12m_cyclo_sqr_body(acc);
+        else if ((op == 3 || op == 4) && d == 0 && a == 0 && b != 0) f12m_mul_body(acc, acc, fe_slot(b, accm, F, E), op == 4);
+        else {
+            const MRef D = fe_slot(d, accm, F, E), A = fe_slot(a, accm, F, E);
+            if (op == 3 || op == 4) f12m_mul_body(D, A, fe_slot(b, accm, F, E), op == 4);
+            else if (op == 0) f12m_copy(D, A);
+            else if (op == 1) f12m_conj(D);
+            else if (op == 2) f12m_inv_body(D, A);
+            else if (op == 5) f12m_frob_body(D, A, b);
+            else one = f12m_is_one(D);
+        }
+    }
+    return one;
+}
+#endif
 
 #if !defined(ZKV_PAIRED)
 // ---------------------------------------------------------------- context set-up (run once per VK on the device)

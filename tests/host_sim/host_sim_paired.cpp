@@ -45,12 +45,13 @@ static void lane(Job* j, uint32_t par) {
     static thread_local uint32_t half[48 + 24];
     static uint32_t full[8 * 96];                    // shared by the two lanes like the HBM slots
     MRef fm = m_ref(half, 1, 8), tm = m_ref(half + 48, 1, 8);
-    miller_loop_m(j->t, j->flags, n, bx, by, fm, tm);
+    SoaRef norm = {j->norm48, 1}, bsrc = {j->b32 + 8 * par, 1};
+    miller_loop_p(j->t, j->flags, norm, bsrc, fm, tm);        // the flat, fully inlined loop k_miller2 runs
     MRef ab = m_ref((uint32_t*)j->t->f_alpha_beta + 8 * par, 1, 16);
     MRef F = m_ref(full + 8 * par, 1, 16), E = m_ref(full + 96 + 8 * par, 1, 16);
     f12m_mul(F, fm, ab);
     j->muls[par][1] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
-    j->accept[par] = final_exp_is_one_m(F, E, m_off(E, 96), m_off(E, 192), m_off(E, 288), m_off(E, 384), fm) ? 1 : 0;
+    j->accept[par] = final_exp_prog_p(F, E, fm, fm) ? 1 : 0;          // the interpreted program k_finalexp2 runs
     j->muls[par][2] = zkv_fp_mul_counter - c0;
 }
 // Fp multiplications (a lane's Fp2 product counts 2, fp_mul 1) spent by BOTH lanes of the pair in g2chk, miller, finalexp
