@@ -134,7 +134,11 @@ struct PlonkKey {
     uint32_t nb_public, n_c, valid, pad;
     G1A pts[PK_POINTS]; uint32_t inf[PK_POINTS];
     uint32_t raw[PK_POINTS][2][8];  // the same points as canonical integers, for the transcripts
+    G1A mult[PK_POINTS + 1][8];     // k * P, k = 1..8, affine, for the nine key points and (last row) the G1 generator: the
+                                    // signed-window tables of the FIXED terms of the multi-scalar multiplications
+    uint32_t mult_inf[PK_POINTS + 1][8];
 };
+constexpr int PK_GEN = PK_POINTS;
 // A G1 point as the precompiles take it: coordinates < P, on the curve or (0,0) = infinity.  Returns false when invalid.
 ZKV_HD bool plonk_g1(const uint32_t x[8], const uint32_t y[8], G1A& out, uint32_t& inf) {
     if (!raw_lt_p(x) || !raw_lt_p(y)) return false;
@@ -157,6 +161,19 @@ ZKV_HD void plonk_setup_key(const PlonkKeyRaw& r, PlonkKey& k) {
         ok = plonk_g1(r.pts[p][0], r.pts[p][1], k.pts[p], k.inf[p]) && ok;
     }
     k.valid = ok ? 1u : 0u;
+    // window tables (a key point may have small order only if it is the point at infinity: the curve has prime order)
+#pragma unroll 1
+    for (int p = 0; p <= PK_POINTS; p++) {
+        G1A base; uint32_t binf = 0;
+        if (p == PK_GEN) { base.x = fp_one(); Fp two = fp_zero(); two.v[0] = 2; base.y = fp_from_raw(two.v); }
+        else { base = k.pts[p]; binf = k.inf[p]; }
+        G1J acc = g1j_infinity();
+#pragma unroll 1
+        for (int m = 0; m < 8; m++) {
+            if (!binf && ok) acc = g1j_add_affine(acc, base.x, base.y);
+            g1j_to_affine(acc, k.mult[p][m], k.mult_inf[p][m]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- G1 helpers
@@ -179,20 +196,69 @@ ZKV_HD G1J g1j_add(const G1J& p, const G1J& q) {             // complete Jacobia
     return r;
 }
 // One term of a multi-scalar multiplication: an affine point (or infinity) and a canonical 256-bit scalar.
-struct MsmTerm { Fp x, y; uint32_t inf; uint32_t k[8]; };
-// acc0 + sum k_i P_i with shared doublings (Straus, one bit per step; the scalars are Fiat-Shamir outputs: ~127 set bits each)
+struct MsmTerm { Fp x, y; uint32_t inf; uint32_t k[8]; const G1A* fixed; };      // fixed: the key's affine table of 1P..8P, or null
+// start + sum k_i P_i: Straus with SIGNED 4-BIT WINDOWS.  Per term the multiples P .. 8P (Jacobian) are tabulated once; the 64
+// windows of the shared doubling chain then add +-(|d| P) for every term -- every lane of the wavefront takes the same path
+// (a one-bit-per-step loop executes each chord addition for all lanes although only half of them need it: 256 additions per
+// term instead of 64).  Scalars are < r < 2^254, so the recoding never carries out of the top window.
+struct MsmTable { G1J m[8]; };
+ZKV_HD void plonk_msm_table(MsmTable& tb, const MsmTerm& t) {
+    G1J p; p.x = t.x; p.y = t.y; p.z = fp_one();
+    tb.m[0] = p;
+    tb.m[1] = g1j_dbl(p);
+    tb.m[2] = g1j_add_affine(tb.m[1], t.x, t.y);
+    tb.m[3] = g1j_dbl(tb.m[1]);
+    tb.m[4] = g1j_add_affine(tb.m[3], t.x, t.y);
+    tb.m[5] = g1j_dbl(tb.m[2]);
+    tb.m[6] = g1j_add_affine(tb.m[5], t.x, t.y);
+    tb.m[7] = g1j_dbl(tb.m[3]);
+}
 template <int N> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&t)[N], int n) {
+    MsmTable tab[N];
+    uint32_t dig[N][8];                                   // 64 signed digits per term, packed 4 bits each as d + 8 (0..15)
+#pragma unroll 1
+    for (int i = 0; i < n; i++) {
+        if (t[i].inf) continue;
+        if (!t[i].fixed) plonk_msm_table(tab[i], t[i]);
+        uint32_t carry = 0;
+#pragma unroll 1
+        for (int w = 0; w < 8; w++) {
+            uint32_t out = 0;
+#pragma unroll 1
+            for (int j = 0; j < 8; j++) {
+                uint32_t d = ((t[i].k[w] >> (4 * j)) & 15u) + carry;          // 0 .. 16
+                carry = d >= 8u ? 1u : 0u;
+                out |= ((d + 8u) & 15u) << (4 * j);                            // d - 16 * carry + 8
+            }
+            dig[i][w] = out;
+        }
+    }
     G1J acc = g1j_infinity();
 #pragma unroll 1
-    for (int bit = 255; bit >= 0; bit--) {
-        acc = g1j_dbl(acc);
+    for (int win = 63; win >= 0; win--) {
+        acc = g1j_dbl(g1j_dbl(g1j_dbl(g1j_dbl(acc))));
 #pragma unroll 1
-        for (int i = 0; i < n; i++)
-            if (!t[i].inf && ((t[i].k[bit >> 5] >> (bit & 31)) & 1u)) acc = g1j_add_affine(acc, t[i].x, t[i].y);
+        for (int i = 0; i < n; i++) {
+            if (t[i].inf) continue;
+            const int d = (int)((dig[i][win >> 3] >> (4 * (win & 7))) & 15u) - 8;       // -8 .. 7
+            if (d == 0) continue;
+            const int m = (d < 0 ? -d : d) - 1;
+            if (t[i].fixed) {                                    // wave-uniform: the same term index in every lane
+                const G1A e = t[i].fixed[m];
+                acc = g1j_add_affine(acc, e.x, d < 0 ? fp_neg(e.y) : e.y);
+            } else {
+                G1J q = tab[i].m[m];
+                if (d < 0) q.y = fp_neg(q.y);
+                acc = g1j_add(acc, q);
+            }
+        }
     }
     return g1j_add(acc, start);
 }
-ZKV_HD void plonk_term(MsmTerm& t, const G1A& p, uint32_t inf, const Fr& k) { t.x = p.x; t.y = p.y; t.inf = inf; fr_to_raw(t.k, k); }
+ZKV_HD void plonk_term(MsmTerm& t, const G1A& p, uint32_t inf, const Fr& k) { t.x = p.x; t.y = p.y; t.inf = inf; t.fixed = nullptr; fr_to_raw(t.k, k); }
+ZKV_HD void plonk_key_term(MsmTerm& t, const PlonkKey& key, int p, const Fr& k) {      // a key point (or PK_GEN): table from the context
+    t.x = key.mult[p][0].x; t.y = key.mult[p][0].y; t.inf = key.mult_inf[p][0]; t.fixed = key.mult[p]; fr_to_raw(t.k, k);
+}
 // affine form + canonical coordinates for the transcripts
 struct G1Bytes { uint32_t x[8], y[8]; };
 ZKV_HD void plonk_affine(const G1J& p, G1A& a, uint32_t& inf, G1Bytes& raw) {
@@ -312,9 +378,9 @@ ZKV_HD_NI bool plonk_prepare(const PlonkKey& key, const uint32_t (&w)[27][8], co
     G1A lin_a, fold_a; uint32_t lin_inf, fold_inf; G1Bytes lin_b, fold_b;
     {
         MsmTerm t[10];
-        plonk_term(t[0], key.pts[PK_QL], key.inf[PK_QL], l); plonk_term(t[1], key.pts[PK_QR], key.inf[PK_QR], r);
-        plonk_term(t[2], key.pts[PK_QM], key.inf[PK_QM], fr_mul(l, r)); plonk_term(t[3], key.pts[PK_QO], key.inf[PK_QO], o);
-        plonk_term(t[4], key.pts[PK_S3], key.inf[PK_S3], _s1); plonk_term(t[5], pp[6], pinf[6], coeff_z);
+        plonk_key_term(t[0], key, PK_QL, l); plonk_key_term(t[1], key, PK_QR, r);
+        plonk_key_term(t[2], key, PK_QM, fr_mul(l, r)); plonk_key_term(t[3], key, PK_QO, o);
+        plonk_key_term(t[4], key, PK_S3, _s1); plonk_term(t[5], pp[6], pinf[6], coeff_z);
         plonk_term(t[6], pp[3], pinf[3], k0); plonk_term(t[7], pp[4], pinf[4], k1); plonk_term(t[8], pp[5], pinf[5], k2);
         if (n_c) plonk_term(t[9], pp[9], pinf[9], qcpz);
         plonk_affine(plonk_msm(qk, t, n_c ? 10 : 9), lin_a, lin_inf, lin_b);
@@ -341,8 +407,8 @@ ZKV_HD_NI bool plonk_prepare(const PlonkKey& key, const uint32_t (&w)[27][8], co
         if (n_c) folded_eval = fr_add(folded_eval, fr_mul(g6, qcpz));
         MsmTerm t[6];
         plonk_term(t[0], pp[0], pinf[0], g); plonk_term(t[1], pp[1], pinf[1], g2); plonk_term(t[2], pp[2], pinf[2], g3);
-        plonk_term(t[3], key.pts[PK_S1], key.inf[PK_S1], g4); plonk_term(t[4], key.pts[PK_S2], key.inf[PK_S2], g5);
-        if (n_c) plonk_term(t[5], key.pts[PK_QCP], key.inf[PK_QCP], g6);
+        plonk_key_term(t[3], key, PK_S1, g4); plonk_key_term(t[4], key, PK_S2, g5);
+        if (n_c) plonk_key_term(t[5], key, PK_QCP, g6);
         G1J linj = g1j_infinity();
         if (!lin_inf) { linj.x = lin_a.x; linj.y = lin_a.y; linj.z = fp_one(); }
         plonk_affine(plonk_msm(linj, t, n_c ? 6 : 5), fold_a, fold_inf, fold_b);
@@ -358,11 +424,9 @@ ZKV_HD_NI bool plonk_prepare(const PlonkKey& key, const uint32_t (&w)[27][8], co
     const Fr evals = fr_add(folded_eval, fr_mul(lam, zu));
     G1J dj, qj;
     {
-        const Fp gx = fp_one(); Fp two = fp_zero(); two.v[0] = 2;
-        G1A gen; gen.x = gx; gen.y = fp_from_raw(two.v);
         MsmTerm t[4];
         plonk_term(t[0], pp[6], pinf[6], lam);
-        plonk_term(t[1], gen, 0, fr_neg(evals));
+        plonk_key_term(t[1], key, PK_GEN, fr_neg(evals));
         plonk_term(t[2], pp[7], pinf[7], zeta);
         plonk_term(t[3], pp[8], pinf[8], fr_mul(lam, fr_mul(zeta, key.gen)));
         G1J fj = g1j_infinity();
