@@ -4,6 +4,8 @@
 //   kind 0  fp_mul        one 81-term column product + one Montgomery reduction per call                (1 mulmod per lane-call)
 //   kind 1  f2_mul_lane   the lane-pair Fp2 product: two column products + one reduction per lane       (2 mulmods per lane-call,
 //                         the unit the op counter of tests/host_sim counts for the pair kernels)
+//   kind 2 / 3 / 4        the other primitives of the instruction stream, counted per lane-call (kind 1's factor 2 does not apply):
+//                         modular add / sub as single carry chains, as interleaved pairs (fp_add_x2 / fp_sub_x2), and f2_mul_xi
 // Rates are measured in TIME (HIP events around the launch), so no clock frequency is assumed anywhere; the shader clock under
 // this load is reported separately from s_memtime / s_memrealtime when the two counters differ.
 #define ZKV_PAIRED 1
@@ -25,7 +27,14 @@ __global__ __launch_bounds__(64) void k_diag_mulmod(uint32_t iters, uint32_t* __
 #pragma unroll 1
     for (uint32_t i = 0; i < iters; i++) {
         if (KIND == 0) { a0 = fp_mul(a0, b0); a1 = fp_mul(a1, b1); b0 = fp_mul(b0, a1); b1 = fp_mul(b1, a0); }
-        else { a0 = f2_mul_lane(a0, b0); a1 = f2_mul_lane(a1, b1); b0 = f2_mul_lane(b0, a1); b1 = f2_mul_lane(b1, a0); }
+        else if (KIND == 1) { a0 = f2_mul_lane(a0, b0); a1 = f2_mul_lane(a1, b1); b0 = f2_mul_lane(b0, a1); b1 = f2_mul_lane(b1, a0); }
+        else if (KIND == 2) { a0 = fp_add(a0, b0); a1 = fp_sub(a1, b1); b0 = fp_add(b0, a1); b1 = fp_sub(b1, a0); }          // four single chains
+        else if (KIND == 3) {                                                                                             // four ops as two interleaved pairs
+            Fp r0, r1; fp_add_x2(a0, b0, a1, b1, r0, r1); a0 = r0; a1 = r1;
+            fp_sub_x2(b0, a1, b1, a0, r0, r1); b0 = r0; b1 = r1;
+        } else {                                                                                                          // four xi-multiplications
+            Fp2 x; x.h = a0; a0 = f2_mul_xi(x).h; x.h = a1; a1 = f2_mul_xi(x).h; x.h = b0; b0 = f2_mul_xi(x).h; x.h = b1; b1 = f2_mul_xi(x).h;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         clk[0] = __builtin_readcyclecounter() - t0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
@@ -37,7 +46,10 @@ __global__ __launch_bounds__(64) void k_diag_mulmod(uint32_t iters, uint32_t* __
 
 void launch_diag_mulmod(int kind, unsigned blocks, uint32_t iters, uint32_t* out, unsigned long long* clk, hipStream_t s) {
     if (kind == 0) hipLaunchKernelGGL(k_diag_mulmod<0>, dim3(blocks), dim3(64), 0, s, iters, out, clk);
-    else hipLaunchKernelGGL(k_diag_mulmod<1>, dim3(blocks), dim3(64), 0, s, iters, out, clk);
+    else if (kind == 1) hipLaunchKernelGGL(k_diag_mulmod<1>, dim3(blocks), dim3(64), 0, s, iters, out, clk);
+    else if (kind == 2) hipLaunchKernelGGL(k_diag_mulmod<2>, dim3(blocks), dim3(64), 0, s, iters, out, clk);
+    else if (kind == 3) hipLaunchKernelGGL(k_diag_mulmod<3>, dim3(blocks), dim3(64), 0, s, iters, out, clk);
+    else hipLaunchKernelGGL(k_diag_mulmod<4>, dim3(blocks), dim3(64), 0, s, iters, out, clk);
 }
 
 }  // namespace zkv

@@ -1174,7 +1174,7 @@ ZKV_EXPORT int zkv_ctx_vk_x_batch(zkv_ctx* c, size_t n, const uint8_t* var_signa
 
 // ------------------------------------------------------------------ diagnostics: multiplication-rate microbenchmark
 ZKV_EXPORT int zkv_diag_mulmod_rate(int device, int kind, int waves_per_simd, uint32_t iters, double* mulmods_per_s, double* shader_clock_ghz) {
-    if ((kind != 0 && kind != 1) || waves_per_simd < 1 || waves_per_simd > 8 || !iters || !mulmods_per_s) return ZKV_ERR_INVALID_ARG;
+    if (kind < 0 || kind > 4 || waves_per_simd < 1 || waves_per_simd > 8 || !iters || !mulmods_per_s) return ZKV_ERR_INVALID_ARG;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return ZKV_ERR_NO_DEVICE; }
     if (device < 0 || device >= n || !device_is_gfx950(device)) return ZKV_ERR_NO_DEVICE;
@@ -1196,7 +1196,7 @@ ZKV_EXPORT int zkv_diag_mulmod_rate(int device, int kind, int waves_per_simd, ui
     if (hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) goto done;
     if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipMemcpy(clk, d_clk, 16, hipMemcpyDeviceToHost) != hipSuccess) goto done;
     // four primitive calls per iteration and lane; kind 1 counts two multiplications per call
-    *mulmods_per_s = (double)blocks * 64.0 * 4.0 * (kind ? 2.0 : 1.0) * (double)iters / ((double)ms * 1e-3);
+    *mulmods_per_s = (double)blocks * 64.0 * 4.0 * (kind == 1 ? 2.0 : 1.0) * (double)iters / ((double)ms * 1e-3);
     if (shader_clock_ghz) *shader_clock_ghz = clk[1] ? 0.1 * (double)clk[0] / (double)clk[1] : 0.0;     // s_memrealtime ticks at 100 MHz
     rc = ZKV_OK;
 done:

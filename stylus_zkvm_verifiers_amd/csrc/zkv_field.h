@@ -466,11 +466,44 @@ ZKV_HD Fp2 f2_sqr(const Fp2& a) {           // reduced (< 2p) input: even lane (
     return r;
 }
 ZKV_HD Fp2 f2_mul_fp(const Fp2& a, const Fp& k) { Fp2 r; r.h = fp_mul(a.h, k); return r; }
-ZKV_HD Fp2 f2_mul_xi(const Fp2& a) {          // (9+u)(a0 + a1 u) = (9a0 - a1) + (9a1 + a0) u
-    Fp o = zkv_partner(a.h);
-    Fp t = fp_add(fp_dbl(fp_dbl(fp_dbl(a.h))), a.h);
-    Fp2 r; r.h = fp_add(t, fp_sel(zkv_parity() != 0, o, fp_neg(o)));
-    return r;
+// (9+u)(a0 + a1 u) = (9a0 - a1) + (9a1 + a0) u: each lane needs 9 * mine -/+ partner's.  Measured (zkv_diag_mulmod_rate kind 4) the
+// round-1 form -- three modular doublings, an addition, a negation, a select and another addition, every one a carry chain with
+// its conditional subtraction -- cost 0.69 of an fp_mul, 17-31 % of the time of an Fp12 routine.  Now: the odd lane hands its
+// partner 2p - a1 (so that both lanes ADD), T = (mine << 3) + mine + partner's is formed once on nine limbs (T < 20p), a quotient
+// estimate from the top 14 bits (one v_mul_hi) takes T below 1.0034 * 2p (checked at every multiple of 2p +- 3 and on random values),
+// and a single conditional subtraction restores the loose range [0, 2p).
+ZKV_HD Fp2 f2_mul_xi(const Fp2& a) {
+    const uint32_t P2[8] = ZKV_FP_2P_LIMBS;
+    const bool odd = zkv_parity() != 0;
+    Fp n; uint32_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) n.v[i] = subb(P2[i], a.h.v[i], br);            // 2p - mine, in (0, 2p]
+    const Fp o = zkv_partner(fp_sel(odd, n, a.h));
+    uint32_t t[9], c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = addc(a.h.v[i], o.v[i], c);                // mine + partner's, nine limbs
+    t[8] = c;
+    uint32_t sh[9];
+    sh[0] = a.h.v[0] << 3;
+#pragma unroll
+    for (int i = 1; i < 8; i++) sh[i] = (a.h.v[i] << 3) | (a.h.v[i - 1] >> 29);
+    sh[8] = a.h.v[7] >> 29;
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = addc(t[i], sh[i], c);                     // T = 9 mine + partner's < 20p < 2^259
+    const uint32_t x = (t[8] << 12) | (t[7] >> 20);                              // floor(T / 2^244)
+    const uint32_t q = (uint32_t)(((uint64_t)x * 0x2a4effu) >> 32);              // floor(T / 2p) or one less: 0x2a4eff = floor(2^32 / ceil(2p / 2^244))
+    uint64_t carry = 0;
+    Fp r, s2; br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { carry += (uint64_t)q * P2[i]; r.v[i] = subb(t[i], (uint32_t)carry, br); carry >>= 32; }       // T - q 2p < 4p: eight limbs
+    br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s2.v[i] = subb(r.v[i], P2[i], br);
+    Fp2 out;
+#pragma unroll
+    for (int i = 0; i < 8; i++) out.h.v[i] = br ? r.v[i] : s2.v[i];
+    return out;
 }
 ZKV_HD Fp2 f2_inv(const Fp2& a) {
     Fp sq = fp_sqr(a.h);
