@@ -162,9 +162,9 @@ int zkv_mixed_verify_batch_dev(zkv_ctx* ctx, size_t n, const uint8_t* d_vm, cons
  * those of the Groth16 `verify_proof`: INVALID_PROOF_DATA (length < 4), SELECTOR_MISMATCH, INVALID_PROOF_DATA (length != 868),
  * VERIFICATION_FAILED (program_vkey >= R, a scalar >= R, a point off the curve, the algebraic relation or the pairing failing), OK.
  * The verifying key is supplied by the caller (no SP1 PLONK key exists in the reference): 32-byte big-endian words
- *   size | size_inv | generator | coset_shift | nb_public (= 2) | n_qcp (0 or 1) | commitment_constraint_index |
- *   S1 S2 S3 Ql Qr Qm Qo Qk [Qcp] (G1 x, y) | G2 generator | [tau]G2 (EIP-197 order x_im x_re y_im y_re)
- * A key holding an invalid point fails every proof. */
+ *   size | size_inv | generator | coset_shift | nb_public (= 2) | n_qcp (= 1: SP1's circuit has one BSB22 commitment) | commitment_constraint_index |
+ *   S1 S2 S3 Ql Qr Qm Qo Qk Qcp (G1 x, y) | G2 generator | [tau]G2 (EIP-197 order x_im x_re y_im y_re)
+ * (1,056 bytes; any other shape returns NULL).  A key holding an invalid point fails every proof. */
 #define ZKV_VM_SP1_PLONK 6
 #define ZKV_PLONK_PROOF_BYTES 868
 zkv_ctx* zkv_sp1_plonk_ctx_create(const uint8_t* vk_bytes, size_t vk_len, const uint8_t verifier_hash[32], int device);

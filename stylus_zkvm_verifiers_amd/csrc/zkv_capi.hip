@@ -345,7 +345,8 @@ static int run_host_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const uint6
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_ready(c, n);
     if (rc != ZKV_OK) return rc;
-    const size_t cap = c->ws.cap, pass_max = (size_t)1 << 22;
+    const char* pe = getenv("ZKV_HOST_PASS");                   // proofs staged per pass (tests shrink it to reach the multi-pass loop)
+    const size_t cap = c->ws.cap, pass_max = pe && strtoull(pe, nullptr, 10) ? (size_t)strtoull(pe, nullptr, 10) : (size_t)1 << 22;
     const bool sp1 = c->vm == ZKV_VM_SP1 || c->vm == ZKV_VM_SP1_PLONK;
     if ((rc = order_after_previous(c, c->stream)) != ZKV_OK) return rc;
     std::vector<uint64_t> rel, prel;
@@ -791,7 +792,8 @@ ZKV_EXPORT zkv_ctx* zkv_sp1_plonk_ctx_create(const uint8_t* vk, size_t vk_len, c
     uint32_t w[7][8];
     for (int k = 0; k < 7; k++) host::be_to_limbs(w[k], vk + 32 * k);
     auto small = [](const uint32_t* x) { for (int i = 1; i < 8; i++) if (x[i]) return false; return true; };
-    if (!small(w[4]) || !small(w[5]) || !small(w[6]) || w[5][0] > 1) return nullptr;
+    // SP1's circuit: two public inputs and exactly one BSB22 commitment (the 27-word proof layout); other shapes are not supported
+    if (!small(w[4]) || !small(w[5]) || !small(w[6]) || w[5][0] != 1 || w[4][0] != 2) return nullptr;
     const size_t n_c = w[5][0];
     if (vk_len != 7 * 32 + (8 + n_c) * 64 + 256) return nullptr;
     zkv_ctx* c = new (std::nothrow) zkv_ctx();

@@ -73,6 +73,31 @@ def scatter_rows(full, n_total, row_bytes, device, src=0):
     return mine
 
 
+def scatter_rows_multi(fulls, n_total, widths, device, src=0):
+    """scatter_rows for several row arrays at once: all sends (root) / receives (peers) are posted as ONE batch
+    (`dist.batch_isend_irecv` = one ncclGroupStart/End on RCCL), so the root drives its seven xGMI links concurrently instead of
+    peer after peer.  fulls: list of uint8 [n_total, w] tensors on the root (ignored elsewhere).  Returns this rank's shards."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = shard_bounds(n_total, world, rank)
+    mine = [torch.empty((hi - lo, w), dtype=torch.uint8, device=device) for w in widths]
+    ops = []
+    if rank == src:
+        for peer in range(world):
+            plo, phi = shard_bounds(n_total, world, peer)
+            for k, w in enumerate(widths):
+                if peer == src:
+                    mine[k].copy_(fulls[k][plo:phi])
+                elif phi > plo:
+                    ops.append(dist.P2POp(dist.isend, fulls[k][plo:phi].contiguous(), peer))
+    elif hi > lo:
+        for k in range(len(widths)):
+            ops.append(dist.P2POp(dist.irecv, mine[k], src))
+    if ops:
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+    return mine
+
+
 def gather_status(local_status, n_total, device, dst=0):
     """Collect one status byte per proof on rank `dst` (returns the full uint8 [n_total] there, None elsewhere)."""
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -165,11 +190,9 @@ def mixed_step(params, root, n_total, verify_fn, dev, cdev, sync=lambda: None):
         if rank == 0:
             w[0] = root[3].shape[1]
         dist.broadcast(w, src=0)
-        shard = []
-        for k, wid in enumerate(widths):
-            wid = int(w.item()) if wid is None else wid
-            full = root[k].reshape(n_total, wid) if rank == 0 else None
-            shard.append(scatter_rows(full, n_total, wid, cdev))
+        wids = [int(w.item()) if x is None else x for x in widths]
+        fulls = [root[k].reshape(n_total, wids[k]) for k in range(4)] if rank == 0 else None
+        shard = scatter_rows_multi(fulls, n_total, wids, cdev)
     else:
         shard = [root[0].reshape(n_total, 1), root[1], root[2], root[3]]
     local = [t if t.device == dev else t.to(dev) for t in shard]

@@ -702,6 +702,40 @@ def test_small_chunks_give_the_same_answers(zkv, r0, sp1, real_proofs):
     pc2.close()
 
 
+def test_host_batches_in_several_passes_and_segments(zkv, r0, sp1, real_proofs, verify_corpus):
+    """The host-buffer driver stages a batch pass by pass (ZKV_HOST_PASS proofs) and, inside a pass, segment by segment on the copy
+    stream (a short first segment, then workspace-sized ones).  With a 150-proof pass, a 40-proof first segment and a 64-proof
+    workspace a 700-proof RAGGED batch (corpus seals of every length spliced in, so passes start at non-zero blob offsets) must
+    return exactly what the default contexts return; same for SP1 with ragged public values."""
+    from stylus_zkvm_verifiers_amd import synth
+    r, s = real_proofs['risc0'], real_proofs['sp1']
+    n = 700
+    seals, mut, _, flip = synth.make_batch('risc0', H(r['seal']), n, 0x5A4B56B1, pool=4, mutate_every=7)
+    ids = [H(r['image_id'])] * n
+    jds = [H(r['journal_digest'])[:-1] + bytes([H(r['journal_digest'])[-1] ^ (1 if f else 0)]) for f in flip]
+    ragged = [H(c['seal']) for c in verify_corpus['cases'] if c['vm'] == 'risc0']
+    sl = [x.tobytes() for x in seals]
+    for k, x in enumerate(ragged):
+        sl[(37 * k + 5) % n] = x                                  # lengths 0 .. 292 sprinkled through the batch
+    proofs, smut, _, sflip = synth.make_batch('sp1', H(s['proof']), n, 0x5A4B56B2, pool=4, mutate_every=7)
+    pvs = [H(s['public_values'])[:(96 if i % 3 else 40 + i % 50)] for i in range(n)]             # ragged public values (most proofs then fail)
+    want, want_rv = r0.verify_batch(sl, ids, jds)
+    swant, swant_rv = sp1.verify_batch([H(s['vkey'])] * n, pvs, [x.tobytes() for x in proofs])
+    os.environ.update(ZKV_HOST_PASS='150', ZKV_HOST_FIRST_SEGMENT='40', ZKV_CHUNK='64')
+    try:
+        r0s = zkv.RiscZeroVerifier(); r0s.initialize(H(r['control_root']), H(r['bn254_control_id']))
+        sp1s = zkv.Sp1Verifier()
+        got, got_rv = r0s.verify_batch(sl, ids, jds)
+        assert (got == want).all() and (got_rv == want_rv).all()
+        sgot, sgot_rv = sp1s.verify_batch([H(s['vkey'])] * n, pvs, [x.tobytes() for x in proofs])
+        assert (sgot == swant).all() and (sgot_rv == swant_rv).all()
+        r0s.close(); sp1s.close()
+    finally:
+        for k in ('ZKV_HOST_PASS', 'ZKV_HOST_FIRST_SEGMENT', 'ZKV_CHUNK'):
+            os.environ.pop(k, None)
+    assert (want == 0).sum() > 500 and (swant == 0).sum() > 300 and len(set(want)) >= 3
+
+
 def test_device_calldata_with_corrupt_offsets_is_never_read(zkv, r0, real_proofs):
     """zkv_eth_call_batch_dev takes its offsets from device memory: requests whose offsets run backwards or leave the blob get
     BAD_CALLDATA without being dereferenced; their neighbours are unaffected."""
