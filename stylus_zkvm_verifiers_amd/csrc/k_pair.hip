@@ -58,6 +58,72 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_finalexp2(size_t n, Workspace 
     if (!par) status[i] = one ? ST_OK : ST_VERIFICATION_FAILED;
 }
 
+// The ecPairing precompile as a batch (the inner seam of the reference: common/groth16.rs:109-128 builds k x 192 bytes of
+// calldata and STATICCALLs 0x08): one CALL per lane pair, k pairs per call, EIP-197 semantics -- every point of every pair is
+// validated (coordinates < Q, G1 on the curve or (0,0), G2 on the twist and in the order-r subgroup or all-zero) whether or not
+// the pair is skipped; a pair with a point at infinity contributes 1; result = 1 iff the product of the pairings is 1.
+// Same building blocks as the verify path: the flat Miller loop with a single variable pair (no tables), the product kept in
+// the call's F slot, the interpreted final exponentiation.  The call's workspace rows (ws.norm, ws.prep) carry x/y, 1/y of the
+// current G1 point and the current G2 point, which the loop re-reads where it needs them.
+ZKV_HD bool pair_all(bool mine) {          // AND over the two lanes of a pair
+    uint32_t v = mine ? 0u : 1u;
+    v |= zkv_partner_u32(v);
+    return v == 0;
+}
+__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing2(size_t n, uint32_t k, const uint8_t* __restrict__ in, Workspace ws,
+                                                           uint8_t* __restrict__ result, uint8_t* __restrict__ ok) {
+    __shared__ uint32_t lds[(48 + 24) * ZKV_BLOCK];
+    size_t i = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
+    if (i >= n) return;
+    const uint32_t par = threadIdx.x & 1u;
+    const uint8_t* base = in + (size_t)192 * k * i;
+    LRef fm = l_ref(lds + threadIdx.x);
+    LRef tm = l_ref(lds + 48 * ZKV_BLOCK + threadIdx.x);
+    const uint32_t st = (uint32_t)ws.cap;
+    MRef P = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, st, 16);
+    MRef E = m_ref(ws.fe + (size_t)(8 * par) * ws.cap + i, st, 16);
+    SoaRef norm = {ws.norm + i, ws.cap};
+    SoaRef bsrc = {ws.prep + (size_t)(32 + 8 * par) * ws.cap + i, ws.cap};
+    f12m_set_one(P);
+    bool good = true;
+#pragma unroll 1
+    for (uint32_t j = 0; j < k; j++) {
+        const uint8_t* p = base + 192 * j;
+        uint32_t gx[8], gy[8], qxw[8], qyw[8];
+        load_be256(gx, p); load_be256(gy, p + 32);
+        load_be256(qxw, p + 64 + 32 * (1 - par));               // wire order (imaginary, real): the even lane takes the real parts
+        load_be256(qyw, p + 128 + 32 * (1 - par));
+        bool okj = raw_lt_p(gx) && raw_lt_p(gy);
+        okj = pair_all(okj && raw_lt_p(qxw) && raw_lt_p(qyw));
+        const bool pinf = raw_is_zero(gx) && raw_is_zero(gy);
+        const bool qinf = pair_all(raw_is_zero(qxw) && raw_is_zero(qyw));
+        Fp px = fp_zero(), py = fp_zero();
+        if (okj && !pinf) { px = fp_from_raw(gx); py = fp_from_raw(gy); okj = g1_on_curve(px, py); }
+        if (okj && !qinf) {
+            Fp2 qx, qy; qx.h = fp_from_raw(qxw); qy.h = fp_from_raw(qyw);
+            okj = g2_on_twist(qx, qy) && g2_in_subgroup(qx, qy);
+            if (okj && !pinf) {
+                const Fp iy = fp_inv(py);
+                ws_st(ws.norm, ws.cap, 0, i, fp_mul(px, iy)); ws_st(ws.norm, ws.cap, 8, i, iy);            // both lanes store the same words
+                ws_st(ws.prep, ws.cap, 32 + 8 * (int)par, i, qx.h); ws_st(ws.prep, ws.cap, 48 + 8 * (int)par, i, qy.h);
+                miller_loop_p((const VkTables*)nullptr, 0u, norm, bsrc, fm, tm);
+                f12m_mul_body(P, P, fm, false);
+            }
+        }
+        if (!okj) { good = false; break; }
+    }
+    uint8_t res = 0;
+    if (good) {
+        MRef accm = m_ref(lds + threadIdx.x, 64, 8);
+        res = final_exp_prog_p(P, E, fm, accm) ? 1 : 0;
+    }
+    if (!par) { result[i] = res; ok[i] = good ? 1 : 0; }
+}
+void launch_pairing(size_t n, uint32_t k, const uint8_t* in, const Workspace& ws, uint8_t* result, uint8_t* ok, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_pairing2, dim3((unsigned)((2 * n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, k, in, ws, result, ok);
+}
+
 static inline unsigned pair_grid(size_t n) { return (unsigned)((2 * n + ZKV_BLOCK - 1) / ZKV_BLOCK); }
 
 void launch_g2chk2(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s) {

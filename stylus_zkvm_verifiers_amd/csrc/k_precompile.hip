@@ -58,48 +58,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_ecmul(size_t n, const uint8_t* __
     ok[i] = good ? 1 : 0;
 }
 
-// k pairs per call; the Miller value of each non-degenerate pair is formed in LDS and multiplied into the product slot.
-__global__ __launch_bounds__(ZKV_BLOCK) void k_pairing(size_t n, uint32_t k, const uint8_t* __restrict__ in, Workspace ws,
-                                                        uint8_t* __restrict__ result, uint8_t* __restrict__ ok) {
-    __shared__ uint32_t lds[(96 + 48) * ZKV_BLOCK];
-    size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const uint8_t* base = in + (size_t)192 * k * i;
-    LRef fm = l_ref(lds + threadIdx.x);
-    LRef tm = l_ref(lds + 96 * ZKV_BLOCK + threadIdx.x);
-    const uint32_t st = (uint32_t)ws.cap;
-    MRef P = m_ref(ws.f + i, st), E = m_ref(ws.fe + i, st);
-    f12m_set_one(P);
-    bool good = true;
-#pragma unroll 1
-    for (uint32_t j = 0; j < k && good; j++) {               // validate every pair first (EIP-197), then pair
-        const uint8_t* p = base + 192 * j;
-        Fp px, py; bool pinf;
-        good = rd_g1(p, px, py, pinf);
-        uint32_t w[4][8];
-        bool win = true;
-#pragma unroll 1
-        for (int c = 0; c < 4; c++) { load_be256(w[c], p + 64 + 32 * c); win = win && raw_lt_p(w[c]); }
-        good = good && win;
-        if (!good) break;
-        bool qinf = raw_is_zero(w[0]) && raw_is_zero(w[1]) && raw_is_zero(w[2]) && raw_is_zero(w[3]);
-        if (qinf) continue;
-        Fp2 qx, qy;
-        qx.c1 = fp_from_raw(w[0]); qx.c0 = fp_from_raw(w[1]); qy.c1 = fp_from_raw(w[2]); qy.c0 = fp_from_raw(w[3]);
-        good = g2_on_twist(qx, qy) && g2_in_subgroup(qx, qy);
-        if (!good || pinf) continue;
-        G1Norm nm;
-        Fp iy = fp_inv(py);
-        nm.axs = fp_mul(px, iy); nm.ays = iy;
-        nm.lxs = nm.lys = nm.cxs = nm.cys = fp_zero();
-        miller_loop_m((const VkTables*)nullptr, 0u, nm, qx, qy, fm, tm);             // one variable pair, no fixed pairs
-        f12m_mul(P, P, fm);
-    }
-    uint8_t res = 0;
-    if (good) res = final_exp_is_one_m(P, E, m_off(E, 96), m_off(E, 192), m_off(E, 288), m_off(E, 384), fm) ? 1 : 0;
-    result[i] = res;
-    ok[i] = good ? 1 : 0;
-}
+// ecPairing: k_pairing2 in k_pair.hip (lane-pair kernels, shared with the verify path).
 
 void launch_ecadd(size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok, hipStream_t s) {
     if (!n) return;
@@ -108,10 +67,6 @@ void launch_ecadd(size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok, hipStr
 void launch_ecmul(size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_ecmul, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, in, out, ok);
-}
-void launch_pairing(size_t n, uint32_t k, const uint8_t* in, const Workspace& ws, uint8_t* result, uint8_t* ok, hipStream_t s) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_pairing, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, k, in, ws, result, ok);
 }
 
 }  // namespace zkv
