@@ -1,3 +1,5 @@
+"""Quick device check of the kernel mappings (lane pairs / 16 lanes per proof / automatic) at a few batch sizes and of the PLONK path:
+prints the statuses (0 = verified) and stage times.  `python tools/check_mappings.py` on a GPU box."""
 import json, sys
 sys.path.insert(0, '.')
 import stylus_zkvm_verifiers_amd as z
