@@ -224,3 +224,54 @@ def test_plonk_2p18_batch_through_properties(zkv, pool):
     assert ((st == 0) == ~mut).all()
     assert (run() == st).all()
     v.close()
+
+
+@pytest.mark.gpu
+def test_plonk_differential_fuzz_against_the_oracle(zkv, pool):
+    """Seeded structural fuzz of pool proofs -- a word replaced by a random field element / a random 256-bit value / zero, a point
+    replaced by a random curve point or by another proof's point, two words swapped, the proof truncated or extended, public values of
+    random length, a random program vkey -- 400 cases in one ragged batch: every status equals the C oracle's."""
+    import random
+    rng = random.Random(0x5A4B56C3)
+    vk, vh = H(pool['vk']), H(pool['verifier_hash'])
+    G = (1, 2)
+    def rand_point():
+        k = rng.randrange(1, m.R)
+        pt = m.g1_mul(G, k)
+        return m.be32(pt[0]) + m.be32(pt[1])
+    POINT_WORDS = [0, 2, 4, 6, 8, 10, 17, 20, 22, 25]
+    vkeys, pvs, proofs = [], [], []
+    for i in range(400):
+        p = pool['proofs'][rng.randrange(len(pool['proofs']))]
+        vkey, pv, proof = H(p['vkey']), H(p['public_values']), bytearray(H(p['proof']))
+        kind = rng.randrange(10)
+        w = rng.randrange(27)
+        if kind == 0:
+            proof[4 + 32 * w:36 + 32 * w] = m.be32(rng.randrange(m.R))
+        elif kind == 1:
+            proof[4 + 32 * w:36 + 32 * w] = m.be32(rng.randrange(1 << 256))
+        elif kind == 2:
+            proof[4 + 32 * w:36 + 32 * w] = bytes(32)
+        elif kind == 3:
+            q = rng.choice(POINT_WORDS); proof[4 + 32 * q:68 + 32 * q] = rand_point()
+        elif kind == 4:
+            other = H(pool['proofs'][rng.randrange(len(pool['proofs']))]['proof'])
+            q = rng.choice(POINT_WORDS); proof[4 + 32 * q:68 + 32 * q] = other[4 + 32 * q:68 + 32 * q]
+        elif kind == 5:
+            a, b = rng.randrange(27), rng.randrange(27)
+            wa, wb = bytes(proof[4 + 32 * a:36 + 32 * a]), bytes(proof[4 + 32 * b:36 + 32 * b])
+            proof[4 + 32 * a:36 + 32 * a], proof[4 + 32 * b:36 + 32 * b] = wb, wa
+        elif kind == 6:
+            proof = proof[:rng.randrange(0, 900)] if rng.random() < 0.7 else proof + bytes(rng.randrange(1, 40))
+        elif kind == 7:
+            pv = bytes(rng.randrange(256) for _ in range(rng.randrange(0, 150)))
+        elif kind == 8:
+            vkey = m.be32(rng.randrange(1 << 256))
+        # kind 9: untouched (valid)
+        vkeys.append(vkey); pvs.append(pv); proofs.append(bytes(proof))
+    v = zkv.Sp1PlonkVerifier(vk, vh)
+    st, rv = v.verify_batch(vkeys, pvs, proofs)
+    ost, orv = ol.sp1_plonk_verify_batch(vk, vh, vkeys, pvs, proofs, threads=8)
+    assert (st == ost).all() and (rv.reshape(-1) == orv).all()
+    assert (st == 0).sum() >= 25 and len(set(st.tolist())) >= 3
+    v.close()
