@@ -457,41 +457,6 @@ Fp f2_mul_lane(Fp my_a, Fp my_b) {
     return fp_reduce_cols(col);
 }
 ZKV_HD Fp2 f2_mul(const Fp2& a, const Fp2& b) { Fp2 r; r.h = f2_mul_lane(a.h, b.h); return r; }
-// a b + c d with ONE Montgomery reduction per lane: four 81-term column products (even lane a0 b0 + a1 (8p - b1) + c0 d0 + c1 (8p - d1),
-// odd lane a0 b1 + a1 b0 + c0 d1 + c1 d0).  All four operands must be reduced values (< 2p: limbs < 2^29 after unpacking; no lazy
-// sums here): a column then holds at most 18 products below 2^58, 18 below 2^59 (the 8p - x limbs are below 2^30) and the 9
-// reduction terms below 2^58 -- 63 * 2^58 < 2^64 -- and the value stays below 40 p^2 < 169 p^2.  Used where two products are only
-// ever added (the sparse line products of the Miller loop): 405 multiplies and one unpack / pack set instead of 486 and two.
-#if defined(ZKV_FP_MUL_NOINLINE)
-ZKV_HD_NI
-#else
-ZKV_HD
-#endif
-Fp f2_dot2_lane(Fp my_a, Fp my_b, Fp my_c, Fp my_d) {
-#if defined(ZKV_COUNT_FP_MUL)
-    zkv_fp_mul_counter += 4;
-#endif
-    const uint32_t FAT[9] = ZKV_FP_FAT8P_LIMBS;
-    const bool odd = zkv_parity() != 0;
-    uint64_t col[18];
-#pragma unroll
-    for (int k = 0; k < 18; k++) col[k] = 0;
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        uint32_t xa[9], xo[9], yb[9], yo[9], U[9], V[9];
-        fp_unpack29(t ? my_c : my_a, xa); fp_unpack29(t ? my_d : my_b, yb);
-#pragma unroll
-        for (int i = 0; i < 9; i++) { xo[i] = zkv_partner_u32(xa[i]); yo[i] = zkv_partner_u32(yb[i]); }
-#pragma unroll
-        for (int i = 0; i < 9; i++) {
-            U[i] = odd ? yo[i] : yb[i];
-            V[i] = odd ? yb[i] : FAT[i] - yo[i];
-        }
-        fp_mac81(col, xa, U); fp_mac81(col, xo, V);
-    }
-    return fp_reduce_cols(col);
-}
-ZKV_HD Fp2 f2_dot2(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) { Fp2 r; r.h = f2_dot2_lane(a.h, b.h, c.h, d.h); return r; }
 ZKV_HD Fp2 f2_sqr(const Fp2& a) {           // reduced (< 2p) input: even lane (a0+a1)(a0-a1), odd lane (2 a1) a0
     const bool odd = zkv_parity() != 0;
     Fp o = zkv_partner(a.h);

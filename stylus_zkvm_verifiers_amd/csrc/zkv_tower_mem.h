@@ -143,25 +143,6 @@ template <class RF> ZKV_HD void f12m_mul_by_034_body(RF f, const Fp2& c0, const 
 }
 template <class RF> ZKV_HD_NI void f12m_mul_by_034(RF f, const Fp2* c0, const Fp2* c3, const Fp2* c4) { f12m_mul_by_034_body(f, *c0, *c3, *c4); }
 // f <- f * (1 + (c3 + c4 v) w)
-#if defined(ZKV_PAIRED)
-// With l = c3 + c4 v:  g' = g + v (h l),  h' = h + g l.  Written out per coefficient every output is its input plus a sum of TWO
-// products -- g'0 = g0 + h1 (xi c4) + h2 (xi c3), g'1 = g1 + h0 c3 + h2 (xi c4), g'2 = g2 + h0 c4 + h1 c3, and the same for h' with
-// g in place of h and no wrap for h'0: h'0 = h0 + g0 c3 + g2 (xi c4) -- so the six outputs are six fused two-product sums (f2_dot2: one
-// reduction each) instead of ten products with Karatsuba's additions: the same 2,430 multiplies per lane, but 6 instead of 10
-// unpack / exchange / pack sets and 8 instead of 24 modular additions and xi-multiplications.
-template <class RF> ZKV_HD void f12m_mul_by_134_body(RF f, const Fp2& c3, const Fp2& c4) {
-    const Fp2 x3 = f2_mul_xi(c3), x4 = f2_mul_xi(c4);
-    const Fp2 g0 = m_ld_f2(f, 0), g1 = m_ld_f2(f, 1), g2 = m_ld_f2(f, 2), h0 = m_ld_f2(f, 3), h1 = m_ld_f2(f, 4), h2 = m_ld_f2(f, 5);
-    const Fp2 ng0 = f2_add(g0, f2_dot2(h1, x4, h2, x3));
-    const Fp2 ng1 = f2_add(g1, f2_dot2(h0, c3, h2, x4));
-    const Fp2 ng2 = f2_add(g2, f2_dot2(h0, c4, h1, c3));
-    const Fp2 nh0 = f2_add(h0, f2_dot2(g0, c3, g2, x4));
-    const Fp2 nh1 = f2_add(h1, f2_dot2(g0, c4, g1, c3));
-    const Fp2 nh2 = f2_add(h2, f2_dot2(g1, c4, g2, c3));
-    m_st_f2(f, 0, ng0); m_st_f2(f, 1, ng1); m_st_f2(f, 2, ng2); m_st_f2(f, 3, nh0); m_st_f2(f, 4, nh1); m_st_f2(f, 5, nh2);
-}
-#else
-// one proof per lane (set-up kernels, host reference, op count of the canonical algorithm): two Karatsuba products by c3 + c4 v
 template <class RF> ZKV_HD void f12m_mul_by_134_body(RF f, const Fp2& c3, const Fp2& c4) {
     Fp6 g = m_ld_f6(f, 0), h = m_ld_f6(f, 3);
     Fp6 hs = f6_mul_by_01(h, c3, c4);
@@ -169,7 +150,6 @@ template <class RF> ZKV_HD void f12m_mul_by_134_body(RF f, const Fp2& c3, const 
     m_st_f6(f, 0, f6_add(g, f6_mul_v(hs)));
     m_st_f6(f, 3, f6_add(h, gs));
 }
-#endif
 template <class RF> ZKV_HD_NI void f12m_mul_by_134(RF f, const Fp2* c3, const Fp2* c4) { f12m_mul_by_134_body(f, *c3, *c4); }
 // d <- a^-1
 template <class RD, class RA> ZKV_HD void f12m_inv_body(RD d, RA a) {
