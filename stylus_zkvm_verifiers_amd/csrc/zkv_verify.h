@@ -268,22 +268,6 @@ ZKV_HD void miller_loop_m(const VkTables* vkp, uint32_t flags, const G1Norm& n, 
 // for -- the routines need no frame; only fp_mul / f2_mul_lane stay calls (leaf functions inside the caller-saved registers).
 // Per-proof constants (x/y and 1/y of the three G1 points, B) are re-read from their workspace rows where they are used instead of
 // being held in registers across the whole loop.
-// A table entry that is the same for every lane of the wavefront, copied through the CONSTANT address space: a uniform address
-// in that space is read with scalar loads (s_load into SGPRs) instead of vector loads of one broadcast address.  The tables are
-// written by the set-up kernels of an earlier launch and never by the kernel that reads them.
-template <class T> ZKV_HD T zkv_uniform_load(const T* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef const __attribute__((address_space(4))) uint32_t cword;
-    cword* q = (cword*)(uintptr_t)p;
-    T r;
-    uint32_t* w = (uint32_t*)&r;
-#pragma unroll
-    for (unsigned k = 0; k < sizeof(T) / 4; k++) w[k] = q[k];
-    return r;
-#else
-    return *p;
-#endif
-}
 struct SoaRef {                         // word k of this proof's (this lane's) value at p[k * stride]
     const uint32_t* p; size_t stride;
     ZKV_HD Fp fp(int word0) const {
@@ -325,8 +309,8 @@ ZKV_HD void miller_loop_p(const VkTables* vkp, uint32_t flags, SoaRef norm, SoaR
         for (int j = 0; j < 2; j++) {
             if (j == 0 ? !do_l : !do_c) continue;
             // the step's line is the same for every lane: 8 vector loads of one broadcast address.  Reading it through the constant
-            // address space instead (zkv_uniform_load: two s_load_dwordx16 into SGPRs) was measured and is slower -- 125.3 against
-            // 123.8 ms per 2^20 proofs: 32 more live SGPRs and a scalar wait in front of every line product.
+            // address space instead (two s_load_dwordx16 into SGPRs; commit 'Line tables: scalar-load variant built and measured') was
+            // slower -- 125.3 against 123.8 ms per 2^20 proofs: 32 more live SGPRs and a scalar wait in front of every line product.
             const LineAffC& L = vkp->lines[j][li];
             const Fp2 c3 = f2_mul_fp(f2_const(L.nl), norm.fp(16 + 16 * j)), c4 = f2_mul_fp(f2_const(L.c), norm.fp(24 + 16 * j));
             f12m_mul_by_134_body(fm, c3, c4);
