@@ -25,18 +25,23 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_g2chk2(size_t n, Workspace ws,
     if (!ok && !(threadIdx.x & 1u)) { ws.g2bad[i] = 1; status[i] = ST_VERIFICATION_FAILED; }
 }
 
-__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller2(size_t n, const VkTables* __restrict__ vk, Workspace ws) {
+// The Miller loop is also the subgroup test of B (miller_loop_p, check_b): a proof whose B is outside G2 gets the precompile-failure
+// status here and is skipped by k_finalexp2.  (k_g2chk2 remains for the 16-lane kernels of small chunks.)
+__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller2(size_t n, const VkTables* __restrict__ vk, Workspace ws, uint8_t* __restrict__ status) {
     __shared__ uint32_t lds[(48 + 24) * ZKV_BLOCK];       // f: 6 Fp per lane, T: 3 Fp per lane, lane-interleaved
     size_t i = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
     if (i >= n) return;
     uint32_t flags = ws.flags[i];
-    if (!(flags & FL_ALIVE)) return;        // the subgroup check of B may still be running: its verdict is read by k_finalexp2
+    if (!(flags & FL_ALIVE)) return;
     const uint32_t par = threadIdx.x & 1u;
     LRef fm = l_ref(lds + threadIdx.x);
     LRef tm = l_ref(lds + 48 * ZKV_BLOCK + threadIdx.x);
     SoaRef norm = {ws.norm + i, ws.cap};                                        // Fp values: both lanes of the pair read them
     SoaRef bsrc = {ws.prep + (size_t)(32 + 8 * par) * ws.cap + i, ws.cap};      // this lane's component of B.x (B.y 16 words on)
-    miller_loop_p(vk, flags, norm, bsrc, fm, tm);
+    if (!miller_loop_p(vk, flags, norm, bsrc, fm, tm, true)) {
+        if (!par) { ws.g2bad[i] = 1; status[i] = ST_VERIFICATION_FAILED; }
+        return;
+    }
     MRef ab = m_ref((uint32_t*)(vk->f_alpha_beta) + 8 * par, 1, 16);
     MRef out = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, (uint32_t)ws.cap, 16);
     f12m_mul_body(out, fm, ab, false);
@@ -101,13 +106,14 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing2(size_t n, uint32_t k,
         if (okj && !pinf) { px = fp_from_raw(gx); py = fp_from_raw(gy); okj = g1_on_curve(px, py); }
         if (okj && !qinf) {
             Fp2 qx, qy; qx.h = fp_from_raw(qxw); qy.h = fp_from_raw(qyw);
-            okj = g2_on_twist(qx, qy) && g2_in_subgroup(qx, qy);
-            if (okj && !pinf) {
-                const Fp iy = fp_inv(py);
+            okj = g2_on_twist(qx, qy);
+            if (okj) {
+                // the Miller loop is the subgroup test of Q as well; for P = infinity only the point is stepped (no line products)
+                const Fp iy = pinf ? fp_zero() : fp_inv(py);
                 ws_st(ws.norm, ws.cap, 0, i, fp_mul(px, iy)); ws_st(ws.norm, ws.cap, 8, i, iy);            // both lanes store the same words
                 ws_st(ws.prep, ws.cap, 32 + 8 * (int)par, i, qx.h); ws_st(ws.prep, ws.cap, 48 + 8 * (int)par, i, qy.h);
-                miller_loop_p((const VkTables*)nullptr, 0u, norm, bsrc, fm, tm);
-                f12m_mul_body(P, P, fm, false);
+                okj = miller_loop_p((const VkTables*)nullptr, pinf ? (uint32_t)FL_A_INF : 0u, norm, bsrc, fm, tm, true);
+                if (okj && !pinf) f12m_mul_body(P, P, fm, false);
             }
         }
         if (!okj) { good = false; break; }
@@ -130,9 +136,9 @@ void launch_g2chk2(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s
     if (!n) return;
     hipLaunchKernelGGL(k_g2chk2, dim3(pair_grid(n)), dim3(ZKV_BLOCK), 0, s, n, ws, status);
 }
-void launch_miller2(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s) {
+void launch_miller2(size_t n, const VkTables* d_tab, const Workspace& ws, uint8_t* status, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_miller2, dim3(pair_grid(n)), dim3(ZKV_BLOCK), 0, s, n, d_tab, ws);
+    hipLaunchKernelGGL(k_miller2, dim3(pair_grid(n)), dim3(ZKV_BLOCK), 0, s, n, d_tab, ws, status);
 }
 void launch_finalexp2(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s) {
     if (!n) return;

@@ -272,7 +272,7 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
         if (timed) { (void)hipEventRecord(c->ev[1], s); (void)hipEventRecord(c->ev[2], s); (void)hipEventRecord(c->ev[3], s); }
         const int pl = c->lanes ? c->lanes : 2;
         const bool wide_p = pl == 16 || (c->lanes == 0 && a.n <= wide_below());
-        if (wide_p) launch_miller_w(a.n, c->d_tab, c->ws, s); else launch_miller2(a.n, c->d_tab, c->ws, s);
+        if (wide_p) launch_miller_w(a.n, c->d_tab, c->ws, s); else launch_miller2(a.n, c->d_tab, c->ws, a.status, s);
         if (timed) (void)hipEventRecord(c->ev[4], s);
         if (wide_p) launch_finalexp_w(a.n, c->ws, a.status, s); else launch_finalexp2(a.n, c->ws, a.status, s);
         if (timed) (void)hipEventRecord(c->ev[5], s);
@@ -283,11 +283,12 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     else launch_prep_sp1(a, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[1], s);
     const int lanes = c->lanes ? c->lanes : 2;       // 2 = one proof per lane pair; 16 = one proof per 16 lanes (small chunks)
-    // The subgroup check of B only needs the PREP output and only its verdict (ws.g2bad; the MSM owns ws.flags) is needed, by the
-    // final exponentiation: it runs on a second stream beside the MSM and the Miller loop, which is computed speculatively for
-    // the rare proof whose B fails the check.  Small chunks leave most of the chip idle, so the check disappears (-0.7 ms); at
-    // 2^16 proofs the overlap with the one-wave-per-SIMD MSM is still worth 0.13 ms.  Stage time [2] is then ~0.
-    const bool fork = c->side != nullptr;
+    const bool wide = lanes == 16 || (c->lanes == 0 && a.n <= wide_below());
+    // Lane-pair kernels: the Miller loop itself is the subgroup test of B (miller_loop_p), there is no separate check; stage time
+    // [2] is then 0.  16-lane kernels (small chunks, most of the chip idle): the check (k_g2chk2) only needs the PREP output and only
+    // its verdict (ws.g2bad; the MSM owns ws.flags) is needed, by the final exponentiation, so it runs on a second stream beside the
+    // MSM and the Miller loop, which is computed speculatively for the rare proof whose B fails the check (-0.7 ms).
+    const bool fork = wide && c->side != nullptr;
     if (fork) {
         (void)hipEventRecord(c->ev_fork, s);
         (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
@@ -296,17 +297,12 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     }
     launch_msm(a.n, c->d_tab, a.inst ? c->d_inst : nullptr, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[2], s);
-    // Up to 2^16 proofs (one resident set of Miller wavefronts) the check may also run beside the Miller loop; with more, its
-    // second round of wavefronts displaces Miller wavefronts and the batch gets slower (measured -11 % at 2^17), so join here.
-    const bool late_join = fork && a.n <= ((size_t)1 << 16);
-    if (!fork) launch_g2chk2(a.n, c->ws, a.status, s);
-    else if (!late_join) (void)hipStreamWaitEvent(s, c->ev_join, 0);
+    if (wide && !fork) launch_g2chk2(a.n, c->ws, a.status, s);
     if (timed) (void)hipEventRecord(c->ev[3], s);
-    const bool wide = lanes == 16 || (c->lanes == 0 && a.n <= wide_below());
     if (wide) launch_miller_w(a.n, c->d_tab, c->ws, s);
-    else launch_miller2(a.n, c->d_tab, c->ws, s);
+    else launch_miller2(a.n, c->d_tab, c->ws, a.status, s);
     if (timed) (void)hipEventRecord(c->ev[4], s);
-    if (late_join) (void)hipStreamWaitEvent(s, c->ev_join, 0); // the final exponentiation reads the verdict of the subgroup check
+    if (fork) (void)hipStreamWaitEvent(s, c->ev_join, 0);     // the final exponentiation reads the verdict of the subgroup check
     if (wide) launch_finalexp_w(a.n, c->ws, a.status, s);
     else launch_finalexp2(a.n, c->ws, a.status, s);
     if (timed) (void)hipEventRecord(c->ev[5], s);

@@ -251,18 +251,17 @@ ZKV_HD void fp_to_raw(uint32_t* limbs, const Fp& a) {      // out of Montgomery 
 // a loop, not unrolled.
 ZKV_HD Fp fp_inv(const Fp& a) {
     const uint8_t S[ZKV_FP_INV_SCHED_LEN] = ZKV_FP_INV_SCHED;
-    Fp odd[4];
-    odd[0] = a;
-    const Fp a2 = fp_sqr(a);
-    odd[1] = fp_mul(a2, a); odd[2] = fp_mul(odd[1], a2); odd[3] = fp_mul(odd[2], a2);
-    Fp acc = odd[(S[0] & 7) >> 1];
+    const Fp a3 = fp_mul(fp_sqr(a), a);
+    Fp acc = (S[0] & 7) == 3 ? a3 : a;
 #pragma unroll 1
     for (int i = 1; i < ZKV_FP_INV_SCHED_LEN; i++) {
         const int nsq = S[i] >> 3, v = S[i] & 7;
 #pragma unroll 1
         for (int k = 0; k < nsq; k++) acc = fp_sqr(acc);
         if (v) {
-            const Fp m = v == 1 ? odd[0] : v == 3 ? odd[1] : v == 5 ? odd[2] : odd[3];
+            Fp m;
+#pragma unroll
+            for (int k = 0; k < 8; k++) m.v[k] = v == 3 ? a3.v[k] : a.v[k];
             acc = fp_mul(acc, m);
         }
     }

@@ -81,7 +81,7 @@ void launch_setup_instances(const VkRaw* d_raw, const InstConsts& k, const InstR
 void launch_vk_x(size_t n, const VkTables* d_tab, const InstTab* inst_tab, const uint32_t* inst, const uint8_t* sig, uint8_t* out, hipStream_t s);
 // lane-pair variants (k_pair.hip): one proof per two lanes, two waves per SIMD
 void launch_g2chk2(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
-void launch_miller2(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
+void launch_miller2(size_t n, const VkTables* d_tab, const Workspace& ws, uint8_t* status, hipStream_t s);
 void launch_finalexp2(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
 // coefficient-parallel small-batch variants (k_wide.hip): one proof per 16 lanes
 void launch_miller_w(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);

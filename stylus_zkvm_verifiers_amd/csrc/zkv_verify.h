@@ -209,11 +209,21 @@ template <class RF> ZKV_HD void var_line_mul(RF fm, const Fp2& l0, const Fp2& l1
     f12m_mul_by_034(fm, &l0, &c3, &c4);
 }
 // vkp: the context's tables, or nullptr for a single variable pair without fixed pairs (the ecPairing seam, e(alpha, beta) at set-up).
+// Does psi^3(B) = -T hold for the running point T left by the loop, T != O?  <=> B in the order-r subgroup (see miller_loop_p).
+template <class RT> ZKV_HD bool miller_point_closes(RT tm, const Fp2& bx, const Fp2& by) {
+    const Fp2C G3[6] = ZKV_FROB3;
+    const Fp2 tz = m_ld_f2(tm, 2);
+    const Fp2 x3 = f2_mul(f2_mul(f2_conj(bx), f2_const(G3[2])), tz);       // psi^3(B) scaled to T's Z
+    const Fp2 y3 = f2_mul(f2_mul(f2_conj(by), f2_const(G3[3])), tz);
+    return !f2_is_zero(tz) && f2_eq(m_ld_f2(tm, 0), x3) && f2_is_zero(f2_add(m_ld_f2(tm, 1), y3));
+}
+// check_b: also step the point for A = infinity and return the subgroup verdict for B (miller_loop_p explains why this is one).
 template <class RF, class RT>
-ZKV_HD void miller_loop_m(const VkTables* vkp, uint32_t flags, const G1Norm& n, const Fp2& bx, const Fp2& by, RF fm, RT tm) {
+ZKV_HD bool miller_loop_m(const VkTables* vkp, uint32_t flags, const G1Norm& n, const Fp2& bx, const Fp2& by, RF fm, RT tm, bool check_b = false) {
     const bool with_fixed = vkp != nullptr;
     const VkTables* vkq = with_fixed ? vkp : nullptr;
-    bool do_ab = !(flags & (FL_A_INF | FL_B_INF));
+    const bool do_ab = !(flags & (FL_A_INF | FL_B_INF));
+    const bool do_t = do_ab || (check_b && !(flags & FL_B_INF));
     bool do_l = with_fixed && !(flags & FL_L_INF) && !vkq->skip_fixed[0], do_c = with_fixed && !(flags & FL_C_INF) && !vkq->skip_fixed[1];
     const LineAffC* lines0 = with_fixed ? vkq->lines[0] : nullptr;
     const LineAffC* lines1 = with_fixed ? vkq->lines[1] : nullptr;
@@ -225,19 +235,19 @@ ZKV_HD void miller_loop_m(const VkTables* vkp, uint32_t flags, const G1Norm& n, 
 #pragma unroll 1
     for (int i = ZKV_ATE_NAF_LEN - 2; i >= 0; i--) {
         if (i != ZKV_ATE_NAF_LEN - 2) f12m_sqr(fm);
-        if (do_ab) {
+        if (do_t) {
             g2m_line_dbl(tm, &l0, &l1, &l3);
-            var_line_mul(fm, l0, l1, l3, n.axs, n.ays);
+            if (do_ab) var_line_mul(fm, l0, l1, l3, n.axs, n.ays);
         }
         if (do_l) fixed_line_mul(fm, lines0[li], n.lxs, n.lys);
         if (do_c) fixed_line_mul(fm, lines1[li], n.cxs, n.cys);
         li++;
         int d = ate_naf(i);
         if (d != 0) {
-            if (do_ab) {
+            if (do_t) {
                 Fp2 qy = d > 0 ? by : nby;
                 g2m_line_add(tm, &bx, &qy, &l0, &l1, &l3);
-                var_line_mul(fm, l0, l1, l3, n.axs, n.ays);
+                if (do_ab) var_line_mul(fm, l0, l1, l3, n.axs, n.ays);
             }
             if (do_l) fixed_line_mul(fm, lines0[li], n.lxs, n.lys);
             if (do_c) fixed_line_mul(fm, lines1[li], n.cxs, n.cys);
@@ -250,14 +260,15 @@ ZKV_HD void miller_loop_m(const VkTables* vkp, uint32_t flags, const G1Norm& n, 
     qy[1] = f2_neg(qy[1]);
 #pragma unroll 1
     for (int s = 0; s < 2; s++) {
-        if (do_ab) {
+        if (do_t) {
             g2m_line_add(tm, &qx[s], &qy[s], &l0, &l1, &l3);
-            var_line_mul(fm, l0, l1, l3, n.axs, n.ays);
+            if (do_ab) var_line_mul(fm, l0, l1, l3, n.axs, n.ays);
         }
         if (do_l) fixed_line_mul(fm, lines0[li], n.lxs, n.lys);
         if (do_c) fixed_line_mul(fm, lines1[li], n.cxs, n.cys);
         li++;
     }
+    return !(check_b && do_t) || miller_point_closes(tm, bx, by);
 }
 
 #if defined(ZKV_PAIRED)
@@ -278,11 +289,22 @@ struct SoaRef {                         // word k of this proof's (this lane's) 
     }
 };
 // norm: axs ays lxs lys cxs cys at words 0 8 16 24 32 40; bsrc: this lane's component of B.x at word 0 and of B.y at word 16.
+//
+// check_b: the loop doubles as the order-r subgroup test of B (EIP-197), and returns its verdict.  After the 88 steps the running
+// point is T = [6u+2]B + psi(B) - psi^2(B), and (6u+2) + p - p^2 + p^3 = 0 mod r, so B in G2 implies T = -psi^3(B) -- the reason the
+// optimal-ate pairing has no fourth line.  The converse holds as well: h(psi)B = O for h = (6u+2) + X - X^2 + X^3 implies
+// ord(B) | gcd(Res(h, X^2 - tX + p), #E'(Fp2)), and that gcd is r (tools/check_g2_vector.py; the classical test vector
+// (u+1, u, u, -2u) of g2_in_subgroup passes the same computation).  A point outside G2 may drive the incomplete tangent / chord formulas
+// into an exceptional case (T = O, T = +-B, a 2-torsion T); every one of them leaves Z = 0, and Z = 0 is absorbing for both formulas
+// (Z3 = 2 Y^3 Z, Z3 = Z lambda^3), so such a point ends with Z = 0 and is rejected, while a point of G2 (prime order r, larger than
+// every partial scalar) never meets one and ends with Z != 0.  With check_b the point is stepped for A = infinity too (the precompile
+// validates B whether or not the pair contributes); only the line products are skipped then.
 template <class RF, class RT>
-ZKV_HD void miller_loop_p(const VkTables* vkp, uint32_t flags, SoaRef norm, SoaRef bsrc, RF fm, RT tm) {
+ZKV_HD bool miller_loop_p(const VkTables* vkp, uint32_t flags, SoaRef norm, SoaRef bsrc, RF fm, RT tm, bool check_b = false) {
     const uint8_t KIND[ZKV_MILLER_STEPS] = ZKV_MILLER_STEP_KIND;
     const bool with_fixed = vkp != nullptr;
     const bool do_ab = !(flags & (FL_A_INF | FL_B_INF));
+    const bool do_t = do_ab || (check_b && !(flags & FL_B_INF));
     const bool do_l = with_fixed && !(flags & FL_L_INF) && !vkp->skip_fixed[0], do_c = with_fixed && !(flags & FL_C_INF) && !vkp->skip_fixed[1];
     f12m_set_one(fm);
     { Fp2 bx, by; bx.h = bsrc.fp(0); by.h = bsrc.fp(16); m_st_f2(tm, 0, bx); m_st_f2(tm, 1, by); m_st_f2(tm, 2, f2_one()); }
@@ -290,7 +312,7 @@ ZKV_HD void miller_loop_p(const VkTables* vkp, uint32_t flags, SoaRef norm, SoaR
     for (int li = 0; li < ZKV_MILLER_STEPS; li++) {
         const int kind = KIND[li];
         if (kind == 0 && li != 0) f12m_sqr_body(fm);
-        if (do_ab) {
+        if (do_t) {
             Fp2 l0, l1, l3;
             G2H T; T.x = m_ld_f2(tm, 0); T.y = m_ld_f2(tm, 1); T.z = m_ld_f2(tm, 2);
             if (kind == 0) line_dbl(T, l0, l1, l3);
@@ -302,8 +324,10 @@ ZKV_HD void miller_loop_p(const VkTables* vkp, uint32_t flags, SoaRef norm, SoaR
                 line_add(T, qx, qy, l0, l1, l3);
             }
             m_st_f2(tm, 0, T.x); m_st_f2(tm, 1, T.y); m_st_f2(tm, 2, T.z);
-            const Fp2 c3 = f2_mul_fp(l1, norm.fp(0)), c4 = f2_mul_fp(l3, norm.fp(8));
-            f12m_mul_by_034_body(fm, l0, c3, c4);
+            if (do_ab) {
+                const Fp2 c3 = f2_mul_fp(l1, norm.fp(0)), c4 = f2_mul_fp(l3, norm.fp(8));
+                f12m_mul_by_034_body(fm, l0, c3, c4);
+            }
         }
 #pragma unroll 1
         for (int j = 0; j < 2; j++) {
@@ -316,6 +340,9 @@ ZKV_HD void miller_loop_p(const VkTables* vkp, uint32_t flags, SoaRef norm, SoaR
             f12m_mul_by_134_body(fm, c3, c4);
         }
     }
+    if (!check_b || !do_t) return true;
+    Fp2 qx, qy; qx.h = bsrc.fp(0); qy.h = bsrc.fp(16);
+    return miller_point_closes(tm, qx, qy);
 }
 #endif  // ZKV_PAIRED
 

@@ -42,3 +42,8 @@ def revert_vectors():
 @pytest.fixture(scope='session')
 def wire_cases():
     return load_golden('wire_cases.json')
+
+
+@pytest.fixture(scope='session')
+def g2_membership_points():
+    return load_golden('g2_membership_points.json')['points']

@@ -56,7 +56,7 @@ int hs_groth16(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* wor
     // same slot structure as the kernels: f and T in one buffer (LDS on the device), 5 Fp12 slots for the final exp
     static thread_local uint32_t buf[96 + 48], slots[8 * 96];
     MRef fm = m_ref(buf, 1), tm = m_ref(buf + 96, 1);
-    miller_loop_m(t, fl, n, p.bx, p.by, fm, tm);
+    if (!miller_loop_m(t, fl, n, p.bx, p.by, fm, tm, true)) return -1;     // the loop's own subgroup verdict must agree with the classical test above
     g_stage_muls[3] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
     MRef F = m_ref(slots, 1), E = m_ref(slots + 96, 1), Y1 = m_ref(slots + 192, 1), Y3 = m_ref(slots + 288, 1), Y4 = m_ref(slots + 384, 1);
     for (int k = 0; k < 96; k++) slots[k] = t->f_alpha_beta[k];
@@ -240,6 +240,42 @@ int hs_set_instance(const uint8_t* cr, const uint8_t* cid, const uint8_t* s0, co
         for (int i = 0; i < 8; i++) for (int b = 0; b < 4; b++) vkx64[32 * c + 31 - 4 * i - b] = (uint8_t)(r[i] >> (8 * b));
     }
     return (int)tab.fail;
+}
+// The subgroup verdict the Miller loop produces on its way (miller_loop_m / miller_loop_p with check_b), for an on-twist point alone:
+// no G1 point, no line products, only the running point.
+int hs_g2_in_subgroup_by_miller(const uint8_t* q128) {
+    uint32_t w[4][8];
+    for (int k = 0; k < 4; k++) load_be256(w[k], q128 + 32 * k);
+    Fp2 x, y; x.c1 = fp_from_raw(w[0]); x.c0 = fp_from_raw(w[1]); y.c1 = fp_from_raw(w[2]); y.c0 = fp_from_raw(w[3]);
+    if (!g2_on_twist(x, y)) return -1;
+    static thread_local uint32_t buf[96 + 48];
+    G1Norm n; n.axs = n.ays = n.lxs = n.lys = n.cxs = n.cys = fp_zero();
+    return miller_loop_m((const VkTables*)nullptr, FL_A_INF, n, x, y, m_ref(buf, 1), m_ref(buf + 96, 1), true) ? 1 : 0;
+}
+// Exceptional cases of the incomplete tangent / chord formulas (T = B, T = -B, T = O): each must leave Z = 0, and Z = 0 must
+// survive further tangent and chord steps -- what the Miller-loop subgroup verdict relies on for points outside G2.
+// Returns a bit mask of the checks that FAILED (0 = all hold).
+int hs_line_exceptional(const uint8_t* q128) {
+    uint32_t w[4][8];
+    for (int k = 0; k < 4; k++) load_be256(w[k], q128 + 32 * k);
+    Fp2 x, y; x.c1 = fp_from_raw(w[0]); x.c0 = fp_from_raw(w[1]); y.c1 = fp_from_raw(w[2]); y.c0 = fp_from_raw(w[3]);
+    int bad = 0;
+    Fp2 l0, l1, l3;
+    for (int c = 0; c < 3; c++) {
+        G2H T; T.x = x; T.y = c == 1 ? f2_neg(y) : y; T.z = f2_one();
+        if (c == 2) { T.x = f2_zero(); T.z = f2_zero(); }            // O = (0 : Y : 0)
+        // scale to a non-trivial projective representative
+        const Fp2 k = f2_add(f2_mul(x, y), f2_one());
+        T.x = f2_mul(T.x, k); T.y = f2_mul(T.y, k); T.z = f2_mul(T.z, k);
+        line_add(T, x, y, l0, l1, l3);
+        if (!f2_is_zero(T.z)) bad |= 1 << c;
+        line_dbl(T, l0, l1, l3);
+        if (!f2_is_zero(T.z)) bad |= 8 << c;
+        line_add(T, x, y, l0, l1, l3);
+        if (!f2_is_zero(T.z)) bad |= 64 << c;
+    }
+    { G2H T; T.x = x; T.y = f2_zero(); T.z = f2_one(); line_dbl(T, l0, l1, l3); if (!f2_is_zero(T.z)) bad |= 512; }   // a 2-torsion shape (Y = 0)
+    return bad;
 }
 int hs_g2_in_subgroup(const uint8_t* q128) {     // EIP-197 order: x_im x_re y_im y_re; must be on twist
     uint32_t w[4][8];

@@ -37,16 +37,16 @@ static void lane(Job* j, uint32_t par) {
     memcpy(bx.h.v, j->b32 + 8 * par, 32); memcpy(by.h.v, j->b32 + 16 + 8 * par, 32);
     unsigned long long c0 = zkv_fp_mul_counter;
     j->muls[par][0] = j->muls[par][1] = j->muls[par][2] = 0;
-    bool sub = (j->flags & FL_B_INF) ? true : g2_in_subgroup(bx, by);
+    const bool sub_classic = (j->flags & FL_B_INF) ? true : g2_in_subgroup(bx, by);      // k_g2chk2 (kept for the 16-lane kernels)
     j->muls[par][0] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
-    j->sub_ok[par] = sub ? 1 : 0;
-    if (!sub) { j->accept[par] = 0; return; }
     // lane-private half slots (f2w = 8) for f, T and the accumulator; full-layout slots (f2w = 16) for the cold values
     static thread_local uint32_t half[48 + 24];
     static uint32_t full[8 * 96];                    // shared by the two lanes like the HBM slots
     MRef fm = m_ref(half, 1, 8), tm = m_ref(half + 48, 1, 8);
     SoaRef norm = {j->norm48, 1}, bsrc = {j->b32 + 8 * par, 1};
-    miller_loop_p(j->t, j->flags, norm, bsrc, fm, tm);        // the flat, fully inlined loop k_miller2 runs
+    const bool sub = miller_loop_p(j->t, j->flags, norm, bsrc, fm, tm, true);        // the flat, fully inlined loop k_miller2 runs, with its subgroup verdict
+    j->sub_ok[par] = sub == sub_classic ? (sub ? 1 : 0) : -1;                        // the two tests must agree
+    if (!sub) { j->muls[par][1] = zkv_fp_mul_counter - c0; j->accept[par] = 0; return; }
     MRef ab = m_ref((uint32_t*)j->t->f_alpha_beta + 8 * par, 1, 16);
     MRef F = m_ref(full + 8 * par, 1, 16), E = m_ref(full + 96 + 8 * par, 1, 16);
     f12m_mul(F, fm, ab);
@@ -66,7 +66,7 @@ extern "C" int hs2_pairing(const void* tables, uint32_t flags, const uint32_t* n
     lane(&j, 0u);
     t1.join();
     for (int k = 0; k < 3; k++) g_pair_muls[k] = j.muls[0][k] + j.muls[1][k];
-    if (j.sub_ok[0] != j.sub_ok[1] || j.accept[0] != j.accept[1]) return -1;     // the pair must agree
+    if (j.sub_ok[0] != j.sub_ok[1] || j.sub_ok[0] < 0 || j.accept[0] != j.accept[1]) return -1;     // the pair, and the two subgroup tests, must agree
     *sub_ok = j.sub_ok[0];
     return j.accept[0];
 }
