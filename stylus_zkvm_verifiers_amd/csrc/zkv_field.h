@@ -30,6 +30,8 @@ static thread_local unsigned long long zkv_fp_mul_counter = 0;      // per threa
 #define ZKV_TABLE static const
 #endif
 
+#include "zkv_modinv.h"
+
 namespace zkv {
 
 struct Fp { uint32_t v[8]; };
@@ -247,9 +249,9 @@ ZKV_HD void fp_to_raw(uint32_t* limbs, const Fp& a) {      // out of Montgomery 
     for (int i = 0; i < 8; i++) s.v[i] = subb(t.v[i], P[i], br);
     for (int i = 0; i < 8; i++) limbs[i] = br ? t.v[i] : s.v[i];
 }
-// a^(p-2); inv(0) = 0.  Sliding window of width 3 over a, a^3, a^5, a^7 (schedule generated by gen_constants.py):
-// a loop, not unrolled.
-ZKV_HD Fp fp_inv(const Fp& a) {
+// a^(p-2); inv(0) = 0.  Sliding window of width 2 over a, a^3 (schedule generated by gen_constants.py): a loop, not unrolled.
+// Kept as the independent check of fp_inv (tests/host_sim) -- the kernels invert with the division steps of zkv_modinv.h.
+ZKV_HD Fp fp_inv_fermat(const Fp& a) {
     const uint8_t S[ZKV_FP_INV_SCHED_LEN] = ZKV_FP_INV_SCHED;
     const Fp a3 = fp_mul(fp_sqr(a), a);
     Fp acc = (S[0] & 7) == 3 ? a3 : a;
@@ -266,6 +268,16 @@ ZKV_HD Fp fp_inv(const Fp& a) {
         }
     }
     return acc;
+}
+
+// 1/a in Montgomery form; inv(0) = 0.  (aR)^-1 by safegcd division steps (no multiplications, ~1/8 of the Fermat chain's
+// instructions), then one multiplication by R^3 brings a^-1 R^-1 back to a^-1 R.  Accepts the loose range.
+ZKV_HD Fp fp_inv(const Fp& a) {
+    const int32_t M[9] = ZKV_FP_M30_LIMBS;
+    const Fp r3 = ZKV_FP_R3;
+    Fp t = a;
+    modinv30(t.v, M, ZKV_FP_MINV30);
+    return fp_mul(t, r3);
 }
 
 // N independent modular additions / subtractions, carry chains interleaved limb by limb (same idea as *_x2).

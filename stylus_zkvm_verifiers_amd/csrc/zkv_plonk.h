@@ -88,7 +88,15 @@ ZKV_HD Fr fr_pow(const Fr& a, const uint32_t* e, int bits) {   // left to right
     }
     return acc;
 }
-ZKV_HD Fr fr_inv(const Fr& a) { const uint32_t E[8] = ZKV_FR_RM2_LIMBS; return fr_pow(a, E, 254); }     // inv(0) = 0
+ZKV_HD Fr fr_inv_fermat(const Fr& a) { const uint32_t E[8] = ZKV_FR_RM2_LIMBS; return fr_pow(a, E, 254); }     // inv(0) = 0; the check of fr_inv
+// inv(0) = 0.  Division steps (zkv_modinv.h) on the Montgomery residue, then one multiplication by R^3.
+ZKV_HD Fr fr_inv(const Fr& a) {
+    const int32_t M[9] = ZKV_FR_M30_LIMBS;
+    const Fr r3 = ZKV_FR_R3;
+    Fr t = a;
+    modinv30(t.v, M, ZKV_FR_MINV30);
+    return fr_mul(t, r3);
+}
 
 // ---------------------------------------------------------------- streaming SHA-256 for the transcripts (byte granular)
 struct ShaStream {

@@ -277,6 +277,24 @@ int hs_line_exceptional(const uint8_t* q128) {
     { G2H T; T.x = x; T.y = f2_zero(); T.z = f2_one(); line_dbl(T, l0, l1, l3); if (!f2_is_zero(T.z)) bad |= 512; }   // a 2-torsion shape (Y = 0)
     return bad;
 }
+// 1/a through fp_inv (safegcd division steps) for a raw value given big-endian; loose != 0 feeds the second representation
+// (a + p) of the Montgomery residue.  Returns 1 when the Fermat chain (fp_inv_fermat) gives the same canonical result.
+int hs_fp_inv(const uint8_t* a32, int loose, uint8_t* out32) {
+    uint32_t w[8]; load_be256(w, a32);
+    Fp a = fp_from_raw(w);
+    if (loose) {
+        const uint32_t P[8] = ZKV_FP_P_LIMBS; const uint32_t P2[8] = ZKV_FP_2P_LIMBS;
+        Fp t; uint32_t c = 0;
+        for (int i = 0; i < 8; i++) t.v[i] = addc(a.v[i], P[i], c);
+        if (!u256_geq(t.v, P2)) a = t;                  // only if the residue was below p
+    }
+    uint32_t r[8], r2[8];
+    fp_to_raw(r, fp_inv(a)); fp_to_raw(r2, fp_inv_fermat(a));
+    for (int i = 0; i < 8; i++) for (int k = 0; k < 4; k++) out32[31 - 4 * i - k] = r[i] >> (8 * k);
+    int same = 1;
+    for (int i = 0; i < 8; i++) same &= r[i] == r2[i];
+    return same;
+}
 int hs_g2_in_subgroup(const uint8_t* q128) {     // EIP-197 order: x_im x_re y_im y_re; must be on twist
     uint32_t w[4][8];
     for (int k = 0; k < 4; k++) load_be256(w[k], q128 + 32 * k);

@@ -49,6 +49,19 @@ def test_fp_mul_matches_bigint(hs):
         assert int.from_bytes(o.raw, 'big') == a * b % m.P
 
 
+def test_fp_inv_by_division_steps(hs):
+    """fp_inv (csrc/zkv_modinv.h: Bernstein-Yang division steps, 20 batches of 30 on signed 30-bit limbs) against Python's pow and
+    against the Fermat chain it replaced, on edge values, both representations of the loose range, and random values; inv(0) = 0."""
+    rng = random.Random(0xD1F5)
+    vals = [0, 1, 2, 3, m.P - 1, m.P - 2, (m.P + 1) // 2, (1 << 253), (1 << 253) - 1, (1 << 30) - 1, 1 << 30, (1 << 60) + 1, m.P >> 1]
+    vals += [rng.randrange(m.P) for _ in range(400)] + [rng.randrange(1 << k) for k in (31, 61, 91, 128, 200) for _ in range(8)]
+    for a in vals:
+        for loose in (0, 1):
+            o = C.create_string_buffer(32)
+            assert hs.hs_fp_inv(a.to_bytes(32, 'big'), loose, o) == 1, hex(a)
+            assert int.from_bytes(o.raw, 'big') == (pow(a, -1, m.P) if a else 0), hex(a)
+
+
 def test_loose_range_invariance(hs):
     """Field values live in [0, 2p): every operation must return the same residue for either representation of its operands,
     stay below 2p, and the comparisons must identify x with x + p (edge values 0, 1, p-1 and random ones)."""
