@@ -399,12 +399,19 @@ ZKV_HD Fp2 f2_inv(const Fp2& a) {
 
 #else   // ---------------------------------------------------------------- Fp2, lane-pair mode
 #if defined(__HIP_DEVICE_COMPILE__)
-ZKV_HD uint32_t zkv_parity() { return threadIdx.x & 1u; }
+// parity of the lane within its wavefront (= parity of threadIdx.x: blocks are whole wavefronts), from the lane counter: a non-inlined
+// leaf that reads threadIdx is handed the packed work-item id in v31.
+ZKV_HD uint32_t zkv_parity() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 1u; }
 // value held by the other lane of the pair: v_mov_b32_dpp quad_perm:[1,0,3,2]
 ZKV_HD uint32_t zkv_partner_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true); }
+// the even (odd) lane's value in both lanes of the pair: quad_perm:[0,0,2,2] ([1,1,3,3])
+ZKV_HD uint32_t zkv_pair_even_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xA0, 0xF, 0xF, true); }
+ZKV_HD uint32_t zkv_pair_odd_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xF5, 0xF, 0xF, true); }
 #else
 uint32_t zkv_parity();                      // host emulation of a lane pair (tests/host_sim, two threads)
 uint32_t zkv_partner_u32(uint32_t x);
+inline uint32_t zkv_pair_even_u32(uint32_t x) { const uint32_t o = zkv_partner_u32(x); return zkv_parity() ? o : x; }
+inline uint32_t zkv_pair_odd_u32(uint32_t x) { const uint32_t o = zkv_partner_u32(x); return zkv_parity() ? x : o; }
 #endif
 ZKV_HD Fp zkv_partner(const Fp& a) {
     Fp r;
@@ -452,14 +459,16 @@ Fp f2_mul_lane(Fp my_a, Fp my_b) {
 #endif
     const uint32_t FAT[9] = ZKV_FP_FAT8P_LIMBS;
     const bool odd = zkv_parity() != 0;
-    uint32_t xa[9], xo[9], yb[9], yo[9], U[9], V[9];
+    uint32_t xa[9], xo[9], yb[9], U[9], V[9];
     fp_unpack29(my_a, xa); fp_unpack29(my_b, yb);        // each lane unpacks its own operands once ...
+    // ... and the limbs travel: a is swapped; of b both lanes take the even lane's b0 (for the product with their own a) and the odd
+    // lane's b1 (for the product with the partner's a), which the even lane turns into 8p - b1.  Three DPP moves per limb and no
+    // selects (the swap-and-select form cost 18 more v_mov).
 #pragma unroll
-    for (int i = 0; i < 9; i++) { xo[i] = zkv_partner_u32(xa[i]); yo[i] = zkv_partner_u32(yb[i]); }   // ... and swaps the limbs
+    for (int i = 0; i < 9; i++) { xo[i] = zkv_partner_u32(xa[i]); U[i] = zkv_pair_even_u32(yb[i]); V[i] = zkv_pair_odd_u32(yb[i]); }
+    if (!odd) {
 #pragma unroll
-    for (int i = 0; i < 9; i++) {
-        U[i] = odd ? yo[i] : yb[i];
-        V[i] = odd ? yb[i] : FAT[i] - yo[i];
+        for (int i = 0; i < 9; i++) V[i] = FAT[i] - V[i];
     }
     uint64_t col[18];
 #pragma unroll
@@ -468,6 +477,49 @@ Fp f2_mul_lane(Fp my_a, Fp my_b) {
     return fp_reduce_cols(col);
 }
 ZKV_HD Fp2 f2_mul(const Fp2& a, const Fp2& b) { Fp2 r; r.h = f2_mul_lane(a.h, b.h); return r; }
+// a b + c d with ONE Montgomery reduction per lane: four 81-term column products (even lane a0 b0 + a1 (8p - b1) + c0 d0 + c1 (8p - d1),
+// odd lane a0 b1 + a1 b0 + c0 d1 + c1 d0).  All four operands must be reduced values (< 2p: limbs < 2^29 after unpacking; no lazy
+// sums here): a column then holds at most 18 products below 2^58, 18 below 2^59 (the 8p - x limbs are below 2^30) and the 9
+// reduction terms below 2^58 -- 63 * 2^58 < 2^64 -- and the value stays below 40 p^2 < 169 p^2.  Used where two products are only
+// ever added (the sparse fixed-line products of the Miller loop): 405 multiplies and one reduce / pack set instead of 486 and two.
+// The device leaf is f2_dot2_lds (zkv_tower_mem.h): four Fp structs do not fit the 16 argument registers the ABI grants aggregates -- a
+// first version with four by-value operands had two of them written to and read back from scratch memory at every call, 8.6 GB per
+// 2^20-proof launch -- so the leaf takes the two line coefficients by value and reads the two accumulator coefficients from LDS itself.
+ZKV_HD Fp f2_dot2_body(const Fp& my_a, const Fp& my_b, const Fp& my_c, const Fp& my_d) {
+#if defined(ZKV_COUNT_FP_MUL)
+    zkv_fp_mul_counter += 4;
+#endif
+    const uint32_t FAT[9] = ZKV_FP_FAT8P_LIMBS;
+    const bool odd = zkv_parity() != 0;
+    uint64_t col[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) col[k] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZKV_DOT2_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ZKV_DOT2_FENCE() do {} while (0)
+#endif
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        uint32_t xa[9], yb[9], W[9];
+        fp_unpack29(t ? my_c : my_a, xa); fp_unpack29(t ? my_d : my_b, yb);
+#pragma unroll
+        for (int i = 0; i < 9; i++) W[i] = zkv_pair_even_u32(yb[i]);
+        fp_mac81(col, xa, W);                                   // own a (c) times the even lane's b0 (d0)
+        ZKV_DOT2_FENCE();
+#pragma unroll
+        for (int i = 0; i < 9; i++) { xa[i] = zkv_partner_u32(xa[i]); W[i] = zkv_pair_odd_u32(yb[i]); }
+        if (!odd) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) W[i] = FAT[i] - W[i];
+        }
+        fp_mac81(col, xa, W);                                   // the partner's a (c) times b1 (d1), negated in the even lane
+        ZKV_DOT2_FENCE();
+    }
+#undef ZKV_DOT2_FENCE
+    return fp_reduce_cols(col);
+}
+ZKV_HD Fp2 f2_dot2(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) { Fp2 r; r.h = f2_dot2_body(a.h, b.h, c.h, d.h); return r; }
 ZKV_HD Fp2 f2_sqr(const Fp2& a) {           // reduced (< 2p) input: even lane (a0+a1)(a0-a1), odd lane (2 a1) a0
     const bool odd = zkv_parity() != 0;
     Fp o = zkv_partner(a.h);
