@@ -205,7 +205,7 @@ ZKV_HD G1J g1j_add(const G1J& p, const G1J& q) {             // complete Jacobia
 }
 // One term of a multi-scalar multiplication: an affine point (or infinity) and a canonical 256-bit scalar.
 struct MsmTerm { Fp x, y; uint32_t inf; uint32_t k[8]; const G1A* fixed; };      // fixed: the key's affine table of 1P..8P, or null
-// start + sum k_i P_i: Straus with SIGNED 4-BIT WINDOWS.  Per term the multiples P .. 8P (Jacobian) are tabulated once; the 64
+// start + sum k_i P_i: Straus with SIGNED 4-BIT WINDOWS.  Per term the multiples P .. 8P are tabulated once (affine, see below); the 64
 // windows of the shared doubling chain then add +-(|d| P) for every term -- every lane of the wavefront takes the same path
 // (a one-bit-per-step loop executes each chord addition for all lanes although only half of them need it: 256 additions per
 // term instead of 64).  Scalars are < r < 2^254, so the recoding never carries out of the top window.
@@ -241,6 +241,32 @@ template <int N> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&t)[N], i
             dig[i][w] = out;
         }
     }
+    // The per-proof tables become affine with ONE inversion for the whole multi-scalar multiplication (Montgomery's trick over the
+    // seven Z of 2P..8P of every proof point: 7 multiplications per entry), so that all 64 additions of a term are mixed additions
+    // (11 instead of 16 multiplications).  Entries are never infinity: G1 has prime order.
+    {
+        Fp pre[N][7];
+        Fp run = fp_one();
+#pragma unroll 1
+        for (int i = 0; i < n; i++) {
+            if (t[i].inf || t[i].fixed) continue;
+#pragma unroll 1
+            for (int m = 1; m < 8; m++) { pre[i][m - 1] = run; run = fp_mul(run, tab[i].m[m].z); }
+        }
+        Fp inv = fp_inv(run);
+#pragma unroll 1
+        for (int i = n - 1; i >= 0; i--) {
+            if (t[i].inf || t[i].fixed) continue;
+#pragma unroll 1
+            for (int m = 7; m >= 1; m--) {
+                const Fp zi = fp_mul(inv, pre[i][m - 1]);
+                inv = fp_mul(inv, tab[i].m[m].z);
+                const Fp zi2 = fp_sqr(zi);
+                tab[i].m[m].x = fp_mul(tab[i].m[m].x, zi2);
+                tab[i].m[m].y = fp_mul(tab[i].m[m].y, fp_mul(zi2, zi));
+            }
+        }
+    }
     G1J acc = g1j_infinity();
 #pragma unroll 1
     for (int win = 63; win >= 0; win--) {
@@ -251,14 +277,10 @@ template <int N> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&t)[N], i
             const int d = (int)((dig[i][win >> 3] >> (4 * (win & 7))) & 15u) - 8;       // -8 .. 7
             if (d == 0) continue;
             const int m = (d < 0 ? -d : d) - 1;
-            if (t[i].fixed) {                                    // wave-uniform: the same term index in every lane
-                const G1A e = t[i].fixed[m];
-                acc = g1j_add_affine(acc, e.x, d < 0 ? fp_neg(e.y) : e.y);
-            } else {
-                G1J q = tab[i].m[m];
-                if (d < 0) q.y = fp_neg(q.y);
-                acc = g1j_add(acc, q);
-            }
+            G1A e;
+            if (t[i].fixed) e = t[i].fixed[m];                   // wave-uniform: the same term index in every lane
+            else { e.x = tab[i].m[m].x; e.y = tab[i].m[m].y; }
+            acc = g1j_add_affine(acc, e.x, d < 0 ? fp_neg(e.y) : e.y);
         }
     }
     return g1j_add(acc, start);
