@@ -145,6 +145,7 @@ struct PlonkKey {
     G1A mult[PK_POINTS + 1][8];     // k * P, k = 1..8, affine, for the nine key points and (last row) the G1 generator: the
                                     // signed-window tables of the FIXED terms of the multi-scalar multiplications
     uint32_t mult_inf[PK_POINTS + 1][8];
+    Fp mult_bx[PK_POINTS + 1][8];   // beta * x of the same entries: the tables of phi(P) = (beta x, y) = lambda P (GLV)
 };
 constexpr int PK_GEN = PK_POINTS;
 // A G1 point as the precompiles take it: coordinates < P, on the curve or (0,0) = infinity.  Returns false when invalid.
@@ -180,6 +181,8 @@ ZKV_HD void plonk_setup_key(const PlonkKeyRaw& r, PlonkKey& k) {
         for (int m = 0; m < 8; m++) {
             if (!binf && ok) acc = g1j_add_affine(acc, base.x, base.y);
             g1j_to_affine(acc, k.mult[p][m], k.mult_inf[p][m]);
+            const Fp beta = ZKV_GLV_BETA;
+            k.mult_bx[p][m] = fp_mul(k.mult[p][m].x, beta);
         }
     }
 }
@@ -204,11 +207,72 @@ ZKV_HD G1J g1j_add(const G1J& p, const G1J& q) {             // complete Jacobia
     return r;
 }
 // One term of a multi-scalar multiplication: an affine point (or infinity) and a canonical 256-bit scalar.
-struct MsmTerm { Fp x, y; uint32_t inf; uint32_t k[8]; const G1A* fixed; };      // fixed: the key's affine table of 1P..8P, or null
-// start + sum k_i P_i: Straus with SIGNED 4-BIT WINDOWS.  Per term the multiples P .. 8P are tabulated once (affine, see below); the 64
-// windows of the shared doubling chain then add +-(|d| P) for every term -- every lane of the wavefront takes the same path
-// (a one-bit-per-step loop executes each chord addition for all lanes although only half of them need it: 256 additions per
-// term instead of 64).  Scalars are < r < 2^254, so the recoding never carries out of the top window.
+// fixed / fixed_bx: the key's affine table of 1P..8P and of beta * x of the same entries, or null (table built per proof).
+struct MsmTerm { Fp x, y; uint32_t inf; uint32_t k[8]; const G1A* fixed; const Fp* fixed_bx; };
+
+// ---- GLV: k = k1 + k2 lambda (mod r) with |k1|, |k2| < 2^128, lambda P = phi(P) = (beta x, y).
+// Babai rounding against the basis (a1, -n), (n, b2), n = 2u + 1, a1 = 6u^2 + 2u, b2 = 6u^2 + 4u + 1:  c1 = floor(k g1 / 2^256),
+// c2 = floor(k g2 / 2^256) with g1 = floor(2^256 b2 / r), g2 = floor(2^256 n / r);  k1 = k - c1 a1 - c2 n,  k2 = c1 n - c2 b2.
+// The identity k1 + k2 lambda = k holds for ANY c1, c2 (both basis vectors are 0 mod r); the truncations only cost magnitude:
+// |k1|, |k2| <= 2^127 on 2 x 10^5 random and edge scalars in the model (gen_constants.py documents the constants).
+template <int NA, int NB> ZKV_HD void glv_mul(const uint32_t (&a)[NA], const uint32_t (&b)[NB], uint32_t (&out)[NA + NB]) {
+    for (int i = 0; i < NA + NB; i++) out[i] = 0;
+#pragma unroll 1
+    for (int i = 0; i < NA; i++) {
+        uint64_t c = 0;
+#pragma unroll 1
+        for (int j = 0; j < NB; j++) { c += (uint64_t)a[i] * b[j] + out[i + j]; out[i + j] = (uint32_t)c; c >>= 32; }
+        out[i + NB] = (uint32_t)c;
+    }
+}
+// m <- |x - y - z| on six words (two's complement; the true value is below 2^129 in magnitude), returns 1 when negative
+ZKV_HD uint32_t glv_diff(const uint32_t* x, const uint32_t* y, const uint32_t* z, int nz, uint32_t (&m)[5]) {
+    uint32_t t[6]; uint32_t b = 0;
+#pragma unroll 1
+    for (int i = 0; i < 6; i++) t[i] = subb(x[i], y[i], b);
+    if (z) { b = 0;
+#pragma unroll 1
+        for (int i = 0; i < 6; i++) t[i] = subb(t[i], i < nz ? z[i] : 0u, b); }
+    const uint32_t neg = t[5] >> 31, mask = 0u - neg;
+    uint32_t c = neg;
+#pragma unroll 1
+    for (int i = 0; i < 6; i++) { const uint64_t v = (uint64_t)(t[i] ^ mask) + c; t[i] = (uint32_t)v; c = (uint32_t)(v >> 32); }
+    for (int i = 0; i < 5; i++) m[i] = t[i];
+    return neg;
+}
+ZKV_HD void glv_split(const uint32_t (&k)[8], uint32_t (&m1)[5], uint32_t& neg1, uint32_t (&m2)[5], uint32_t& neg2) {
+    const uint32_t G1[5] = ZKV_GLV_G1, G2[3] = ZKV_GLV_G2, A1[4] = ZKV_GLV_A1, NN[2] = ZKV_GLV_N, B2[4] = ZKV_GLV_B2;
+    uint32_t p1[13], p2[11];
+    glv_mul<8, 5>(k, G1, p1); glv_mul<8, 3>(k, G2, p2);
+    uint32_t c1[5], c2[3];
+    for (int i = 0; i < 5; i++) c1[i] = p1[8 + i];
+    for (int i = 0; i < 3; i++) c2[i] = p2[8 + i];
+    uint32_t t1[9], t2[5], u1[7], u2[7];
+    glv_mul<5, 4>(c1, A1, t1); glv_mul<3, 2>(c2, NN, t2); glv_mul<5, 2>(c1, NN, u1); glv_mul<3, 4>(c2, B2, u2);
+    neg1 = glv_diff(k, t1, t2, 5, m1);                      // k - c1 a1 - c2 n   (low six words are enough)
+    neg2 = glv_diff(u1, u2, nullptr, 0, m2);               // c1 n - c2 b2
+}
+// 33 signed 4-bit digits of a magnitude below 2^131, packed 4 bits each as d + 8
+ZKV_HD void glv_digits(const uint32_t (&m)[5], uint32_t (&dig)[5]) {
+    uint32_t carry = 0;
+#pragma unroll 1
+    for (int w = 0; w < 5; w++) {
+        uint32_t out = 0;
+#pragma unroll 1
+        for (int j = 0; j < 8; j++) {
+            uint32_t d = ((m[w] >> (4 * j)) & 15u) + carry;          // 0 .. 16
+            carry = d >= 8u ? 1u : 0u;
+            out |= ((d + 8u) & 15u) << (4 * j);                        // d - 16 * carry + 8
+        }
+        dig[w] = out;
+    }
+}
+
+// start + sum k_i P_i: Straus with SIGNED 4-BIT WINDOWS over the GLV halves of every scalar.  Per term the multiples P .. 8P are
+// tabulated once (affine, see below) together with beta * x, which makes them the multiples of phi(P) = lambda P; each scalar splits
+// into two halves below 2^128, so the shared doubling chain has 33 windows = 132 doublings instead of 256, and every window adds
+// +-(|d| P) and +-(|d'| phi(P)) for every term -- every lane of the wavefront takes the same path (a one-bit-per-step loop executes
+// each chord addition for all lanes although only half of them need it).
 struct MsmTable { G1J m[8]; };
 ZKV_HD void plonk_msm_table(MsmTable& tb, const MsmTerm& t) {
     G1J p; p.x = t.x; p.y = t.y; p.z = fp_one();
@@ -223,28 +287,22 @@ ZKV_HD void plonk_msm_table(MsmTable& tb, const MsmTerm& t) {
 }
 template <int N> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&t)[N], int n) {
     MsmTable tab[N];
-    uint32_t dig[N][8];                                   // 64 signed digits per term, packed 4 bits each as d + 8 (0..15)
+    uint32_t dig[N][2][5];                                // per half 33 signed digits, packed 4 bits each as d + 8 (0..15)
+    uint32_t negs[N];                                     // bit 0 / 1: the first / second half is negative
 #pragma unroll 1
     for (int i = 0; i < n; i++) {
         if (t[i].inf) continue;
         if (!t[i].fixed) plonk_msm_table(tab[i], t[i]);
-        uint32_t carry = 0;
-#pragma unroll 1
-        for (int w = 0; w < 8; w++) {
-            uint32_t out = 0;
-#pragma unroll 1
-            for (int j = 0; j < 8; j++) {
-                uint32_t d = ((t[i].k[w] >> (4 * j)) & 15u) + carry;          // 0 .. 16
-                carry = d >= 8u ? 1u : 0u;
-                out |= ((d + 8u) & 15u) << (4 * j);                            // d - 16 * carry + 8
-            }
-            dig[i][w] = out;
-        }
+        uint32_t m1[5], m2[5], n1, n2;
+        glv_split(t[i].k, m1, n1, m2, n2);
+        glv_digits(m1, dig[i][0]); glv_digits(m2, dig[i][1]);
+        negs[i] = n1 | (n2 << 1);
     }
     // The per-proof tables become affine with ONE inversion for the whole multi-scalar multiplication (Montgomery's trick over the
-    // seven Z of 2P..8P of every proof point: 7 multiplications per entry), so that all 64 additions of a term are mixed additions
-    // (11 instead of 16 multiplications).  Entries are never infinity: G1 has prime order.
+    // seven Z of 2P..8P of every proof point: 7 multiplications per entry), so that all additions of a term are mixed additions
+    // (11 instead of 16 multiplications).  Entries are never infinity: G1 has prime order.  z then holds beta * x.
     {
+        const Fp beta = ZKV_GLV_BETA;
         Fp pre[N][7];
         Fp run = fp_one();
 #pragma unroll 1
@@ -264,30 +322,36 @@ template <int N> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&t)[N], i
                 const Fp zi2 = fp_sqr(zi);
                 tab[i].m[m].x = fp_mul(tab[i].m[m].x, zi2);
                 tab[i].m[m].y = fp_mul(tab[i].m[m].y, fp_mul(zi2, zi));
+                tab[i].m[m].z = fp_mul(tab[i].m[m].x, beta);
             }
+            tab[i].m[0].z = fp_mul(tab[i].m[0].x, beta);
         }
     }
     G1J acc = g1j_infinity();
 #pragma unroll 1
-    for (int win = 63; win >= 0; win--) {
+    for (int win = 32; win >= 0; win--) {
         acc = g1j_dbl(g1j_dbl(g1j_dbl(g1j_dbl(acc))));
 #pragma unroll 1
         for (int i = 0; i < n; i++) {
             if (t[i].inf) continue;
-            const int d = (int)((dig[i][win >> 3] >> (4 * (win & 7))) & 15u) - 8;       // -8 .. 7
-            if (d == 0) continue;
-            const int m = (d < 0 ? -d : d) - 1;
-            G1A e;
-            if (t[i].fixed) e = t[i].fixed[m];                   // wave-uniform: the same term index in every lane
-            else { e.x = tab[i].m[m].x; e.y = tab[i].m[m].y; }
-            acc = g1j_add_affine(acc, e.x, d < 0 ? fp_neg(e.y) : e.y);
+#pragma unroll 1
+            for (int h = 0; h < 2; h++) {
+                const int d = (int)((dig[i][h][win >> 3] >> (4 * (win & 7))) & 15u) - 8;       // -8 .. 7
+                if (d == 0) continue;
+                const int m = (d < 0 ? -d : d) - 1;
+                Fp ex, ey;
+                if (t[i].fixed) { ex = h ? t[i].fixed_bx[m] : t[i].fixed[m].x; ey = t[i].fixed[m].y; }    // wave-uniform: the same term index in every lane
+                else { ex = h ? tab[i].m[m].z : tab[i].m[m].x; ey = tab[i].m[m].y; }
+                const bool neg = (d < 0) != (((negs[i] >> h) & 1u) != 0);
+                acc = g1j_add_affine(acc, ex, neg ? fp_neg(ey) : ey);
+            }
         }
     }
     return g1j_add(acc, start);
 }
-ZKV_HD void plonk_term(MsmTerm& t, const G1A& p, uint32_t inf, const Fr& k) { t.x = p.x; t.y = p.y; t.inf = inf; t.fixed = nullptr; fr_to_raw(t.k, k); }
+ZKV_HD void plonk_term(MsmTerm& t, const G1A& p, uint32_t inf, const Fr& k) { t.x = p.x; t.y = p.y; t.inf = inf; t.fixed = nullptr; t.fixed_bx = nullptr; fr_to_raw(t.k, k); }
 ZKV_HD void plonk_key_term(MsmTerm& t, const PlonkKey& key, int p, const Fr& k) {      // a key point (or PK_GEN): table from the context
-    t.x = key.mult[p][0].x; t.y = key.mult[p][0].y; t.inf = key.mult_inf[p][0]; t.fixed = key.mult[p]; fr_to_raw(t.k, k);
+    t.x = key.mult[p][0].x; t.y = key.mult[p][0].y; t.inf = key.mult_inf[p][0]; t.fixed = key.mult[p]; t.fixed_bx = key.mult_bx[p]; fr_to_raw(t.k, k);
 }
 // affine form + canonical coordinates for the transcripts
 struct G1Bytes { uint32_t x[8], y[8]; };

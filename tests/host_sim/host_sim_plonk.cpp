@@ -44,6 +44,14 @@ void hsp_fr_mulmod(const uint8_t* a, const uint8_t* b, uint8_t* out) {
     fr_to_raw(r, fr_mul(fr_from_raw_reduce(x), fr_from_raw_reduce(y)));
     wr_be(out, r);
 }
+// GLV split of a canonical scalar (zkv_plonk.h glv_split): out = |k1| (5 words), sign, |k2| (5 words), sign, little-endian words
+void hsp_glv_split(const uint8_t* k32, uint32_t* out12) {
+    uint32_t k[8], m1[5], m2[5], n1, n2;
+    host::be_to_limbs(k, k32);
+    glv_split(k, m1, n1, m2, n2);
+    for (int i = 0; i < 5; i++) { out12[i] = m1[i]; out12[6 + i] = m2[i]; }
+    out12[5] = n1; out12[11] = n2;
+}
 void hsp_fr_inv(const uint8_t* a, uint8_t* out) {
     uint32_t x[8], r[8];
     host::be_to_limbs(x, a);

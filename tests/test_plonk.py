@@ -42,6 +42,27 @@ def hsp():
 
 
 # ---------------------------------------------------------------- CPU
+def test_glv_split_of_the_msm_scalars(hsp):
+    """k = k1 + k2 lambda (mod r) with both halves below 2^128 (33 signed 4-bit windows cover 2^131): the split the multi-scalar
+    multiplications of k_plonk_prep use, on edge and random scalars; lambda acts on G1 as (x, y) -> (beta x, y) (spec model)."""
+    import random
+    import spec_model as sm
+    lam = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23
+    beta = 0x30644e72e131a0295e6dd9e7e0acccb0c28f069fbb966e3de4bd44e5607cfd48
+    g = sm.g1_mul((1, 2), 0xC0FFEE)
+    assert sm.g1_mul(g, lam) == (beta * g[0] % sm.P, g[1])
+    rng = random.Random(0x61F)
+    ks = [0, 1, 2, sm.R - 1, sm.R - 2, lam, lam + 1, lam - 1, sm.R // 2, 1 << 253, (1 << 128) - 1, 1 << 128, (1 << 127) + 5]
+    ks += [rng.randrange(sm.R) for _ in range(3000)] + [rng.randrange(1 << b) for b in (64, 127, 129, 190) for _ in range(50)]
+    for k in ks:
+        out = (C.c_uint32 * 12)()
+        hsp.hsp_glv_split(k.to_bytes(32, 'big'), out)
+        m1 = sum(out[i] << (32 * i) for i in range(5)); m2 = sum(out[6 + i] << (32 * i) for i in range(5))
+        k1 = -m1 if out[5] else m1; k2 = -m2 if out[11] else m2
+        assert (k1 + k2 * lam - k) % sm.R == 0, hex(k)
+        assert m1 < 1 << 128 and m2 < 1 << 128, hex(k)
+
+
 def test_c_oracle_equals_the_golden_statuses(cases):
     vk, vh = H(cases['vk']), H(cases['verifier_hash'])
     for c in cases['cases']:
