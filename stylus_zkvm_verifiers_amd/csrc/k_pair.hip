@@ -75,59 +75,74 @@ ZKV_HD bool pair_all(bool mine) {          // AND over the two lanes of a pair
     v |= zkv_partner_u32(v);
     return v == 0;
 }
-__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing2(size_t n, uint32_t k, const uint8_t* __restrict__ in, Workspace ws,
-                                                           uint8_t* __restrict__ result, uint8_t* __restrict__ ok) {
+// One launch per pair index j (k launches: pair j of every call is validated, run through the Miller loop and multiplied into the
+// call's F slot; ok[] collects the verdict on the inputs), then the final exponentiation of the valid calls.  (As one kernel with
+// the pair loop inside, the inlined stages pushed the register allocator to 217 spilled VGPRs and an 880-byte scratch frame.)
+__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_pair(size_t n, uint32_t k, uint32_t j, const uint8_t* __restrict__ in, Workspace ws,
+                                                               uint8_t* __restrict__ ok) {
     __shared__ uint32_t lds[(48 + 24) * ZKV_BLOCK];
     size_t i = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
     if (i >= n) return;
     const uint32_t par = threadIdx.x & 1u;
-    const uint8_t* base = in + (size_t)192 * k * i;
     LRef fm = l_ref(lds + threadIdx.x);
     LRef tm = l_ref(lds + 48 * ZKV_BLOCK + threadIdx.x);
-    const uint32_t st = (uint32_t)ws.cap;
-    MRef P = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, st, 16);
-    MRef E = m_ref(ws.fe + (size_t)(8 * par) * ws.cap + i, st, 16);
-    SoaRef norm = {ws.norm + i, ws.cap};
-    SoaRef bsrc = {ws.prep + (size_t)(32 + 8 * par) * ws.cap + i, ws.cap};
-    f12m_set_one(P);
-    bool good = true;
-#pragma unroll 1
-    for (uint32_t j = 0; j < k; j++) {
-        const uint8_t* p = base + 192 * j;
-        uint32_t gx[8], gy[8], qxw[8], qyw[8];
-        load_be256(gx, p); load_be256(gy, p + 32);
-        load_be256(qxw, p + 64 + 32 * (1 - par));               // wire order (imaginary, real): the even lane takes the real parts
-        load_be256(qyw, p + 128 + 32 * (1 - par));
-        bool okj = raw_lt_p(gx) && raw_lt_p(gy);
-        okj = pair_all(okj && raw_lt_p(qxw) && raw_lt_p(qyw));
-        const bool pinf = raw_is_zero(gx) && raw_is_zero(gy);
-        const bool qinf = pair_all(raw_is_zero(qxw) && raw_is_zero(qyw));
-        Fp px = fp_zero(), py = fp_zero();
-        if (okj && !pinf) { px = fp_from_raw(gx); py = fp_from_raw(gy); okj = g1_on_curve(px, py); }
-        if (okj && !qinf) {
-            Fp2 qx, qy; qx.h = fp_from_raw(qxw); qy.h = fp_from_raw(qyw);
-            okj = g2_on_twist(qx, qy);
-            if (okj) {
-                // the Miller loop is the subgroup test of Q as well; for P = infinity only the point is stepped (no line products)
-                const Fp iy = pinf ? fp_zero() : fp_inv(py);
-                ws_st(ws.norm, ws.cap, 0, i, fp_mul(px, iy)); ws_st(ws.norm, ws.cap, 8, i, iy);            // both lanes store the same words
-                ws_st(ws.prep, ws.cap, 32 + 8 * (int)par, i, qx.h); ws_st(ws.prep, ws.cap, 48 + 8 * (int)par, i, qy.h);
-                okj = miller_loop_p((const VkTables*)nullptr, pinf ? (uint32_t)FL_A_INF : 0u, norm, bsrc, fm, tm, true);
-                if (okj && !pinf) f12m_mul_body(P, P, fm, false);
-            }
+    MRef P = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, (uint32_t)ws.cap, 16);
+    if (j == 0) { f12m_set_one(P); if (!par) ok[i] = 1; }
+    else if (!ok[i]) return;                                    // an earlier pair of this call was invalid (both lanes read the same byte)
+    const uint8_t* p = in + (size_t)192 * ((size_t)k * i + j);
+    uint32_t gx[8], gy[8], qxw[8], qyw[8];
+    load_be256(gx, p); load_be256(gy, p + 32);
+    load_be256(qxw, p + 64 + 32 * (1 - par));                   // wire order (imaginary, real): the even lane takes the real parts
+    load_be256(qyw, p + 128 + 32 * (1 - par));
+    bool okj = raw_lt_p(gx) && raw_lt_p(gy);
+    okj = pair_all(okj && raw_lt_p(qxw) && raw_lt_p(qyw));
+    const bool pinf = raw_is_zero(gx) && raw_is_zero(gy);
+    const bool qinf = pair_all(raw_is_zero(qxw) && raw_is_zero(qyw));
+    Fp px = fp_zero(), py = fp_zero();
+    if (okj && !pinf) { px = fp_from_raw(gx); py = fp_from_raw(gy); okj = g1_on_curve(px, py); }
+    bool run = false;
+    if (okj && !qinf) {
+        Fp2 qx, qy; qx.h = fp_from_raw(qxw); qy.h = fp_from_raw(qyw);
+        okj = g2_on_twist(qx, qy);
+        if (okj) {
+            const Fp iy = pinf ? fp_zero() : fp_inv(py);
+            ws_st(ws.norm, ws.cap, 0, i, fp_mul(px, iy)); ws_st(ws.norm, ws.cap, 8, i, iy);            // both lanes store the same words
+            ws_st(ws.prep, ws.cap, 32 + 8 * (int)par, i, qx.h); ws_st(ws.prep, ws.cap, 48 + 8 * (int)par, i, qy.h);
+            run = true;
         }
-        if (!okj) { good = false; break; }
     }
-    uint8_t res = 0;
-    if (good) {
+    if (run) {
+        // the Miller loop is the subgroup test of Q as well; for P = infinity only the point is stepped (no line products)
+        SoaRef norm = {ws.norm + i, ws.cap};
+        SoaRef bsrc = {ws.prep + (size_t)(32 + 8 * par) * ws.cap + i, ws.cap};
+        okj = miller_loop_p((const VkTables*)nullptr, pinf ? (uint32_t)FL_A_INF : 0u, norm, bsrc, fm, tm, true);
+        if (okj && !pinf) f12m_mul_body(P, P, fm, false);
+    }
+    if (!okj && !par) ok[i] = 0;
+}
+__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_finalexp(size_t n, Workspace ws, const uint8_t* __restrict__ ok, uint8_t* __restrict__ result,
+                                                                   uint32_t empty) {
+    __shared__ uint32_t lds[48 * ZKV_BLOCK];
+    size_t i = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
+    if (i >= n) return;
+    const uint32_t par = threadIdx.x & 1u;
+    uint8_t res = empty ? 1 : 0;                                 // k = 0: the empty product is 1
+    if (ok[i] && !empty) {
+        const uint32_t st = (uint32_t)ws.cap;
+        LRef acc = l_ref(lds + threadIdx.x);
+        MRef P = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, st, 16);
+        MRef E = m_ref(ws.fe + (size_t)(8 * par) * ws.cap + i, st, 16);
         MRef accm = m_ref(lds + threadIdx.x, 64, 8);
-        res = final_exp_prog_p(P, E, fm, accm) ? 1 : 0;
+        res = final_exp_prog_p(P, E, acc, accm) ? 1 : 0;
     }
-    if (!par) { result[i] = res; ok[i] = good ? 1 : 0; }
+    if (!par) result[i] = res;
 }
 void launch_pairing(size_t n, uint32_t k, const uint8_t* in, const Workspace& ws, uint8_t* result, uint8_t* ok, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_pairing2, dim3((unsigned)((2 * n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, k, in, ws, result, ok);
+    const unsigned grid = (unsigned)((2 * n + ZKV_BLOCK - 1) / ZKV_BLOCK);
+    if (k == 0) (void)hipMemsetAsync(ok, 1, n, s);              // the empty product: valid input, result 1 (its F slot is set below)
+    for (uint32_t j = 0; j < k; j++) hipLaunchKernelGGL(k_pairing_pair, dim3(grid), dim3(ZKV_BLOCK), 0, s, n, k, j, in, ws, ok);
+    hipLaunchKernelGGL(k_pairing_finalexp, dim3(grid), dim3(ZKV_BLOCK), 0, s, n, ws, ok, result, k == 0 ? 1u : 0u);
 }
 
 static inline unsigned pair_grid(size_t n) { return (unsigned)((2 * n + ZKV_BLOCK - 1) / ZKV_BLOCK); }
