@@ -1,6 +1,6 @@
 // Small-batch variants of the Miller loop and the final exponentiation: ONE PROOF PER 16 LANES (four proofs per
 // wavefront), the six Fp2 coefficients of every Fp12 value spread over six lane pairs (csrc/zkv_tower_wide.h).  Selected
-// by the C ABI for chunks of at most ZKV_WIDE_BELOW proofs (default 12,288), where the lane-pair kernels cannot fill the
+// by the C ABI for chunks of at most ZKV_WIDE_BELOW proofs (default 8,192), where the lane-pair kernels cannot fill the
 // chip anyway: the answer is the same, a proof just finishes sooner.
 #define ZKV_PAIRED 1
 #include "zkv_internal.h"

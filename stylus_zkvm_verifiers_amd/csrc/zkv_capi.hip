@@ -75,13 +75,14 @@ static size_t chunk_capacity() {
     return (c + 63) & ~(size_t)63;
 }
 
-// Chunks of at most this many proofs take the coefficient-parallel kernels (one proof per 16 lanes).  Measured: 5.3-5.6 ms
-// against 11.6 ms up to 4,096 proofs (one wavefront per SIMD), 7.7 against 11.7 ms at 8,192, 10.8 against 11.9 ms at 12,288,
-// 13.2 against 11.9 ms at 16,384: above the threshold the lane-pair kernels win because they do a third of the work per proof.
+// Chunks of at most this many proofs take the coefficient-parallel kernels (one proof per 16 lanes).  Measured (RISC Zero,
+// tools/small_batch_sweep.sh, profiles/round2_e_small_batch_sweep.txt): 4.1-4.4 ms against 8.4 ms up to 4,096 proofs (one wavefront per
+// SIMD), 6.2 against 8.5 ms at 8,192 (two), 8.6 against 8.6 ms at 10,240 and 9.0 against 8.6 ms at 12,288 (a second round of
+// wavefronts): above 8,192 the lane-pair kernels win because they do a third of the work per proof.
 // ZKV_WIDE_BELOW=0 disables the 16-lane kernels.
 static size_t wide_below() {
     const char* e = getenv("ZKV_WIDE_BELOW");
-    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)12288;
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)8192;
 }
 
 static bool device_is_gfx950(int dev) {
