@@ -235,7 +235,32 @@ Fp fp_mul(Fp a, Fp b) {   // by value: 16 VGPRs in, 8 out, no scratch traffic at
     fp_mac81(col, x, y);
     return fp_reduce_cols(col);
 }
-ZKV_HD Fp fp_sqr(const Fp& a) { return fp_mul(a, a); }
+// a^2: the 36 cross products once, against doubled limbs (45 instead of 81 column terms; one unpack).  Used by the one-value-per-lane
+// code (point doublings and additions of k_msm and the PLONK stage); the lane-pair Fp2 squaring multiplies two different values.
+#if defined(ZKV_FP_MUL_NOINLINE)
+ZKV_HD_NI
+#else
+ZKV_HD
+#endif
+Fp fp_sqr(Fp a) {
+#if defined(ZKV_COUNT_FP_MUL)
+    zkv_fp_mul_counter++;
+#endif
+    uint32_t x[9], d[9];
+    fp_unpack29(a, x);
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = x[i] << 1;            // < 2^30: a column holds at most 4 terms below 2^59 and one below 2^58
+    uint64_t col[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) col[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        col[2 * i] += (uint64_t)x[i] * x[i];
+#pragma unroll
+        for (int j = i + 1; j < 9; j++) col[i + j] += (uint64_t)d[i] * x[j];
+    }
+    return fp_reduce_cols(col);
+}
 
 ZKV_HD Fp fp_from_raw(const uint32_t* limbs) {        // canonical value < p -> Montgomery form
     Fp t, r2 = ZKV_FP_R2;

@@ -295,6 +295,13 @@ int hs_fp_inv(const uint8_t* a32, int loose, uint8_t* out32) {
     for (int i = 0; i < 8; i++) same &= r[i] == r2[i];
     return same;
 }
+// fp_sqr against fp_mul(a, a) on ANY 256-bit operand (the multipliers accept lazy sums): 1 when the residues agree and stay below 2p
+int hs_fp_sqr_check(const uint8_t* a32) {
+    Fp a; load_be256(a.v, a32);
+    const uint32_t P2[8] = ZKV_FP_2P_LIMBS;
+    const Fp s = fp_sqr(a), m = fp_mul(a, a);
+    return fp_eq(s, m) && !u256_geq(s.v, P2);
+}
 int hs_g2_in_subgroup(const uint8_t* q128) {     // EIP-197 order: x_im x_re y_im y_re; must be on twist
     uint32_t w[4][8];
     for (int k = 0; k < 4; k++) load_be256(w[k], q128 + 32 * k);

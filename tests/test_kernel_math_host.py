@@ -49,6 +49,16 @@ def test_fp_mul_matches_bigint(hs):
         assert int.from_bytes(o.raw, 'big') == a * b % m.P
 
 
+def test_fp_sqr_matches_fp_mul_on_any_operand(hs):
+    """The dedicated squaring (45 column terms against doubled limbs) against the general multiplier, for reduced values, lazy sums up
+    to 4p, and arbitrary 256-bit words (top limb of 24 bits)."""
+    rng = random.Random(0x5C2)
+    vals = [0, 1, m.P - 1, m.P, 2 * m.P - 1, 4 * m.P - 1, (1 << 256) - 1, (1 << 255), (1 << 232) - 1, int('5' * 64, 16), int('a' * 64, 16)]
+    vals += [rng.randrange(1 << 256) for _ in range(300)] + [rng.randrange(4 * m.P) for _ in range(300)]
+    for a in vals:
+        assert hs.hs_fp_sqr_check(a.to_bytes(32, 'big')) == 1, hex(a)
+
+
 def test_fp_inv_by_division_steps(hs):
     """fp_inv (csrc/zkv_modinv.h: Bernstein-Yang division steps, 20 batches of 30 on signed 30-bit limbs) against Python's pow and
     against the Fermat chain it replaced, on edge values, both representations of the loose range, and random values; inv(0) = 0."""
