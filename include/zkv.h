@@ -273,7 +273,8 @@ int zkv_ctx_reserve(zkv_ctx* ctx, size_t n);
 /* Blocks until everything enqueued on the context's stream has finished. */
 int zkv_ctx_synchronize(zkv_ctx* ctx);
 /* HIP-event durations (ms) of the stages of the most recent batch chunk on this context:
- * [0] prep (parse + SHA-256 + point validation)  [1] vk_x MSM + normalisation  [2] G2 subgroup check
+ * [0] prep (parse + SHA-256 + point validation)  [1] vk_x MSM + normalisation  [2] G2 subgroup check (a stage of its own only when
+ * the 16-lane kernels run in line; the lane-pair Miller loop is the subgroup test itself, and the time is then ~0)
  * [3] Miller loop  [4] final exponentiation.  Synchronises the context. */
 int zkv_ctx_last_stage_ms(zkv_ctx* ctx, float out_ms[5]);
 /* Revert bytes of a status exactly as the reference ABI-encodes its errors (common/errors.rs:18-27,

@@ -819,14 +819,15 @@ def test_last_small_chunk_switches_kernels_inside_one_batch(zkv, real_proofs):
     assert len(set(st[16384:])) >= 2                             # the remainder holds accepted and rejected proofs
 
 
-def test_small_order_g2_points_through_the_pairing_kernels(zkv, r0, sp1, precompile_kats, real_proofs):
-    """The 14 G2 known-answer points (in-subgroup, random twist points, points with components of order 10069 and 5864401) go
+def test_small_order_g2_points_through_the_pairing_kernels(zkv, r0, sp1, precompile_kats, g2_membership_points, real_proofs):
+    """The 14 + 36 G2 known-answer points (in-subgroup, random twist points, points of exact order 10069 / 5864401 / their product,
+    G2 points with such a component, cofactor-only points) go
     through the GPU's subgroup checks where the reference would meet them (the ecPairing call, groth16.rs:121-125): as the G2 input of
     `zkv_bn254_pairing_batch` (`ok` = the precompile succeeds) and as `B` of a RISC Zero seal and of an SP1 proof (lane-pair kernels
     k_g2chk2 / k_miller2, and the 16-lane kernels for this small batch).  Expected: the fixture's flags, the C oracle, and the
     oracle's verifiers."""
     import oracle_lib as ol
-    pts = precompile_kats['g2_subgroup']
+    pts = precompile_kats['g2_subgroup'] + [dict(point=c['point'], on_twist=True, in_subgroup=c['in_subgroup']) for c in g2_membership_points]
     G1 = (1).to_bytes(32, 'big') + (2).to_bytes(32, 'big')
     calls = [G1 + H(''.join(c['point'])) for c in pts]
     pc = zkv.Bn254Precompiles()
