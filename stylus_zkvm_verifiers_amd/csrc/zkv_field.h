@@ -507,44 +507,38 @@ ZKV_HD Fp2 f2_mul(const Fp2& a, const Fp2& b) { Fp2 r; r.h = f2_mul_lane(a.h, b.
 // sums here): a column then holds at most 18 products below 2^58, 18 below 2^59 (the 8p - x limbs are below 2^30) and the 9
 // reduction terms below 2^58 -- 63 * 2^58 < 2^64 -- and the value stays below 40 p^2 < 169 p^2.  Used where two products are only
 // ever added (the sparse fixed-line products of the Miller loop): 405 multiplies and one reduce / pack set instead of 486 and two.
-// The device leaf is f2_dot2_lds (zkv_tower_mem.h): four Fp structs do not fit the 16 argument registers the ABI grants aggregates -- a
-// first version with four by-value operands had two of them written to and read back from scratch memory at every call, 8.6 GB per
-// 2^20-proof launch -- so the leaf takes the two line coefficients by value and reads the two accumulator coefficients from LDS itself.
-ZKV_HD Fp f2_dot2_body(const Fp& my_a, const Fp& my_b, const Fp& my_c, const Fp& my_d) {
+// (History: a leaf taking four Fp by value had two of them passed through scratch memory -- the ABI grants aggregates 16 argument
+// registers -- 8.6 GB per 2^20-proof launch; a leaf reading two operands from LDS fixed that; the form below replaced both.)
+// Operands arrive unpacked and exchanged, for callers that use every operand several times:
+//   multiplicand form (f2_limbs_x): this lane's nine limbs and the partner's;
+//   multiplier form   (f2_limbs_y): U = the even lane's component in both lanes, V = the odd lane's (8p - it in the even lane).
+ZKV_HD void f2_limbs_x(const Fp& v, uint32_t (&own)[9], uint32_t (&par)[9]) {
+    fp_unpack29(v, own);
+#pragma unroll
+    for (int i = 0; i < 9; i++) par[i] = zkv_partner_u32(own[i]);
+}
+ZKV_HD void f2_limbs_y(const Fp& v, uint32_t (&U)[9], uint32_t (&V)[9]) {
+    const uint32_t FAT[9] = ZKV_FP_FAT8P_LIMBS;
+    uint32_t y[9];
+    fp_unpack29(v, y);
+#pragma unroll
+    for (int i = 0; i < 9; i++) { U[i] = zkv_pair_even_u32(y[i]); V[i] = zkv_pair_odd_u32(y[i]); }
+    if (zkv_parity() == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) V[i] = FAT[i] - V[i];
+    }
+}
+ZKV_HD Fp f2_dot2_limbs(const uint32_t (&ao)[9], const uint32_t (&ap)[9], const uint32_t (&bU)[9], const uint32_t (&bV)[9],
+                        const uint32_t (&co)[9], const uint32_t (&cp)[9], const uint32_t (&dU)[9], const uint32_t (&dV)[9]) {
 #if defined(ZKV_COUNT_FP_MUL)
     zkv_fp_mul_counter += 4;
 #endif
-    const uint32_t FAT[9] = ZKV_FP_FAT8P_LIMBS;
-    const bool odd = zkv_parity() != 0;
     uint64_t col[18];
 #pragma unroll
     for (int k = 0; k < 18; k++) col[k] = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#define ZKV_DOT2_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define ZKV_DOT2_FENCE() do {} while (0)
-#endif
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        uint32_t xa[9], yb[9], W[9];
-        fp_unpack29(t ? my_c : my_a, xa); fp_unpack29(t ? my_d : my_b, yb);
-#pragma unroll
-        for (int i = 0; i < 9; i++) W[i] = zkv_pair_even_u32(yb[i]);
-        fp_mac81(col, xa, W);                                   // own a (c) times the even lane's b0 (d0)
-        ZKV_DOT2_FENCE();
-#pragma unroll
-        for (int i = 0; i < 9; i++) { xa[i] = zkv_partner_u32(xa[i]); W[i] = zkv_pair_odd_u32(yb[i]); }
-        if (!odd) {
-#pragma unroll
-            for (int i = 0; i < 9; i++) W[i] = FAT[i] - W[i];
-        }
-        fp_mac81(col, xa, W);                                   // the partner's a (c) times b1 (d1), negated in the even lane
-        ZKV_DOT2_FENCE();
-    }
-#undef ZKV_DOT2_FENCE
+    fp_mac81(col, ao, bU); fp_mac81(col, ap, bV); fp_mac81(col, co, dU); fp_mac81(col, cp, dV);
     return fp_reduce_cols(col);
 }
-ZKV_HD Fp2 f2_dot2(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) { Fp2 r; r.h = f2_dot2_body(a.h, b.h, c.h, d.h); return r; }
 ZKV_HD Fp2 f2_sqr(const Fp2& a) {           // reduced (< 2p) input: even lane (a0+a1)(a0-a1), odd lane (2 a1) a0
     const bool odd = zkv_parity() != 0;
     Fp o = zkv_partner(a.h);

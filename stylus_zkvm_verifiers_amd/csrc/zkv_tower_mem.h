@@ -44,31 +44,6 @@ struct LRef {
 };
 ZKV_HD LRef l_ref(uint32_t* lds_base_plus_lane) { LRef r; r.p = (zkv_lds_u32*)lds_base_plus_lane; return r; }
 
-#if defined(ZKV_PAIRED)
-// a b + c d (one lane's component, f2_dot2_body) for coefficients ia and ic of the slot f.
-template <class RF> ZKV_HD Fp2 f12m_dot2(RF f, int ia, const Fp2& b, int ic, const Fp2& d) {
-    Fp a, c;
-#pragma unroll
-    for (int k = 0; k < 8; k++) { a.v[k] = f.ld(f.fw() * ia + k); c.v[k] = f.ld(f.fw() * ic + k); }
-    Fp2 r; r.h = f2_dot2_body(a, b.h, c, d.h);
-    return r;
-}
-#if defined(ZKV_FP_MUL_NOINLINE) && defined(__HIP_DEVICE_COMPILE__)
-// LDS slots on the device: a non-inlined leaf like f2_mul_lane; the two by-value operands fill the 16 aggregate argument registers,
-// the two coefficients of f arrive as LDS addresses.
-__device__ __noinline__ inline Fp f2_dot2_lds(Fp my_b, Fp my_d, zkv_lds_u32* pa, zkv_lds_u32* pc) {
-    Fp a, c;
-#pragma unroll
-    for (int k = 0; k < 8; k++) { a.v[k] = pa[k * 64]; c.v[k] = pc[k * 64]; }
-    return f2_dot2_body(a, my_b, c, my_d);
-}
-ZKV_HD Fp2 f12m_dot2(LRef f, int ia, const Fp2& b, int ic, const Fp2& d) {
-    Fp2 r; r.h = f2_dot2_lds(b.h, d.h, f.p + 64 * 8 * ia, f.p + 64 * 8 * ic);
-    return r;
-}
-#endif
-#endif
-
 template <class R> ZKV_HD Fp m_ld_fp(R m, int word0) {
     Fp r;
 #pragma unroll
@@ -158,6 +133,8 @@ template <class RD, class RA, class RB> ZKV_HD void f12m_mul_body(RD d, RA a, RB
 template <class RD, class RA, class RB> ZKV_HD_NI void f12m_mul(RD d, RA a, RB b) { f12m_mul_body(d, a, b, false); }
 template <class RD, class RA, class RB> ZKV_HD_NI void f12m_mul_conj(RD d, RA a, RB b) { f12m_mul_body(d, a, b, true); }
 // f <- f * (c0 + (c3 + c4 v) w)
+// (The thirteen products inlined with c0 and c4 -- or all four multipliers -- unpacked and exchanged once were measured: 112.3 and
+// 115.9 against 112.5 ms for k_miller2; 36 / 92 spilled VGPRs eat the 460-590 instructions saved per product.  Not kept.)
 template <class RF> ZKV_HD void f12m_mul_by_034_body(RF f, const Fp2& c0, const Fp2& c3, const Fp2& c4) {
     Fp6 g = m_ld_f6(f, 0), h = m_ld_f6(f, 3);
     Fp6 t0 = f6_mul_fp2(g, c0);
@@ -171,19 +148,35 @@ template <class RF> ZKV_HD_NI void f12m_mul_by_034(RF f, const Fp2* c0, const Fp
 #if defined(ZKV_PAIRED)
 // With l = c3 + c4 v:  g' = g + v (h l),  h' = h + g l.  Written out per coefficient every output is its input plus a sum of TWO
 // products -- g'0 = g0 + h1 (xi c4) + h2 (xi c3), g'1 = g1 + h0 c3 + h2 (xi c4), g'2 = g2 + h0 c4 + h1 c3, and the same for h' with
-// g in place of h and no wrap for h'0: h'0 = h0 + g0 c3 + g2 (xi c4) -- so the six outputs are six fused two-product sums (f2_dot2: one
-// reduction each) instead of ten products with Karatsuba's additions: the same 2,430 multiplies per lane, but 6 instead of 10
-// reduce / pack sets and 8 instead of 24 modular additions and xi-multiplications.
+// g in place of h and no wrap for h'0: h'0 = h0 + g0 c3 + g2 (xi c4) -- so the six outputs are six fused two-product sums (one
+// reduction each, f2_dot2_limbs) instead of ten products with Karatsuba's additions: the same 2,430 multiplies per lane, but 6 instead
+// of 10 reduce / pack sets and 8 instead of 24 modular additions and xi-multiplications (k_miller2 124.2 -> 117.7 ms as six calls of a
+// leaf that read its two coefficients of f from LDS).  And every operand is unpacked and exchanged ONCE: the four line coefficients
+// (c3, xi c3, c4, xi c4) enter five or six of the twelve products each and every coefficient of f two, so the per-product form spent
+// 500 of its 4,700 instructions unpacking and exchanging values it had already seen; inlined into the caller's loop body
+// (117.7 -> 112.5 ms).
 template <class RF> ZKV_HD void f12m_mul_by_134_body(RF f, const Fp2& c3, const Fp2& c4) {
-    const Fp2 x3 = f2_mul_xi(c3), x4 = f2_mul_xi(c4);
-    const Fp2 g0 = m_ld_f2(f, 0), g1 = m_ld_f2(f, 1), g2 = m_ld_f2(f, 2), h0 = m_ld_f2(f, 3), h1 = m_ld_f2(f, 4), h2 = m_ld_f2(f, 5);
-    const Fp2 ng0 = f2_add(g0, f12m_dot2(f, 4, x4, 5, x3));
-    const Fp2 ng1 = f2_add(g1, f12m_dot2(f, 3, c3, 5, x4));
-    const Fp2 ng2 = f2_add(g2, f12m_dot2(f, 3, c4, 4, c3));
-    const Fp2 nh0 = f2_add(h0, f12m_dot2(f, 0, c3, 2, x4));
-    const Fp2 nh1 = f2_add(h1, f12m_dot2(f, 0, c4, 1, c3));
-    const Fp2 nh2 = f2_add(h2, f12m_dot2(f, 1, c4, 2, c3));
-    m_st_f2(f, 0, ng0); m_st_f2(f, 1, ng1); m_st_f2(f, 2, ng2); m_st_f2(f, 3, nh0); m_st_f2(f, 4, nh1); m_st_f2(f, 5, nh2);
+    uint32_t c3U[9], c3V[9], c4U[9], c4V[9], x3U[9], x3V[9], x4U[9], x4V[9];
+    f2_limbs_y(c3.h, c3U, c3V); f2_limbs_y(c4.h, c4U, c4V);
+    { const Fp2 x3 = f2_mul_xi(c3), x4 = f2_mul_xi(c4); f2_limbs_y(x3.h, x3U, x3V); f2_limbs_y(x4.h, x4U, x4V); }
+    Fp ng0, ng1, ng2, nh0, nh1, nh2;
+    {
+        uint32_t h0o[9], h0p[9], h1o[9], h1p[9], h2o[9], h2p[9];
+        f2_limbs_x(m_ld_f2(f, 3).h, h0o, h0p); f2_limbs_x(m_ld_f2(f, 4).h, h1o, h1p); f2_limbs_x(m_ld_f2(f, 5).h, h2o, h2p);
+        ng0 = fp_add(m_ld_f2(f, 0).h, f2_dot2_limbs(h1o, h1p, x4U, x4V, h2o, h2p, x3U, x3V));
+        ng1 = fp_add(m_ld_f2(f, 1).h, f2_dot2_limbs(h0o, h0p, c3U, c3V, h2o, h2p, x4U, x4V));
+        ng2 = fp_add(m_ld_f2(f, 2).h, f2_dot2_limbs(h0o, h0p, c4U, c4V, h1o, h1p, c3U, c3V));
+    }
+    {
+        uint32_t g0o[9], g0p[9], g1o[9], g1p[9], g2o[9], g2p[9];
+        f2_limbs_x(m_ld_f2(f, 0).h, g0o, g0p); f2_limbs_x(m_ld_f2(f, 1).h, g1o, g1p); f2_limbs_x(m_ld_f2(f, 2).h, g2o, g2p);
+        nh0 = fp_add(m_ld_f2(f, 3).h, f2_dot2_limbs(g0o, g0p, c3U, c3V, g2o, g2p, x4U, x4V));
+        nh1 = fp_add(m_ld_f2(f, 4).h, f2_dot2_limbs(g0o, g0p, c4U, c4V, g1o, g1p, c3U, c3V));
+        nh2 = fp_add(m_ld_f2(f, 5).h, f2_dot2_limbs(g1o, g1p, c4U, c4V, g2o, g2p, c3U, c3V));
+    }
+    Fp2 o;
+    o.h = ng0; m_st_f2(f, 0, o); o.h = ng1; m_st_f2(f, 1, o); o.h = ng2; m_st_f2(f, 2, o);
+    o.h = nh0; m_st_f2(f, 3, o); o.h = nh1; m_st_f2(f, 4, o); o.h = nh2; m_st_f2(f, 5, o);
 }
 #else
 // one proof per lane (set-up kernels, host reference, op count of the canonical algorithm): two Karatsuba products by c3 + c4 v
