@@ -67,8 +67,14 @@ __global__ __launch_bounds__(ZKV_BLOCK, ZKV_PLONK_WAVES) void k_plonk_prep(PrepA
     a.status[i] = st;
 }
 
+// one lane per row (point, a) of the joint P / phi(P) tables, after k_plonk_setup has tabulated the multiples
+__global__ __launch_bounds__(64) void k_plonk_joint(PlonkKey* __restrict__ key) {
+    const int t = (int)(blockIdx.x * 64 + threadIdx.x);
+    if (t < (PK_POINTS + 1) * 9) plonk_joint_row(*key, t / 9, t % 9);
+}
 void launch_plonk_setup(const PlonkKeyRaw* d_raw, PlonkKey* d_key, hipStream_t s) {
     hipLaunchKernelGGL(k_plonk_setup, dim3(1), dim3(64), 0, s, d_raw, d_key);
+    hipLaunchKernelGGL(k_plonk_joint, dim3(((PK_POINTS + 1) * 9 + 63) / 64), dim3(64), 0, s, d_key);
 }
 void launch_plonk_prep(const PrepArgs& a, const PlonkKey* d_key, const Workspace& ws, hipStream_t s) {
     if (!a.n) return;

@@ -146,6 +146,8 @@ struct PlonkKey {
                                     // signed-window tables of the FIXED terms of the multi-scalar multiplications
     uint32_t mult_inf[PK_POINTS + 1][8];
     Fp mult_bx[PK_POINTS + 1][8];   // beta * x of the same entries: the tables of phi(P) = (beta x, y) = lambda P (GLV)
+    G1A joint[PK_POINTS + 1][9][17];        // a P + b phi(P), a = 0..8, b = -8..8 (index b + 8), affine: ONE addition per window serves both
+                                    // GLV halves of a fixed term (33 instead of 66 per term); (0, 0) unused.  98 KB per context
 };
 constexpr int PK_GEN = PK_POINTS;
 // A G1 point as the precompiles take it: coordinates < P, on the curve or (0,0) = infinity.  Returns false when invalid.
@@ -187,6 +189,31 @@ ZKV_HD void plonk_setup_key(const PlonkKeyRaw& r, PlonkKey& k) {
     }
 }
 
+// Row a of the joint table of key point p (needs mult / mult_bx of that point): independent per (p, a), one lane each at set-up.
+ZKV_HD void plonk_joint_row(PlonkKey& k, int p, int a) {
+#pragma unroll 1
+    for (int b = -8; b <= 8; b++) {
+        G1A e; e.x = fp_zero(); e.y = fp_zero();
+        if (!k.mult_inf[p][0] && (a || b)) {
+            G1J acc = g1j_infinity();
+            if (a) { acc.x = k.mult[p][a - 1].x; acc.y = k.mult[p][a - 1].y; acc.z = fp_one(); }
+            if (b) {
+                const int m = (b < 0 ? -b : b) - 1;
+                acc = g1j_add_affine(acc, k.mult_bx[p][m], b < 0 ? fp_neg(k.mult[p][m].y) : k.mult[p][m].y);
+            }
+            uint32_t inf; g1j_to_affine(acc, e, inf);       // never infinity: a + b lambda != 0 mod r for |a|, |b| <= 8
+        }
+        k.joint[p][a][b + 8] = e;
+    }
+}
+
+ZKV_HD void plonk_setup_joint(PlonkKey& k) {                // all rows in sequence (host builds; the device runs one lane per row)
+#pragma unroll 1
+    for (int p = 0; p <= PK_POINTS; p++)
+#pragma unroll 1
+        for (int a = 0; a < 9; a++) plonk_joint_row(k, p, a);
+}
+
 // ---------------------------------------------------------------- G1 helpers
 ZKV_HD G1J g1j_add(const G1J& p, const G1J& q) {             // complete Jacobian + Jacobian
     if (fp_is_zero(p.z)) return q;
@@ -207,8 +234,7 @@ ZKV_HD G1J g1j_add(const G1J& p, const G1J& q) {             // complete Jacobia
     return r;
 }
 // One term of a multi-scalar multiplication: an affine point (or infinity) and a canonical 256-bit scalar.
-// fixed / fixed_bx: the key's affine table of 1P..8P and of beta * x of the same entries, or null (table built per proof).
-struct MsmTerm { Fp x, y; uint32_t inf; uint32_t k[8]; const G1A* fixed; const Fp* fixed_bx; };
+struct MsmTerm { Fp x, y; uint32_t inf; uint32_t k[8]; const G1A* fixed; };      // fixed: the key's joint table [9][17] of the point, or null
 
 // ---- GLV: k = k1 + k2 lambda (mod r) with |k1|, |k2| < 2^128, lambda P = phi(P) = (beta x, y).
 // Babai rounding against the basis (a1, -n), (n, b2), n = 2u + 1, a1 = 6u^2 + 2u, b2 = 6u^2 + 4u + 1:  c1 = floor(k g1 / 2^256),
@@ -334,24 +360,25 @@ template <int N> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&t)[N], i
 #pragma unroll 1
         for (int i = 0; i < n; i++) {
             if (t[i].inf) continue;
-#pragma unroll 1
-            for (int h = 0; h < 2; h++) {
-                const int d = (int)((dig[i][h][win >> 3] >> (4 * (win & 7))) & 15u) - 8;       // -8 .. 7
-                if (d == 0) continue;
-                const int m = (d < 0 ? -d : d) - 1;
-                Fp ex, ey;
-                if (t[i].fixed) { ex = h ? t[i].fixed_bx[m] : t[i].fixed[m].x; ey = t[i].fixed[m].y; }    // wave-uniform: the same term index in every lane
-                else { ex = h ? tab[i].m[m].z : tab[i].m[m].x; ey = tab[i].m[m].y; }
-                const bool neg = (d < 0) != (((negs[i] >> h) & 1u) != 0);
-                acc = g1j_add_affine(acc, ex, neg ? fp_neg(ey) : ey);
+            const int d1 = (int)((dig[i][0][win >> 3] >> (4 * (win & 7))) & 15u) - 8;      // -8 .. 7, magnitudes' digits
+            const int d2 = (int)((dig[i][1][win >> 3] >> (4 * (win & 7))) & 15u) - 8;
+            const int e1 = (negs[i] & 1u) ? -d1 : d1, e2 = (negs[i] & 2u) ? -d2 : d2;         // digits of k1 and k2
+            if (t[i].fixed) {                                    // wave-uniform: the same term index in every lane
+                if (e1 == 0 && e2 == 0) continue;
+                const bool flip = e1 < 0;                        // -(|e1| P + (-e2) phi P)
+                const G1A e = t[i].fixed[(flip ? -e1 : e1) * 17 + (flip ? -e2 : e2) + 8];
+                acc = g1j_add_affine(acc, e.x, flip ? fp_neg(e.y) : e.y);
+                continue;
             }
+            if (e1) { const int m = (e1 < 0 ? -e1 : e1) - 1; acc = g1j_add_affine(acc, tab[i].m[m].x, e1 < 0 ? fp_neg(tab[i].m[m].y) : tab[i].m[m].y); }
+            if (e2) { const int m = (e2 < 0 ? -e2 : e2) - 1; acc = g1j_add_affine(acc, tab[i].m[m].z, e2 < 0 ? fp_neg(tab[i].m[m].y) : tab[i].m[m].y); }
         }
     }
     return g1j_add(acc, start);
 }
-ZKV_HD void plonk_term(MsmTerm& t, const G1A& p, uint32_t inf, const Fr& k) { t.x = p.x; t.y = p.y; t.inf = inf; t.fixed = nullptr; t.fixed_bx = nullptr; fr_to_raw(t.k, k); }
+ZKV_HD void plonk_term(MsmTerm& t, const G1A& p, uint32_t inf, const Fr& k) { t.x = p.x; t.y = p.y; t.inf = inf; t.fixed = nullptr; fr_to_raw(t.k, k); }
 ZKV_HD void plonk_key_term(MsmTerm& t, const PlonkKey& key, int p, const Fr& k) {      // a key point (or PK_GEN): table from the context
-    t.x = key.mult[p][0].x; t.y = key.mult[p][0].y; t.inf = key.mult_inf[p][0]; t.fixed = key.mult[p]; t.fixed_bx = key.mult_bx[p]; fr_to_raw(t.k, k);
+    t.x = key.mult[p][0].x; t.y = key.mult[p][0].y; t.inf = key.mult_inf[p][0]; t.fixed = &key.joint[p][0][0]; fr_to_raw(t.k, k);
 }
 // affine form + canonical coordinates for the transcripts
 struct G1Bytes { uint32_t x[8], y[8]; };
