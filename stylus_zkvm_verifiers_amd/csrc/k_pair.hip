@@ -36,8 +36,8 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller2(size_t n, const VkTabl
     const uint32_t par = threadIdx.x & 1u;
     LRef fm = l_ref(lds + threadIdx.x);
     LRef tm = l_ref(lds + 48 * ZKV_BLOCK + threadIdx.x);
-    SoaRef norm = {ws.norm + i, ws.cap};                                        // Fp values: both lanes of the pair read them
-    SoaRef bsrc = {ws.prep + (size_t)(32 + 8 * par) * ws.cap + i, ws.cap};      // this lane's component of B.x (B.y 16 words on)
+    SoaRef norm = {ws.norm, ws.cap, (uint32_t)i * 4u};                                               // Fp values: both lanes of the pair read them
+    SoaRef bsrc = {ws.prep + 32 * ws.cap, ws.cap, (uint32_t)(8 * par * ws.cap + i) * 4u};             // this lane's component of B.x (B.y 16 words on)
     if (!miller_loop_p(vk, flags, norm, bsrc, fm, tm, true)) {
         if (!par) { ws.g2bad[i] = 1; status[i] = ST_VERIFICATION_FAILED; }
         return;
@@ -113,8 +113,8 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_pair(size_t n, uint32_
     }
     if (run) {
         // the Miller loop is the subgroup test of Q as well; for P = infinity only the point is stepped (no line products)
-        SoaRef norm = {ws.norm + i, ws.cap};
-        SoaRef bsrc = {ws.prep + (size_t)(32 + 8 * par) * ws.cap + i, ws.cap};
+        SoaRef norm = {ws.norm, ws.cap, (uint32_t)i * 4u};
+        SoaRef bsrc = {ws.prep + 32 * ws.cap, ws.cap, (uint32_t)(8 * par * ws.cap + i) * 4u};
         okj = miller_loop_p((const VkTables*)nullptr, pinf ? (uint32_t)FL_A_INF : 0u, norm, bsrc, fm, tm, true);
         if (okj && !pinf) f12m_mul_body(P, P, fm, false);
     }

@@ -279,12 +279,15 @@ ZKV_HD bool miller_loop_m(const VkTables* vkp, uint32_t flags, const G1Norm& n, 
 // for -- the routines need no frame; only fp_mul / f2_mul_lane stay calls (leaf functions inside the caller-saved registers).
 // Per-proof constants (x/y and 1/y of the three G1 points, B) are re-read from their workspace rows where they are used instead of
 // being held in registers across the whole loop.
-struct SoaRef {                         // word k of this proof's (this lane's) value at p[k * stride]
-    const uint32_t* p; size_t stride;
+struct SoaRef {                         // word k of this proof's (this lane's) value at base[k * stride] + lane offset
+    // base and stride are wave-uniform, the lane's part of the address is one 32-bit byte offset: every load is
+    // `global_load_dword v, v_off, s[base]` with the base advanced on the scalar unit.  (With a per-lane 64-bit pointer the compiler
+    // hoisted ten loop-invariant per-lane addresses out of the Miller loop and spilled them: 5.5 GB of scratch reloads per launch.)
+    const uint32_t* p; size_t stride; uint32_t off;
     ZKV_HD Fp fp(int word0) const {
         Fp r;
 #pragma unroll
-        for (int k = 0; k < 8; k++) r.v[k] = p[(size_t)(word0 + k) * stride];
+        for (int k = 0; k < 8; k++) r.v[k] = *(const uint32_t*)((const char*)(p + (size_t)(word0 + k) * stride) + off);
         return r;
     }
 };
@@ -311,6 +314,11 @@ ZKV_HD bool miller_loop_p(const VkTables* vkp, uint32_t flags, SoaRef norm, SoaR
 #pragma unroll 1
     for (int li = 0; li < ZKV_MILLER_STEPS; li++) {
         const int kind = KIND[li];
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the lane offsets are re-read through an opaque move every step: otherwise the 64 per-lane addresses of the step's loads are
+        // hoisted out of the loop as invariants, and ten of them end up in a scratch frame (5.5 GB of reloads per 2^20-proof launch)
+        asm volatile("" : "+v"(norm.off), "+v"(bsrc.off));
+#endif
         if (kind == 0 && li != 0) f12m_sqr_body(fm);
         if (do_t) {
             Fp2 l0, l1, l3;

@@ -43,7 +43,7 @@ static void lane(Job* j, uint32_t par) {
     static thread_local uint32_t half[48 + 24];
     static uint32_t full[8 * 96];                    // shared by the two lanes like the HBM slots
     MRef fm = m_ref(half, 1, 8), tm = m_ref(half + 48, 1, 8);
-    SoaRef norm = {j->norm48, 1}, bsrc = {j->b32 + 8 * par, 1};
+    SoaRef norm = {j->norm48, 1, 0u}, bsrc = {j->b32 + 8 * par, 1, 0u};
     const bool sub = miller_loop_p(j->t, j->flags, norm, bsrc, fm, tm, true);        // the flat, fully inlined loop k_miller2 runs, with its subgroup verdict
     j->sub_ok[par] = sub == sub_classic ? (sub ? 1 : 0) : -1;                        // the two tests must agree
     if (!sub) { j->muls[par][1] = zkv_fp_mul_counter - c0; j->accept[par] = 0; return; }
