@@ -539,6 +539,17 @@ ZKV_HD Fp f2_dot2_limbs(const uint32_t (&ao)[9], const uint32_t (&ap)[9], const 
     fp_mac81(col, ao, bU); fp_mac81(col, ap, bV); fp_mac81(col, co, dU); fp_mac81(col, cp, dV);
     return fp_reduce_cols(col);
 }
+// one product from prepared operands (what f2_mul_lane computes; the multiplicand and multiplier may be lazy sums below 4p)
+ZKV_HD Fp f2_mul_limbs(const uint32_t (&ao)[9], const uint32_t (&ap)[9], const uint32_t (&bU)[9], const uint32_t (&bV)[9]) {
+#if defined(ZKV_COUNT_FP_MUL)
+    zkv_fp_mul_counter += 2;
+#endif
+    uint64_t col[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) col[k] = 0;
+    fp_mac81(col, ao, bU); fp_mac81(col, ap, bV);
+    return fp_reduce_cols(col);
+}
 ZKV_HD Fp2 f2_sqr(const Fp2& a) {           // reduced (< 2p) input: even lane (a0+a1)(a0-a1), odd lane (2 a1) a0
     const bool odd = zkv_parity() != 0;
     Fp o = zkv_partner(a.h);

@@ -133,8 +133,48 @@ template <class RD, class RA, class RB> ZKV_HD void f12m_mul_body(RD d, RA a, RB
 template <class RD, class RA, class RB> ZKV_HD_NI void f12m_mul(RD d, RA a, RB b) { f12m_mul_body(d, a, b, false); }
 template <class RD, class RA, class RB> ZKV_HD_NI void f12m_mul_conj(RD d, RA a, RB b) { f12m_mul_body(d, a, b, true); }
 // f <- f * (c0 + (c3 + c4 v) w)
-// (The thirteen products inlined with c0 and c4 -- or all four multipliers -- unpacked and exchanged once were measured: 112.3 and
-// 115.9 against 112.5 ms for k_miller2; 36 / 92 spilled VGPRs eat the 460-590 instructions saved per product.  Not kept.)
+#if defined(ZKV_PAIRED)
+// Lane pairs: the thirteen Karatsuba products inlined, with the multipliers c0 and c4 (three and four products) and the multiplicands
+// h2 and g2 + h2 (two each) unpacked and exchanged once: k_miller2 112.5 -> 110.7 ms.  (Keeping c3 and c0 + c3 prepared as well needs
+// 36 more registers and spilled: 115.9 ms.)
+template <class RF> ZKV_HD void f12m_mul_by_034_body(RF f, const Fp2& c0, const Fp2& c3, const Fp2& c4) {
+    uint32_t c0U[9], c0V[9], c4U[9], c4V[9], tU[9], tV[9], xo[9], xp[9];
+    f2_limbs_y(c0.h, c0U, c0V); f2_limbs_y(c4.h, c4U, c4V);
+    Fp2 t0c0, t0c1, t0c2, t1c0, t1c1, t1c2;
+    {
+        const Fp2 h0 = m_ld_f2(f, 3), h1 = m_ld_f2(f, 4), h2 = m_ld_f2(f, 5);
+        Fp2 p4, p5, p6, p7, p8;
+        f2_limbs_y(c3.h, tU, tV);
+        f2_limbs_x(h0.h, xo, xp); p4.h = f2_mul_limbs(xo, xp, tU, tV);
+        f2_limbs_x(h2.h, xo, xp); p8.h = f2_mul_limbs(xo, xp, tU, tV); p7.h = f2_mul_limbs(xo, xp, c4U, c4V);
+        f2_limbs_x(h1.h, xo, xp); p5.h = f2_mul_limbs(xo, xp, c4U, c4V);
+        f2_limbs_y(f2_add_nr(c3, c4).h, tU, tV);
+        f2_limbs_x(f2_add_nr(h0, h1).h, xo, xp); p6.h = f2_mul_limbs(xo, xp, tU, tV);
+        t1c0 = f2_add(p4, f2_mul_xi(p7)); t1c1 = f2_sub(f2_sub(p6, p4), p5); t1c2 = f2_add(p5, p8);
+    }
+    Fp2 s0, s1, s2;
+    {
+        const Fp2 g0 = m_ld_f2(f, 0), g1 = m_ld_f2(f, 1), g2 = m_ld_f2(f, 2);
+        f2_limbs_x(g0.h, xo, xp); t0c0.h = f2_mul_limbs(xo, xp, c0U, c0V);
+        f2_limbs_x(g1.h, xo, xp); t0c1.h = f2_mul_limbs(xo, xp, c0U, c0V);
+        f2_limbs_x(g2.h, xo, xp); t0c2.h = f2_mul_limbs(xo, xp, c0U, c0V);
+        s0 = f2_add(g0, m_ld_f2(f, 3)); s1 = f2_add(g1, m_ld_f2(f, 4)); s2 = f2_add(g2, m_ld_f2(f, 5));
+    }
+    m_st_f2(f, 0, f2_add(t0c0, f2_mul_xi(t1c2))); m_st_f2(f, 1, f2_add(t0c1, t1c0)); m_st_f2(f, 2, f2_add(t0c2, t1c1));
+    const Fp2 b0 = f2_add(c0, c3);
+    Fp2 w0, w1, n, q;
+    f2_limbs_y(b0.h, tU, tV);
+    f2_limbs_x(s0.h, xo, xp); w0.h = f2_mul_limbs(xo, xp, tU, tV);
+    f2_limbs_x(s2.h, xo, xp); q.h = f2_mul_limbs(xo, xp, tU, tV);
+    Fp2 q2; q2.h = f2_mul_limbs(xo, xp, c4U, c4V);
+    f2_limbs_x(s1.h, xo, xp); w1.h = f2_mul_limbs(xo, xp, c4U, c4V);
+    f2_limbs_y(f2_add_nr(b0, c4).h, tU, tV);
+    f2_limbs_x(f2_add_nr(s0, s1).h, xo, xp); n.h = f2_mul_limbs(xo, xp, tU, tV);
+    m_st_f2(f, 3, f2_sub(f2_sub(f2_add(w0, f2_mul_xi(q2)), t0c0), t1c0));
+    m_st_f2(f, 4, f2_sub(f2_sub(f2_sub(f2_sub(n, w0), w1), t0c1), t1c1));
+    m_st_f2(f, 5, f2_sub(f2_sub(f2_add(w1, q), t0c2), t1c2));
+}
+#else
 template <class RF> ZKV_HD void f12m_mul_by_034_body(RF f, const Fp2& c0, const Fp2& c3, const Fp2& c4) {
     Fp6 g = m_ld_f6(f, 0), h = m_ld_f6(f, 3);
     Fp6 t0 = f6_mul_fp2(g, c0);
@@ -143,6 +183,7 @@ template <class RF> ZKV_HD void f12m_mul_by_034_body(RF f, const Fp2& c0, const 
     m_st_f6(f, 3, f6_sub(f6_sub(t2, t0), t1));
     m_st_f6(f, 0, f6_add(t0, f6_mul_v(t1)));
 }
+#endif
 template <class RF> ZKV_HD_NI void f12m_mul_by_034(RF f, const Fp2* c0, const Fp2* c3, const Fp2* c4) { f12m_mul_by_034_body(f, *c0, *c3, *c4); }
 // f <- f * (1 + (c3 + c4 v) w)
 #if defined(ZKV_PAIRED)
