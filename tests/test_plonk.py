@@ -42,6 +42,22 @@ def hsp():
 
 
 # ---------------------------------------------------------------- CPU
+def test_scalar_field_arithmetic_of_the_stage(hsp):
+    """Fr product and inverse of the PLONK stage (csrc/zkv_plonk.h; the inverse is the division-step routine of csrc/zkv_modinv.h with
+    the scalar-field modulus) against Python integers, on edge and random values; inv(0) = 0."""
+    import random
+    import spec_model as sm
+    rng = random.Random(0xF2)
+    vals = [0, 1, 2, sm.R - 1, sm.R - 2, (sm.R + 1) // 2, 1 << 253, (1 << 30) - 1, 1 << 30, (1 << 60) + 1] + [rng.randrange(sm.R) for _ in range(300)]
+    o = C.create_string_buffer(32)
+    for i, a in enumerate(vals):
+        hsp.hsp_fr_inv(a.to_bytes(32, 'big'), o)
+        assert int.from_bytes(o.raw, 'big') == (pow(a, -1, sm.R) if a else 0), hex(a)
+        b = vals[(7 * i + 3) % len(vals)]
+        hsp.hsp_fr_mulmod(a.to_bytes(32, 'big'), b.to_bytes(32, 'big'), o)
+        assert int.from_bytes(o.raw, 'big') == a * b % sm.R, (hex(a), hex(b))
+
+
 def test_glv_split_of_the_msm_scalars(hsp):
     """k = k1 + k2 lambda (mod r) with both halves below 2^128 (33 signed 4-bit windows cover 2^131): the split the multi-scalar
     multiplications of k_plonk_prep use, on edge and random scalars; lambda acts on G1 as (x, y) -> (beta x, y) (spec model)."""
