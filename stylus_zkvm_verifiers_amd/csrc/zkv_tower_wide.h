@@ -301,19 +301,23 @@ ZKV_HD void f12m_inv_w(MRef F) {
 #endif
     wide_fence();
 }
-// acc <- x^u, same window schedule as exp_u_m
+// acc <- x^u, same digit schedule as exp_u_m
 ZKV_HD void exp_u_w(MRef acc, MRef x, MRef W, int q) {
-    const MRef X3 = W, X5 = m_off(W, 96), X7 = m_off(W, 192);
-    w12_copy(acc, x, q); w12_cyclo_sqr(acc, q);
-    w12_mul(X3, acc, x, q, false); w12_mul(X5, X3, acc, q, false); w12_mul(X7, X5, acc, q, false);
+    const MRef X17 = W, X35 = m_off(W, 96);
     w12_copy(acc, x, q);
 #pragma unroll 1
-    for (int i = ZKV_U_WNAF3_LEN - 2; i >= 0; i--) {
+    for (int k = 0; k < 4; k++) w12_cyclo_sqr(acc, q);
+    w12_mul(X17, acc, x, q, false);
+    w12_copy(acc, X17, q); w12_cyclo_sqr(acc, q);
+    w12_mul(X35, acc, x, q, false);
+    { const int t = u_digit(ZKV_U_DIG_LEN - 1); w12_copy(acc, t == 1 ? x : t == 17 ? X17 : X35, q); }
+#pragma unroll 1
+    for (int i = ZKV_U_DIG_LEN - 2; i >= 0; i--) {
         w12_cyclo_sqr(acc, q);
-        const int d = u_wnaf3(i);
+        const int d = u_digit(i);
         if (d == 0) continue;
         const int m = d < 0 ? -d : d;
-        const MRef S = m == 1 ? x : m == 3 ? X3 : m == 5 ? X5 : X7;
+        const MRef S = m == 1 ? x : m == 17 ? X17 : X35;
         w12_mul(acc, acc, S, q, d < 0);
     }
 }

@@ -355,26 +355,30 @@ ZKV_HD bool miller_loop_p(const VkTables* vkp, uint32_t flags, SoaRef norm, SoaR
 #endif  // ZKV_PAIRED
 
 // ---------------------------------------------------------------- stage FINALEXP
-// acc <- x^u  (acc and x are different slots; x in the cyclotomic subgroup).  Width-3 signed sliding window: x^3, x^5, x^7
-// go to the three scratch slots at W (one cyclotomic squaring + 3 multiplications), then 62 cyclotomic squarings and 13
-// multiplications, negative digits multiplying by the conjugate (= inverse).  16 multiplications instead of the 23 of the
-// plain NAF.
-ZKV_HD int8_t u_wnaf3(int i) {
-    const int8_t D[ZKV_U_WNAF3_LEN] = ZKV_U_WNAF3;
+// acc <- x^u  (acc and x are different slots; x in the cyclotomic subgroup).  Signed digits from {1, 17, 35} (gen_constants.py: the
+// digit set with the fewest multiplications for this u -- a cyclotomic squaring costs well under half a multiplication): x^17 and x^35
+// go to two scratch slots at W (five squarings, two multiplications), then 57 squarings and 11 multiplications, negative digits
+// multiplying by the conjugate (= inverse): 13 multiplications instead of the 16 of a width-3 window and the 23 of the plain NAF.
+ZKV_HD int8_t u_digit(int i) {
+    const int8_t D[ZKV_U_DIG_LEN] = ZKV_U_DIG;
     return D[i];
 }
 template <class RA> ZKV_HD void exp_u_m(RA acc, MRef x, MRef W) {
-    const MRef X3 = W, X5 = m_off(W, 96), X7 = m_off(W, 192);
-    f12m_copy(acc, x); f12m_cyclo_sqr(acc);             // x^2
-    f12m_mul(X3, acc, x); f12m_mul(X5, X3, acc); f12m_mul(X7, X5, acc);
-    f12m_copy(acc, x);                                  // leading digit 1
+    const MRef X17 = W, X35 = m_off(W, 96);
+    f12m_copy(acc, x);
 #pragma unroll 1
-    for (int i = ZKV_U_WNAF3_LEN - 2; i >= 0; i--) {
+    for (int k = 0; k < 4; k++) f12m_cyclo_sqr(acc);   // x^16
+    f12m_mul(X17, acc, x);
+    f12m_copy(acc, X17); f12m_cyclo_sqr(acc);           // x^34
+    f12m_mul(X35, acc, x);
+    { const int t = u_digit(ZKV_U_DIG_LEN - 1); f12m_copy(acc, t == 1 ? x : t == 17 ? X17 : X35); }
+#pragma unroll 1
+    for (int i = ZKV_U_DIG_LEN - 2; i >= 0; i--) {
         f12m_cyclo_sqr(acc);
-        const int d = u_wnaf3(i);
+        const int d = u_digit(i);
         if (d == 0) continue;
         const int m = d < 0 ? -d : d;
-        const MRef S = m == 1 ? x : m == 3 ? X3 : m == 5 ? X5 : X7;
+        const MRef S = m == 1 ? x : m == 17 ? X17 : X35;
         if (d > 0) f12m_mul(acc, acc, S);
         else f12m_mul_conj(acc, acc, S);
     }
@@ -414,11 +418,11 @@ template <class RA> ZKV_HD bool final_exp_is_one_m(MRef F, MRef E, MRef Y1, MRef
 
 #if defined(ZKV_PAIRED)
 // The same final exponentiation for the lane-pair kernel as a PROGRAM of Fp12-level operations (ZKV_FE_PROG, generated from the chain
-// above by gen_constants.py: 275 entries) run by one loop in which every operation body is inlined exactly once -- no Fp12-level calls,
+// above by gen_constants.py, with x^u on the signed digit set {1, 17, 35}: 266 entries) run by one loop in which every operation body is inlined exactly once -- no Fp12-level calls,
 // hence no callee-saved-register frames (see miller_loop_p).  The two hot operations keep the typed-LDS accumulator: the cyclotomic
-// squaring of ACC (186 entries) and ACC <- ACC * S / ACC * conj(S) with S in an HBM slot (49 entries); everything else (40 entries)
+// squaring of ACC (189 entries) and ACC <- ACC * S / ACC * conj(S) with S in an HBM slot (39 entries); everything else (38 entries)
 // goes through one generic body in which ACC is addressed through `accm`, a flat view of the same LDS words.
-// slots: 0 ACC, 1 F, 2.. = E, Y1, Y3, Y4, X3, X5, X7 (consecutive 96-word slots from E).
+// slots: 0 ACC, 1 F, 2.. = E, Y1, Y3, Y4, X17, X35, (free) (consecutive 96-word slots from E).
 ZKV_HD MRef fe_slot(int s, MRef accm, MRef F, MRef E) { return s == 0 ? accm : s == 1 ? F : m_off(E, 96 * (s - 2)); }
 template <class RA> ZKV_HD bool final_exp_prog_p(MRef F, MRef E, RA acc, MRef accm) {
     const uint32_t PROG[ZKV_FE_PROG_LEN] = ZKV_FE_PROG;
