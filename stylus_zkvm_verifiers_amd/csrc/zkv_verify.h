@@ -418,9 +418,9 @@ template <class RA> ZKV_HD bool final_exp_is_one_m(MRef F, MRef E, MRef Y1, MRef
 
 #if defined(ZKV_PAIRED)
 // The same final exponentiation for the lane-pair kernel as a PROGRAM of Fp12-level operations (ZKV_FE_PROG, generated from the chain
-// above by gen_constants.py, with x^u on the signed digit set {1, 17, 35}: 266 entries) run by one loop in which every operation body is inlined exactly once -- no Fp12-level calls,
+// above by gen_constants.py, with x^u on the signed digit set {1, 17, 35}: 269 entries) run by one loop in which every operation body is inlined exactly once -- no Fp12-level calls,
 // hence no callee-saved-register frames (see miller_loop_p).  The two hot operations keep the typed-LDS accumulator: the cyclotomic
-// squaring of ACC (189 entries) and ACC <- ACC * S / ACC * conj(S) with S in an HBM slot (39 entries); everything else (38 entries)
+// squaring of ACC (189 entries) and ACC <- ACC * S / ACC * conj(S) with S in an HBM slot (48 entries); everything else (32 entries)
 // goes through one generic body in which ACC is addressed through `accm`, a flat view of the same LDS words.
 // slots: 0 ACC, 1 F, 2.. = E, Y1, Y3, Y4, X17, X35, (free) (consecutive 96-word slots from E).
 ZKV_HD MRef fe_slot(int s, MRef accm, MRef F, MRef E) { return s == 0 ? accm : s == 1 ? F : m_off(E, 96 * (s - 2)); }
