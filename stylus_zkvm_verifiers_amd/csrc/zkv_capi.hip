@@ -80,6 +80,12 @@ static size_t chunk_capacity() {
 // SIMD), 6.2 against 8.5 ms at 8,192 (two), 8.6 against 8.6 ms at 10,240 and 9.0 against 8.6 ms at 12,288 (a second round of
 // wavefronts): above 8,192 the lane-pair kernels win because they do a third of the work per proof.
 // ZKV_WIDE_BELOW=0 disables the 16-lane kernels.
+// Chunks of at most this many proofs run the vk_x stage with one proof per wavefront (k_msm_w: latency instead of throughput).
+// ZKV_MSM_WAVE_BELOW=0 disables it.
+static size_t msm_wave_below() {
+    const char* e = getenv("ZKV_MSM_WAVE_BELOW");
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)2048;
+}
 static size_t wide_below() {
     const char* e = getenv("ZKV_WIDE_BELOW");
     return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)8192;
@@ -296,7 +302,8 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
         launch_g2chk2(a.n, c->ws, a.status, c->side);
         (void)hipEventRecord(c->ev_join, c->side);
     }
-    launch_msm(a.n, c->d_tab, a.inst ? c->d_inst : nullptr, c->ws, s);
+    if (a.n <= msm_wave_below()) launch_msm_w(a.n, c->d_tab, a.inst ? c->d_inst : nullptr, c->ws, s);     // one proof per wavefront
+    else launch_msm(a.n, c->d_tab, a.inst ? c->d_inst : nullptr, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[2], s);
     if (wide && !fork) launch_g2chk2(a.n, c->ws, a.status, s);
     if (timed) (void)hipEventRecord(c->ev[3], s);

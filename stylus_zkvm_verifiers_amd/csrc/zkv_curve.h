@@ -47,6 +47,25 @@ ZKV_HD G1J g1j_add_affine(const G1J& p, const Fp& qx, const Fp& qy) {
     return r;
 }
 
+ZKV_HD G1J g1j_add(const G1J& p, const G1J& q) {             // complete Jacobian + Jacobian
+    if (fp_is_zero(p.z)) return q;
+    if (fp_is_zero(q.z)) return p;
+    Fp z1z1 = fp_sqr(p.z), z2z2 = fp_sqr(q.z);
+    Fp u1 = fp_mul(p.x, z2z2), u2 = fp_mul(q.x, z1z1);
+    Fp s1 = fp_mul(fp_mul(p.y, q.z), z2z2), s2 = fp_mul(fp_mul(q.y, p.z), z1z1);
+    Fp h = fp_sub(u2, u1), rr = fp_sub(s2, s1);
+    if (fp_is_zero(h)) {
+        if (fp_is_zero(rr)) return g1j_dbl(p);
+        return g1j_infinity();
+    }
+    Fp hh = fp_sqr(h), hhh = fp_mul(hh, h), v = fp_mul(u1, hh);
+    G1J r;
+    r.x = fp_sub(fp_sub(fp_sqr(rr), hhh), fp_dbl(v));
+    r.y = fp_sub(fp_mul(rr, fp_sub(v, r.x)), fp_mul(s1, hhh));
+    r.z = fp_mul(fp_mul(p.z, q.z), h);
+    return r;
+}
+
 // ---------------------------------------------------------------- G2 (Jacobian over Fp2)
 struct G2J { Fp2 x, y, z; };
 struct G2A { Fp2 x, y; };

@@ -175,8 +175,11 @@ ZKV_HD G1J msm_accumulate(const VkTables& vk, const PrepOut& in, const G1A& base
     return acc;
 }
 ZKV_HD G1J msm_accumulate(const VkTables& vk, const PrepOut& in) { return msm_accumulate(vk, in, vk.base, vk.base_inf); }
+ZKV_HD void msm_normalize_acc(const G1J& acc, const PrepOut& in, uint32_t& flags, G1Norm& out);
 ZKV_HD void msm_normalize(const VkTables& vk, const PrepOut& in, uint32_t& flags, G1Norm& out, const G1A& base, uint32_t base_inf) {
-    G1J acc = msm_accumulate(vk, in, base, base_inf);
+    msm_normalize_acc(msm_accumulate(vk, in, base, base_inf), in, flags, out);
+}
+ZKV_HD void msm_normalize_acc(const G1J& acc, const PrepOut& in, uint32_t& flags, G1Norm& out) {      // uses in.ax ay cx cy only
     Fp one = fp_one();
     bool linf = fp_is_zero(acc.z), ainf = (flags & FL_A_INF) != 0, cinf = (flags & FL_C_INF) != 0;
     if (linf) flags |= FL_L_INF;
