@@ -76,9 +76,9 @@ static size_t chunk_capacity() {
 }
 
 // Chunks of at most this many proofs take the coefficient-parallel kernels (one proof per 16 lanes).  Measured (RISC Zero,
-// tools/small_batch_sweep.sh, profiles/round2_e_small_batch_sweep.txt): 4.1-4.4 ms against 8.4 ms up to 4,096 proofs (one wavefront per
-// SIMD), 6.2 against 8.5 ms at 8,192 (two), 8.6 against 8.6 ms at 10,240 and 9.0 against 8.6 ms at 12,288 (a second round of
-// wavefronts): above 8,192 the lane-pair kernels win because they do a third of the work per proof.
+// tools/small_batch_sweep.sh, profiles/round2_g_small_batch_sweep.txt): 3.4-3.8 ms against 7.8 ms up to 4,096 proofs (one wavefront per
+// SIMD), 5.6 against 7.8 ms at 8,192 (two), 7.9 against 7.9 ms from 10,240 on (a second round of wavefronts): above 8,192 the
+// lane-pair kernels win because they do a third of the work per proof.
 // ZKV_WIDE_BELOW=0 disables the 16-lane kernels.
 // Chunks of at most this many proofs run the vk_x stage with one proof per wavefront (k_msm_w: latency instead of throughput).
 // ZKV_MSM_WAVE_BELOW=0 disables it.

@@ -17,6 +17,11 @@
 #include "zkv_verify.h"
 
 #if defined(ZKV_PAIRED)
+// The Fp12-level routines of this file are inlined into the two kernels: as separate functions each kept its cross-call values in
+// callee-saved registers and saved / restored them around its body (416 / 784-byte frames) -- latency a lone wavefront cannot hide:
+// a single verification 3.82 -> 3.42 ms.  The bodies are small (at most six Fp2 products per pair), so code size is no concern.
+#define ZKV_W_NI ZKV_HD
+
 namespace zkv {
 
 ZKV_HD int w_pow(int mi) { return mi < 3 ? 2 * mi : 2 * (mi - 3) + 1; }         // memory index -> power of w
@@ -57,7 +62,7 @@ ZKV_HD void w12_conj(MRef d, int q) {                     // in place: negate th
     wide_fence();
 }
 // d <- a * b, or a * conj(b) (d may alias a or b)
-ZKV_HD_NI void w12_mul(MRef d, MRef a, MRef b, int q, bool conj_b) {
+ZKV_W_NI void w12_mul(MRef d, MRef a, MRef b, int q, bool conj_b) {
     const int e = w_pow(q);
     Fp2 accn = f2_zero(), accw = f2_zero();
     const Fp2 zero = f2_zero();
@@ -79,7 +84,7 @@ ZKV_HD_NI void w12_mul(MRef d, MRef a, MRef b, int q, bool conj_b) {
 }
 // f <- f^2 (generic): c_e = sum over unordered {i, j}, i + j = e mod 6, of a_i a_j (twice when i != j): at most four products per
 // pair.  Table entry = i | j << 3 | doubled << 6 | wrapped << 7 | valid << 8 for output power e, term t (index 4 e + t).
-ZKV_HD_NI void w12_sqr(MRef f, int q) {
+ZKV_W_NI void w12_sqr(MRef f, int q) {
     const uint16_t TERMS[24] = {256, 489, 482, 411, 328, 490, 483, 0, 336, 265, 491, 420, 344, 337, 492, 0, 352, 345, 274, 429, 360, 353, 346, 0};
     const int e = w_pow(q);
     Fp2 accn = f2_zero(), accw = f2_zero();
@@ -99,7 +104,7 @@ ZKV_HD_NI void w12_sqr(MRef f, int q) {
     wide_fence();
 }
 // f <- f^2 for f in the cyclotomic subgroup (Granger-Scott): pair q needs one Fp4 squaring (A + B y)^2, y^2 = xi.
-ZKV_HD_NI void w12_cyclo_sqr(MRef f, int q) {
+ZKV_W_NI void w12_cyclo_sqr(MRef f, int q) {
     const int ia = (q == 0 || q == 4) ? 0 : (q == 2 || q == 3) ? 1 : 3;
     const int ib = ia == 0 ? 4 : ia == 1 ? 5 : 2;
     const bool odd = q >= 3;                              // this pair's result uses 2AB, otherwise A^2 + xi B^2
@@ -115,7 +120,7 @@ ZKV_HD_NI void w12_cyclo_sqr(MRef f, int q) {
     wide_fence();
 }
 // f <- f * (c0 + c3 w + c4 w^3); with `one` the constant coefficient is 1 and c0 is not read
-ZKV_HD_NI void w12_mul_sparse(MRef f, const Fp2* c0, const Fp2* c3, const Fp2* c4, int q, bool one) {
+ZKV_W_NI void w12_mul_sparse(MRef f, const Fp2* c0, const Fp2* c3, const Fp2* c4, int q, bool one) {
     const int e = w_pow(q);
     const int e1 = e >= 1 ? e - 1 : e + 5, e3 = e >= 3 ? e - 3 : e + 3;
     Fp2 a0 = m_ld_f2(f, q), a1 = m_ld_f2(f, w_mem(e1)), a3 = m_ld_f2(f, w_mem(e3));
@@ -128,7 +133,7 @@ ZKV_HD_NI void w12_mul_sparse(MRef f, const Fp2* c0, const Fp2* c3, const Fp2* c
     wide_fence();
 }
 // d <- pi^k(a), k = 1, 2, 3
-ZKV_HD_NI void w12_frob(MRef d, MRef a, int k, int q) {
+ZKV_W_NI void w12_frob(MRef d, MRef a, int k, int q) {
     const Fp2C G1[6] = ZKV_FROB1;
     const Fp G2[6] = ZKV_FROB2;
     const Fp2C G3[6] = ZKV_FROB3;
@@ -149,7 +154,7 @@ ZKV_HD_NI void w12_frob(MRef d, MRef a, int k, int q) {
 ZKV_HD Fp2 w_pick4(int r, const Fp2& a0, const Fp2& a1, const Fp2& a2, const Fp2& a3) {
     return f2_sel(r == 0, a0, f2_sel(r == 1, a1, f2_sel(r == 2, a2, a3)));
 }
-ZKV_HD_NI void w_line_dbl(MRef Tm, MRef sc, Fp2* l0, Fp2* l1, Fp2* l3, int q) {
+ZKV_W_NI void w_line_dbl(MRef Tm, MRef sc, Fp2* l0, Fp2* l1, Fp2* l3, int q) {
     const Fp2C b3c = ZKV_TWIST_3B;
     const Fp2 b3 = f2_const(b3c);
     const Fp2 x = m_ld_f2(Tm, 0), y = m_ld_f2(Tm, 1), z = m_ld_f2(Tm, 2);
@@ -189,7 +194,7 @@ ZKV_HD_NI void w_line_dbl(MRef Tm, MRef sc, Fp2* l0, Fp2* l1, Fp2* l3, int q) {
     m_st_f2(Tm, 0, tx); m_st_f2(Tm, 1, f2_sub(g2, f2_add(f2_dbl(e2), e2))); m_st_f2(Tm, 2, tz);
     wide_fence();
 }
-ZKV_HD_NI void w_line_add(MRef Tm, MRef sc, const Fp2* qx, const Fp2* qy, Fp2* l0, Fp2* l1, Fp2* l3, int q) {
+ZKV_W_NI void w_line_add(MRef Tm, MRef sc, const Fp2* qx, const Fp2* qy, Fp2* l0, Fp2* l1, Fp2* l3, int q) {
     const Fp2 x = m_ld_f2(Tm, 0), y = m_ld_f2(Tm, 1), z = m_ld_f2(Tm, 2);
     {   // round 1: qy Z | qx Z
         const int r = q & 1;
