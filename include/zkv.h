@@ -258,6 +258,11 @@ int zkv_ctx_vk_x_batch(zkv_ctx* ctx, size_t n, const uint8_t* var_signals, uint8
  * unit in which the verify kernels' work is counted); waves_per_simd 1..8 resident wavefronts per SIMD; iters loop trips (four
  * calls each).  *shader_clock_ghz (may be NULL) = shader clock under this load from s_memtime / s_memrealtime. */
 int zkv_diag_mulmod_rate(int device, int kind, int waves_per_simd, uint32_t iters, double* mulmods_per_s, double* shader_clock_ghz);
+/* Independent issue-rate roof: lane-instructions per second over the whole chip of nothing but one instruction on register-resident
+ * operands (eight independent chains per lane, 64 instructions per loop trip).  kind 0 = v_mad_u64_u32 (the 32 x 32 + 64 multiply-add
+ * every field multiplication of the verify kernels is made of), kind 1 = v_mad_i64_i32, kind 2 = v_add_u32 (a plain VOP2 instruction,
+ * for scale).  Unlike zkv_diag_mulmod_rate this roof does not move when the library's own multiplier changes. */
+int zkv_diag_issue_rate(int device, int kind, int waves_per_simd, uint32_t iters, double* lane_instr_per_s, double* shader_clock_ghz);
 
 /* ------------------------------------------------------------------ shared */
 int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_* */
@@ -270,12 +275,18 @@ int zkv_ctx_set_lanes_per_proof(zkv_ctx* ctx, int lanes);
  * batch call.  Optional: every batch entry point does this on demand; the buffers (about 3.7 KB per proof in flight) grow to the
  * largest batch seen, at most ZKV_CHUNK proofs (environment, default 2^20; larger batches run chunk by chunk). */
 int zkv_ctx_reserve(zkv_ctx* ctx, size_t n);
-/* Blocks until everything enqueued on the context's stream has finished. */
+/* The chunk size in force: ZKV_CHUNK rounded up to a multiple of 64 and clamped to [64, 2^26] (the kernels address a chunk's
+ * workspace rows through 32-bit lane offsets, which a larger chunk would wrap). */
+size_t zkv_chunk_capacity(void);
+/* Blocks until everything enqueued by calls on this context has finished (device-wide wait; on a mixed context this covers
+ * both verifiers behind the tag, whichever of them the last batch used). */
 int zkv_ctx_synchronize(zkv_ctx* ctx);
 /* HIP-event durations (ms) of the stages of the most recent batch chunk on this context:
  * [0] prep (parse + SHA-256 + point validation)  [1] vk_x MSM + normalisation  [2] G2 subgroup check (a stage of its own only when
  * the 16-lane kernels run in line; the lane-pair Miller loop is the subgroup test itself, and the time is then ~0)
- * [3] Miller loop  [4] final exponentiation.  Synchronises the context. */
+ * [3] Miller loop  [4] final exponentiation.  Synchronises the context.  A batch larger than one chunk (and a host-buffer batch,
+ * which is staged segment by segment) reports its LAST chunk / segment only; a mixed context reports the sum over the sub-batches
+ * of its most recent call (zeros for a VM that call held no proof of). */
 int zkv_ctx_last_stage_ms(zkv_ctx* ctx, float out_ms[5]);
 /* Revert bytes of a status exactly as the reference ABI-encodes its errors (common/errors.rs:18-27,
  * risc0/errors.rs:21-32, sp1/errors.rs:21-32).  Returns the length written (0, 4 or 68) or a negative error. */

@@ -59,9 +59,11 @@ SYMBOLS = {
     'zkv_groth16_verify_batch': (_i, [_vp, _sz, _vp, _vp, _vp]),
     'zkv_ctx_vk_x_batch': (_i, [_vp, _sz, _vp, _vp]),
     'zkv_diag_mulmod_rate': (_i, [_i, _i, _i, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    'zkv_diag_issue_rate': (_i, [_i, _i, _i, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'zkv_ctx_vm': (_i, [_vp]),
     'zkv_ctx_set_lanes_per_proof': (_i, [_vp, _i]),
     'zkv_ctx_reserve': (_i, [_vp, _sz]),
+    'zkv_chunk_capacity': (_sz, []),
     'zkv_ctx_synchronize': (_i, [_vp]),
     'zkv_ctx_last_stage_ms': (_i, [_vp, C.POINTER(C.c_float)]),
     'zkv_status_abi_encode': (_i, [_i, C.c_uint8, _cp, _cp, _cp]),

@@ -44,6 +44,41 @@ __global__ __launch_bounds__(64) void k_diag_mulmod(uint32_t iters, uint32_t* __
     out[(size_t)blockIdx.x * 64 + threadIdx.x] = r;
 }
 
+// Independent issue-rate roof (round 3): nothing but v_mad_u64_u32 (kind 0) / v_mad_i64_i32 (kind 1) / v_add_u32 (kind 2: a plain VOP2
+// instruction, for scale) on register-resident operands, eight independent accumulator chains per lane, 64 instructions per loop
+// trip.  The verify kernels' executed multiply-adds per second divided by the kind-0 rate is the fraction of the multiplier-issue
+// bound they reach; unlike roofline.mulmod this roof does not move when the library's own multiplier gets faster.
+template <int KIND>
+__global__ __launch_bounds__(64) void k_diag_issue(uint32_t iters, uint32_t* __restrict__ out, unsigned long long* __restrict__ clk) {
+    uint32_t a[8], b[8]; uint64_t acc[8];
+    for (int u = 0; u < 8; u++) { a[u] = 0x9E3779B9u * (threadIdx.x + 1) + u; b[u] = 0x85EBCA6Bu * (blockIdx.x + 3) + 7 * u; acc[u] = a[u]; }
+    unsigned long long t0 = 0, r0 = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { t0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
+#pragma unroll 1
+    for (uint32_t i = 0; i < iters; i++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (KIND == 0) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[u]) : "v"(a[u]), "v"(b[(u + r) & 7]) : "vcc");
+                else if (KIND == 1) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc[u]) : "v"(a[u]), "v"(b[(u + r) & 7]) : "vcc");
+                else asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[u]) : "v"(b[(u + r) & 7]));
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = __builtin_readcyclecounter() - t0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+    uint32_t r = 0;
+    for (int u = 0; u < 8; u++) r ^= a[u] ^ (uint32_t)acc[u] ^ (uint32_t)(acc[u] >> 32);
+    out[(size_t)blockIdx.x * 64 + threadIdx.x] = r;
+}
+void launch_diag_issue(int kind, unsigned blocks, uint32_t iters, uint32_t* out, unsigned long long* clk, hipStream_t s) {
+    if (kind == 0) hipLaunchKernelGGL(k_diag_issue<0>, dim3(blocks), dim3(64), 0, s, iters, out, clk);
+    else if (kind == 1) hipLaunchKernelGGL(k_diag_issue<1>, dim3(blocks), dim3(64), 0, s, iters, out, clk);
+    else hipLaunchKernelGGL(k_diag_issue<2>, dim3(blocks), dim3(64), 0, s, iters, out, clk);
+}
+
 void launch_diag_mulmod(int kind, unsigned blocks, uint32_t iters, uint32_t* out, unsigned long long* clk, hipStream_t s) {
     if (kind == 0) hipLaunchKernelGGL(k_diag_mulmod<0>, dim3(blocks), dim3(64), 0, s, iters, out, clk);
     else if (kind == 1) hipLaunchKernelGGL(k_diag_mulmod<1>, dim3(blocks), dim3(64), 0, s, iters, out, clk);

@@ -63,17 +63,24 @@ struct zkv_ctx {
     PlonkKey* d_pkey = nullptr;
     // ZKV_VM_MIXED: one RISC Zero and one SP1 verifier behind a per-proof VM tag; mx[] are the demultiplexing buffers
     zkv_ctx* kid[2] = {nullptr, nullptr};
+    bool kid_ran[2] = {false, false};        // which sub-batch of the most recent mixed call was non-empty (zkv_ctx_last_stage_ms)
     uint8_t* mx[20] = {nullptr};
     size_t mx_cap[20] = {0};
     std::mutex mu;
 };
 
+// Proofs per chunk (= per launch of the stage kernels): ZKV_CHUNK, default 2^20, clamped to [64, 2^26].  The upper clamp is a
+// correctness bound, not a tuning choice: the lane-pair kernels address their workspace rows through ONE 32-bit byte offset per lane
+// (SoaRef::off = (8 * cap + i) * 4 in k_miller2), which wraps from cap = 2^32 / 36 (about 2^26.8) on; 2^26 proofs per chunk also is
+// 248 GB of workspace, i.e. all of one MI355X.
 static size_t chunk_capacity() {
     const char* e = getenv("ZKV_CHUNK");
     size_t c = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 20;      // upper bound: the workspace is sized on demand
     if (c < 64) c = 64;
+    if (c > ((size_t)1 << 26)) c = (size_t)1 << 26;
     return (c + 63) & ~(size_t)63;
 }
+ZKV_EXPORT size_t zkv_chunk_capacity(void) { return chunk_capacity(); }
 
 // Chunks of at most this many proofs take the coefficient-parallel kernels (one proof per 16 lanes).  Measured (RISC Zero,
 // tools/small_batch_sweep.sh, profiles/round2_g_small_batch_sweep.txt): 3.4-3.8 ms against 7.8 ms up to 4,096 proofs (one wavefront per
@@ -518,6 +525,7 @@ static int run_mixed(zkv_ctx* c, size_t n, const uint8_t* d_vm, const uint8_t* d
     HIP_TRY(hipStreamSynchronize(s));
     const size_t n0 = tot[0], n1 = tot[1];
     if (n0 + n1 > n) return ZKV_ERR_HIP;
+    c->kid_ran[0] = n0 > 0; c->kid_ran[1] = n1 > 0;
     uint8_t *st = c->mx[MX_ST], *rv = c->mx[MX_RV];
     if ((rc = run_records(c->kid[0], n0, a.c_seals, a.c_len, a.c_a, a.c_b, nullptr, nullptr, nullptr, st, rv, s)) != ZKV_OK) return rc;
     if ((rc = run_records(c->kid[1], n1, a.c_seals + ZKV_SEAL_BYTES * n0, a.c_len + n0, a.c_a + 32 * n0, nullptr, d_b, a.c_pvoff + n0, a.c_pvlen + n0,
@@ -1180,9 +1188,10 @@ ZKV_EXPORT int zkv_ctx_vk_x_batch(zkv_ctx* c, size_t n, const uint8_t* var_signa
     return ZKV_OK;
 }
 
-// ------------------------------------------------------------------ diagnostics: multiplication-rate microbenchmark
-ZKV_EXPORT int zkv_diag_mulmod_rate(int device, int kind, int waves_per_simd, uint32_t iters, double* mulmods_per_s, double* shader_clock_ghz) {
-    if (kind < 0 || kind > 4 || waves_per_simd < 1 || waves_per_simd > 8 || !iters || !mulmods_per_s) return ZKV_ERR_INVALID_ARG;
+// ------------------------------------------------------------------ diagnostics: multiplication-rate and issue-rate microbenchmarks
+// shared driver of the two microbenchmarks: `issue` selects k_diag_issue (64 instructions per loop trip and lane) over k_diag_mulmod
+// (four primitive calls per trip; kind 1 counts two multiplications per call)
+static int run_diag(int device, bool issue, int kind, int waves_per_simd, uint32_t iters, double* per_s, double* shader_clock_ghz) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return ZKV_ERR_NO_DEVICE; }
     if (device < 0 || device >= n || !device_is_gfx950(device)) return ZKV_ERR_NO_DEVICE;
@@ -1195,16 +1204,16 @@ ZKV_EXPORT int zkv_diag_mulmod_rate(int device, int kind, int waves_per_simd, ui
     int rc = ZKV_ERR_HIP;
     float ms = 0;
     unsigned long long clk[2] = {0, 0};
+    auto launch = [&](uint32_t it) { if (issue) launch_diag_issue(kind, blocks, it, d_out, d_clk, nullptr); else launch_diag_mulmod(kind, blocks, it, d_out, d_clk, nullptr); };
     if (hipMalloc(&d_out, (size_t)blocks * 64 * 4) != hipSuccess || hipMalloc(&d_clk, 16) != hipSuccess) goto done;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) goto done;
-    launch_diag_mulmod(kind, blocks, iters / 8 + 1, d_out, d_clk, nullptr);               // warm-up (code fetch, clocks)
+    launch(iters / 8 + 1);                                                                 // warm-up (code fetch, clocks)
     if (hipDeviceSynchronize() != hipSuccess) goto done;
     if (hipEventRecord(e0, nullptr) != hipSuccess) goto done;
-    launch_diag_mulmod(kind, blocks, iters, d_out, d_clk, nullptr);
+    launch(iters);
     if (hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) goto done;
     if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipMemcpy(clk, d_clk, 16, hipMemcpyDeviceToHost) != hipSuccess) goto done;
-    // four primitive calls per iteration and lane; kind 1 counts two multiplications per call
-    *mulmods_per_s = (double)blocks * 64.0 * 4.0 * (kind == 1 ? 2.0 : 1.0) * (double)iters / ((double)ms * 1e-3);
+    *per_s = (double)blocks * 64.0 * (issue ? 64.0 : 4.0 * (kind == 1 ? 2.0 : 1.0)) * (double)iters / ((double)ms * 1e-3);
     if (shader_clock_ghz) *shader_clock_ghz = clk[1] ? 0.1 * (double)clk[0] / (double)clk[1] : 0.0;     // s_memrealtime ticks at 100 MHz
     rc = ZKV_OK;
 done:
@@ -1214,6 +1223,14 @@ done:
     if (d_out) (void)hipFree(d_out);
     if (d_clk) (void)hipFree(d_clk);
     return rc;
+}
+ZKV_EXPORT int zkv_diag_mulmod_rate(int device, int kind, int waves_per_simd, uint32_t iters, double* mulmods_per_s, double* shader_clock_ghz) {
+    if (kind < 0 || kind > 4 || waves_per_simd < 1 || waves_per_simd > 8 || !iters || !mulmods_per_s) return ZKV_ERR_INVALID_ARG;
+    return run_diag(device, false, kind, waves_per_simd, iters, mulmods_per_s, shader_clock_ghz);
+}
+ZKV_EXPORT int zkv_diag_issue_rate(int device, int kind, int waves_per_simd, uint32_t iters, double* lane_instr_per_s, double* shader_clock_ghz) {
+    if (kind < 0 || kind > 2 || waves_per_simd < 1 || waves_per_simd > 8 || !iters || !lane_instr_per_s) return ZKV_ERR_INVALID_ARG;
+    return run_diag(device, true, kind, waves_per_simd, iters, lane_instr_per_s, shader_clock_ghz);
 }
 
 // ------------------------------------------------------------------ shared
@@ -1238,19 +1255,26 @@ ZKV_EXPORT int zkv_ctx_reserve(zkv_ctx* c, size_t n) {
 }
 ZKV_EXPORT int zkv_ctx_synchronize(zkv_ctx* c) {
     if (!c) return ZKV_ERR_INVALID_ARG;
-    if (!c->dev_ready) return ZKV_OK;
+    // a mixed context has work in flight as soon as ANY of its three contexts is set up (an all-SP1 batch never touches the RISC Zero child)
+    const bool any = c->dev_ready || (c->vm == ZKV_VM_MIXED && ((c->kid[0] && c->kid[0]->dev_ready) || (c->kid[1] && c->kid[1]->dev_ready)));
+    if (!any) return ZKV_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
     return ZKV_OK;
 }
 ZKV_EXPORT int zkv_ctx_last_stage_ms(zkv_ctx* c, float out_ms[5]) {
     if (!c || !out_ms) return ZKV_ERR_INVALID_ARG;
-    if (c->vm == ZKV_VM_MIXED) {                         // the two sub-batches run one after the other: stage times add up
-        float a[5], b[5];
-        int rc = zkv_ctx_last_stage_ms(c->kid[0], a);
-        if (rc == ZKV_OK) rc = zkv_ctx_last_stage_ms(c->kid[1], b);
-        if (rc != ZKV_OK) return rc;
-        for (int i = 0; i < 5; i++) out_ms[i] = a[i] + b[i];
+    if (c->vm == ZKV_VM_MIXED) {
+        // the two sub-batches run one after the other: stage times add up.  Only the children that ran in the MOST RECENT mixed call
+        // count (an unused child is either not set up or still holds the event times of an earlier batch).
+        for (int i = 0; i < 5; i++) out_ms[i] = 0.0f;
+        for (int k = 0; k < 2; k++) {
+            if (!c->kid_ran[k]) continue;
+            float a[5];
+            const int rc = zkv_ctx_last_stage_ms(c->kid[k], a);
+            if (rc != ZKV_OK) return rc;
+            for (int i = 0; i < 5; i++) out_ms[i] += a[i];
+        }
         return ZKV_OK;
     }
     if (!c->dev_ready) return ZKV_ERR_NO_DEVICE;

@@ -21,6 +21,10 @@
 
 #if defined(ZKV_COUNT_FP_MUL)
 static thread_local unsigned long long zkv_fp_mul_counter = 0;      // per thread: the lane-pair host emulation runs two
+static thread_local unsigned long long zkv_mad_counter = 0;         // 32 x 32 + 64 multiply-adds (v_mad_u64_u32 on the device) issued by the multipliers
+#define ZKV_COUNT_MADS(n) (zkv_mad_counter += (n))
+#else
+#define ZKV_COUNT_MADS(n) ((void)0)
 #endif
 
 // constant tables that are indexed at run time: namespace-scope device constants (a function-local array would be built on the stack)
@@ -181,6 +185,7 @@ ZKV_HD void fp_unpack29(const Fp& a, uint32_t x[9]) {            // 8 x 32 -> 9 
 }
 template <typename COL>
 ZKV_HD void fp_mac81(COL col[18], const uint32_t x[9], const uint32_t y[9]) {   // col += x * y, 81 independent-column MACs
+    ZKV_COUNT_MADS(81);
 #pragma unroll
     for (int i = 0; i < 9; i++) {
 #pragma unroll
@@ -191,6 +196,7 @@ ZKV_HD void fp_mac81(COL col[18], const uint32_t x[9], const uint32_t y[9]) {   
 // the result is < V / 2^261 + p, which is < 2p because every caller keeps V < p * 2^261 (about 169 p^2; operands are < 4p).
 template <typename COL>                          // int64_t: signed columns (arithmetic carries); uint64_t: all terms >= 0
 ZKV_HD Fp fp_reduce_cols(COL col[18]) {
+    ZKV_COUNT_MADS(81);
     const uint32_t P29[9] = ZKV_FP_P29_LIMBS;
     const uint32_t M29 = 0x1fffffffu;
 #pragma unroll
@@ -251,6 +257,7 @@ Fp fp_sqr(Fp a) {
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = x[i] << 1;            // < 2^30: a column holds at most 4 terms below 2^59 and one below 2^58
     uint64_t col[18];
+    ZKV_COUNT_MADS(45);
 #pragma unroll
     for (int k = 0; k < 18; k++) col[k] = 0;
 #pragma unroll

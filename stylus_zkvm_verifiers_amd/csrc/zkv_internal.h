@@ -113,6 +113,7 @@ void launch_plonk_prep(const PrepArgs& a, const PlonkKey* d_key, const Workspace
 
 // multiplication-rate microbenchmark (k_diag.hip)
 void launch_diag_mulmod(int kind, unsigned blocks, uint32_t iters, uint32_t* out, unsigned long long* clk, hipStream_t s);
+void launch_diag_issue(int kind, unsigned blocks, uint32_t iters, uint32_t* out, unsigned long long* clk, hipStream_t s);
 
 // precompile-level batches (k_precompile.hip)
 void launch_ecadd(size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok, hipStream_t s);

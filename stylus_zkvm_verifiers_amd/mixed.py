@@ -52,7 +52,9 @@ class MixedVerifier:
         _lib.check(self._L.zkv_ctx_reserve(self._h, n), 'zkv_ctx_reserve')
 
     def synchronize(self):
-        _lib.check(self._L.zkv_ctx_synchronize(self._L.zkv_mixed_ctx_risc0(self._h)), 'zkv_ctx_synchronize')
+        """Waits for everything this verifier enqueued -- on the MIXED context itself: an all-SP1 batch never sets up the RISC Zero
+        child, and waiting on that child alone would return at once."""
+        _lib.check(self._L.zkv_ctx_synchronize(self._h), 'zkv_ctx_synchronize')
 
     def last_stage_ms(self):
         import ctypes as C

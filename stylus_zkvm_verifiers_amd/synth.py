@@ -207,6 +207,14 @@ def _lane(args):
     return make_batch(vm, base_seal, n, seed, pool=pool, mutate_every=mutate_every, classes=classes)
 
 
+def profiler_preloaded():
+    """True when this process was started under a profiler whose preloaded library may already have initialised the GPU (rocprofv3
+    --pmc does): forking worker processes from such a process would duplicate HIP-runtime threads into them."""
+    import os
+    pre = os.environ.get('LD_PRELOAD', '')
+    return any(t in pre for t in ('rocprof', 'roctracer', 'rocprofiler')) or any(k.startswith(('ROCPROFILER_', 'ROCPROF_', 'ROCP_')) for k in os.environ)
+
+
 def make_batch_parallel(vm, base_seal, n, seed, pool=16, mutate_every=64, classes=MUTATION_CLASSES, lanes=16, workers=None, cache=True):
     """make_batch for large n: the batch is the concatenation of `lanes` independent generator lanes (lane j = make_batch of its
     slice with seed + j), run in worker processes.  The result depends on (n, seed, lanes) only, never on the worker count.
@@ -235,7 +243,10 @@ def make_batch_parallel(vm, base_seal, n, seed, pool=16, mutate_every=64, classe
             sizes = [per] * (lanes - 1) + [n - per * (lanes - 1)]
     jobs = [(vm, bytes(base_seal), sz, seed + 0x9E3779B1 * j, pool, mutate_every, tuple(classes)) for j, sz in enumerate(sizes) if sz]
     if workers is None:
-        workers = int(os.environ.get('ZKV_SYNTH_WORKERS', '0')) or min(len(jobs), len(os.sched_getaffinity(0)))
+        share = max(1, int(os.environ.get('WORLD_SIZE', '1')))        # ranks of one job generate their shards side by side on one host
+        workers = int(os.environ.get('ZKV_SYNTH_WORKERS', '0')) or min(len(jobs), max(1, len(os.sched_getaffinity(0)) // share))
+        if profiler_preloaded():                         # cache miss under a profiler: generate in-process, never fork (slow but safe)
+            workers = 1
     if workers <= 1:
         parts = [_lane(j) for j in jobs]
     else:

@@ -31,10 +31,12 @@ static VkTables* tables(int vm, const uint8_t* cr, const uint8_t* cid) {
     return t;
 }
 
-static unsigned long long g_stage_muls[5];
+static unsigned long long g_stage_muls[5], g_stage_mads[5];
 extern "C" {
 // Montgomery multiplications spent in each stage (prep, msm, g2chk, miller, finalexp) by the last hs_groth16 call
 void hs_stage_muls(unsigned long long* out) { for (int i = 0; i < 5; i++) out[i] = g_stage_muls[i]; }
+// ... and the 32 x 32 + 64 multiply-adds (v_mad_u64_u32 on the device) those multiplications are made of
+void hs_stage_mads(unsigned long long* out) { for (int i = 0; i < 5; i++) out[i] = g_stage_mads[i]; }
 
 // returns 1 accept / 0 reject for the Groth16 core given the 8 proof words and the two per-proof scalars
 int hs_groth16(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* words, const uint8_t* s0, const uint8_t* s1) {
@@ -45,24 +47,24 @@ int hs_groth16(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* wor
     PrepOut p; memset(&p, 0, sizeof p);
     load_be256(p.s[0], s0); load_be256(p.s[1], s1);
     if (!raw_lt_r(p.s[0]) || !raw_lt_r(p.s[1])) return 0;
-    unsigned long long c0 = zkv_fp_mul_counter;
+    unsigned long long c0 = zkv_fp_mul_counter, d0 = zkv_mad_counter;
     if (!prep_points(w, vm == 0, p)) return 0;
-    g_stage_muls[0] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
+    g_stage_muls[0] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter; g_stage_mads[0] = zkv_mad_counter - d0; d0 = zkv_mad_counter;
     if (!(p.flags & FL_B_INF) && !g2_in_subgroup(p.bx, p.by)) return 0;
-    g_stage_muls[2] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
+    g_stage_muls[2] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter; g_stage_mads[2] = zkv_mad_counter - d0; d0 = zkv_mad_counter;
     G1Norm n; uint32_t fl = p.flags;
     msm_normalize(*t, p, fl, n);
-    g_stage_muls[1] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
+    g_stage_muls[1] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter; g_stage_mads[1] = zkv_mad_counter - d0; d0 = zkv_mad_counter;
     // same slot structure as the kernels: f and T in one buffer (LDS on the device), 5 Fp12 slots for the final exp
     static thread_local uint32_t buf[96 + 48], slots[8 * 96];
     MRef fm = m_ref(buf, 1), tm = m_ref(buf + 96, 1);
     if (!miller_loop_m(t, fl, n, p.bx, p.by, fm, tm, true)) return -1;     // the loop's own subgroup verdict must agree with the classical test above
-    g_stage_muls[3] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
+    g_stage_muls[3] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter; g_stage_mads[3] = zkv_mad_counter - d0; d0 = zkv_mad_counter;
     MRef F = m_ref(slots, 1), E = m_ref(slots + 96, 1), Y1 = m_ref(slots + 192, 1), Y3 = m_ref(slots + 288, 1), Y4 = m_ref(slots + 384, 1);
     for (int k = 0; k < 96; k++) slots[k] = t->f_alpha_beta[k];
     f12m_mul(F, F, fm);
     int acc = final_exp_is_one_m(F, E, Y1, Y3, Y4, m_ref(slots + 480, 1), fm) ? 1 : 0;
-    g_stage_muls[4] = zkv_fp_mul_counter - c0;
+    g_stage_muls[4] = zkv_fp_mul_counter - c0; g_stage_mads[4] = zkv_mad_counter - d0;
     return acc;
 }
 // Runs PREP + MSM for one proof and exports what the Fp2-heavy stages consume (for the lane-pair host emulation,
@@ -276,6 +278,29 @@ int hs_line_exceptional(const uint8_t* q128) {
     }
     { G2H T; T.x = x; T.y = f2_zero(); T.z = f2_one(); line_dbl(T, l0, l1, l3); if (!f2_is_zero(T.z)) bad |= 512; }   // a 2-torsion shape (Y = 0)
     return bad;
+}
+// miller_point_closes on hand-made running points for B = q (EIP-197 word order): bit 0 = verdict for T = -psi^3(B) scaled by a
+// non-trivial Z (must be 1), bit 1 = the same coordinates with Z = 0 (must be 0: an exceptional case of the incomplete formulas
+// leaves Z = 0, and the closing test is what rejects it), bit 2 = T = (0 : Y : 0) (must be 0), bit 3 = T = +psi^3(B) (must be 0).
+int hs_miller_closing_test(const uint8_t* q128) {
+    uint32_t w[4][8];
+    for (int k = 0; k < 4; k++) load_be256(w[k], q128 + 32 * k);
+    Fp2 x, y; x.c1 = fp_from_raw(w[0]); x.c0 = fp_from_raw(w[1]); y.c1 = fp_from_raw(w[2]); y.c0 = fp_from_raw(w[3]);
+    const Fp2C G3[6] = ZKV_FROB3;
+    const Fp2 x3 = f2_mul(f2_conj(x), f2_const(G3[2])), y3 = f2_mul(f2_conj(y), f2_const(G3[3]));     // psi^3(B), affine
+    const Fp2 k = f2_add(f2_mul(x, y), f2_one());
+    uint32_t buf[48];
+    MRef tm = m_ref(buf, 1);
+    int out = 0;
+    m_st_f2(tm, 0, f2_mul(x3, k)); m_st_f2(tm, 1, f2_neg(f2_mul(y3, k))); m_st_f2(tm, 2, k);
+    if (miller_point_closes(tm, x, y)) out |= 1;
+    m_st_f2(tm, 2, f2_zero());
+    if (miller_point_closes(tm, x, y)) out |= 2;
+    m_st_f2(tm, 0, f2_zero()); m_st_f2(tm, 1, y);
+    if (miller_point_closes(tm, x, y)) out |= 4;
+    m_st_f2(tm, 0, f2_mul(x3, k)); m_st_f2(tm, 1, f2_mul(y3, k)); m_st_f2(tm, 2, k);
+    if (miller_point_closes(tm, x, y)) out |= 8;
+    return out;
 }
 // 1/a through fp_inv (safegcd division steps) for a raw value given big-endian; loose != 0 feeds the second representation
 // (a + p) of the Montgomery residue.  Returns 1 when the Fermat chain (fp_inv_fermat) gives the same canonical result.

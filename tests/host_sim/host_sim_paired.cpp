@@ -27,7 +27,7 @@ uint32_t zkv_partner_u32(uint32_t x) {
 }
 using namespace zkv;
 
-struct Job { const VkTables* t; uint32_t flags; const uint32_t* norm48; const uint32_t* b32; int sub_ok[2]; int accept[2]; unsigned long long muls[2][3]; };
+struct Job { const VkTables* t; uint32_t flags; const uint32_t* norm48; const uint32_t* b32; int sub_ok[2]; int accept[2]; unsigned long long muls[2][3], mads[2][3]; };
 
 static void lane(Job* j, uint32_t par) {
     tl_par = par;
@@ -35,10 +35,11 @@ static void lane(Job* j, uint32_t par) {
     for (int k = 0; k < 6; k++) memcpy(nf[k]->v, j->norm48 + 8 * k, 32);
     Fp2 bx, by;
     memcpy(bx.h.v, j->b32 + 8 * par, 32); memcpy(by.h.v, j->b32 + 16 + 8 * par, 32);
-    unsigned long long c0 = zkv_fp_mul_counter;
+    unsigned long long c0 = zkv_fp_mul_counter, d0 = zkv_mad_counter;
     j->muls[par][0] = j->muls[par][1] = j->muls[par][2] = 0;
+    j->mads[par][0] = j->mads[par][1] = j->mads[par][2] = 0;
     const bool sub_classic = (j->flags & FL_B_INF) ? true : g2_in_subgroup(bx, by);      // k_g2chk2 (kept for the 16-lane kernels)
-    j->muls[par][0] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
+    j->muls[par][0] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter; j->mads[par][0] = zkv_mad_counter - d0; d0 = zkv_mad_counter;
     // lane-private half slots (f2w = 8) for f, T and the accumulator; full-layout slots (f2w = 16) for the cold values
     static thread_local uint32_t half[48 + 24];
     static uint32_t full[8 * 96];                    // shared by the two lanes like the HBM slots
@@ -46,18 +47,20 @@ static void lane(Job* j, uint32_t par) {
     SoaRef norm = {j->norm48, 1, 0u}, bsrc = {j->b32 + 8 * par, 1, 0u};
     const bool sub = miller_loop_p(j->t, j->flags, norm, bsrc, fm, tm, true);        // the flat, fully inlined loop k_miller2 runs, with its subgroup verdict
     j->sub_ok[par] = sub == sub_classic ? (sub ? 1 : 0) : -1;                        // the two tests must agree
-    if (!sub) { j->muls[par][1] = zkv_fp_mul_counter - c0; j->accept[par] = 0; return; }
+    if (!sub) { j->muls[par][1] = zkv_fp_mul_counter - c0; j->mads[par][1] = zkv_mad_counter - d0; j->accept[par] = 0; return; }
     MRef ab = m_ref((uint32_t*)j->t->f_alpha_beta + 8 * par, 1, 16);
     MRef F = m_ref(full + 8 * par, 1, 16), E = m_ref(full + 96 + 8 * par, 1, 16);
     f12m_mul(F, fm, ab);
-    j->muls[par][1] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter;
+    j->muls[par][1] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter; j->mads[par][1] = zkv_mad_counter - d0; d0 = zkv_mad_counter;
     j->accept[par] = final_exp_prog_p(F, E, fm, fm) ? 1 : 0;          // the interpreted program k_finalexp2 runs
-    j->muls[par][2] = zkv_fp_mul_counter - c0;
+    j->muls[par][2] = zkv_fp_mul_counter - c0; j->mads[par][2] = zkv_mad_counter - d0;
 }
 // Fp multiplications (a lane's Fp2 product counts 2, fp_mul 1) spent by BOTH lanes of the pair in g2chk, miller, finalexp
 // during the last hs2_pairing call: the work unit of the secondary roofline (bench.py, roofline.mulmod).
-static unsigned long long g_pair_muls[3];
+static unsigned long long g_pair_muls[3], g_pair_mads[3];
 extern "C" void hs2_stage_muls(unsigned long long* out) { for (int k = 0; k < 3; k++) out[k] = g_pair_muls[k]; }
+// the 32 x 32 + 64 multiply-adds (v_mad_u64_u32) behind them, both lanes: the work unit of roofline.mulmod.issue_bound
+extern "C" void hs2_stage_mads(unsigned long long* out) { for (int k = 0; k < 3; k++) out[k] = g_pair_mads[k]; }
 
 extern "C" int hs2_pairing(const void* tables, uint32_t flags, const uint32_t* norm48, const uint32_t* b32, int* sub_ok) {
     Job j; j.t = (const VkTables*)tables; j.flags = flags; j.norm48 = norm48; j.b32 = b32;
@@ -65,7 +68,7 @@ extern "C" int hs2_pairing(const void* tables, uint32_t flags, const uint32_t* n
     std::thread t1(lane, &j, 1u);
     lane(&j, 0u);
     t1.join();
-    for (int k = 0; k < 3; k++) g_pair_muls[k] = j.muls[0][k] + j.muls[1][k];
+    for (int k = 0; k < 3; k++) { g_pair_muls[k] = j.muls[0][k] + j.muls[1][k]; g_pair_mads[k] = j.mads[0][k] + j.mads[1][k]; }
     if (j.sub_ok[0] != j.sub_ok[1] || j.sub_ok[0] < 0 || j.accept[0] != j.accept[1]) return -1;     // the pair, and the two subgroup tests, must agree
     *sub_ok = j.sub_ok[0];
     return j.accept[0];

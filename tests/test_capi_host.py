@@ -155,3 +155,22 @@ def test_hot_kernels_keep_their_resources(z):
         assert int(r['ScratchSize [bytes/lane]']) == 0 and int(r['VGPRs Spill']) == 0, (name, r)
         assert int(r['Occupancy [waves/SIMD]']) >= 2 and int(r['AGPRs']) == 0, (name, r)
         assert int(r['LDS Size [bytes/block]']) <= 18432, (name, r)
+
+
+def test_chunk_capacity_is_clamped(z):
+    """ZKV_CHUNK is clamped to [64, 2^26]: the lane-pair kernels address a chunk's workspace rows through 32-bit lane offsets
+    ((8 * cap + i) * 4 bytes in k_miller2), which wrap from cap = 2^32 / 36 on.  Read per call, in a fresh process each."""
+    import subprocess
+    import sys
+    code = 'from stylus_zkvm_verifiers_amd import _lib; print(_lib.lib().zkv_chunk_capacity())'
+    for env, want in (('', 1 << 20), ('1', 64), ('100', 128), (str(1 << 26), 1 << 26), (str((1 << 26) + 1), 1 << 26), (str(1 << 40), 1 << 26),
+                      ('18446744073709551615', 1 << 26)):
+        e = dict(os.environ, PYTHONPATH=ROOT)
+        e.pop('ZKV_CHUNK', None)
+        if env:
+            e['ZKV_CHUNK'] = env
+        out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=e, timeout=300)
+        assert out.returncode == 0, out.stderr
+        got = int(out.stdout.strip().splitlines()[-1])
+        assert got == want, (env, got, want)
+        assert (8 * got + got) * 4 < 1 << 32                      # the largest lane offset k_miller2 forms

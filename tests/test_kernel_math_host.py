@@ -128,7 +128,8 @@ def test_miller_loop_doubles_as_the_subgroup_test(hs, hs_pair, precompile_kats, 
     seal = H(r0['seal'])
     for q, ins in pts:
         assert hs.hs_g2_in_subgroup(q) == hs.hs_g2_in_subgroup_by_miller(q) == (1 if ins else 0), q.hex()[:16]
-        assert hs.hs_line_exceptional(q) == 0, q.hex()[:16]
+        assert hs.hs_line_exceptional(q) == 0, q.hex()[:16]             # T = +-B, T = O, Y = 0 fed to line_add / line_dbl: Z stays 0
+        assert hs.hs_miller_closing_test(q) == 1, q.hex()[:16]          # ... and Z = 0 (or +psi^3(B)) never passes the closing test
         words = (seal[:68] + q + seal[196:])[4:]
         fl = C.c_uint32(0); norm = (C.c_uint32 * 48)(); b = (C.c_uint32 * 32)(); sub = C.c_int(-7)
         t = hs.hs_prepare(0, cr, cid, words, m.be32(sig[2]), m.be32(sig[3]), C.byref(fl), norm, b)
@@ -377,8 +378,14 @@ def _stage_mul_counts(hs, hs_pair, real_proofs):
         t = hs.hs_prepare(*args, C.byref(fl), norm, b)
         assert hs_pair.hs2_pairing(t, fl.value, norm, b, C.byref(sub)) == 1
         pair = (C.c_ulonglong * 3)(); hs_pair.hs2_stage_muls(pair)
+        lane_mads = (C.c_ulonglong * 5)(); hs.hs_stage_mads(lane_mads)
+        pair_mads = (C.c_ulonglong * 3)(); hs_pair.hs2_stage_mads(pair_mads)
         out[vm] = {'lane': dict(zip(['prep', 'msm', 'g2chk', 'miller', 'finalexp'], [int(x) for x in lane])),
                    'pair': dict(zip(['g2chk', 'miller', 'finalexp'], [int(x) for x in pair]))}
+        # 32 x 32 + 64 multiply-adds (v_mad_u64_u32) the multipliers of the executed pipeline issue per proof, all lanes: prep and msm
+        # from the one-proof-per-lane build, miller and finalexp from the lane-pair build (both lanes)
+        out[vm]['mads_pair_pipeline'] = {'prep': int(lane_mads[0]), 'msm': int(lane_mads[1]), 'miller': int(pair_mads[1]), 'finalexp': int(pair_mads[2])}
+        out[vm]['total_pair_pipeline_mads'] = sum(out[vm]['mads_pair_pipeline'].values())
         # the pipeline has no separate subgroup check (the Miller loop's closing test does it: 12 / 16 multiplications inside
         # 'miller'); 'g2chk' is the classical test that only the 16-lane kernels of small chunks still launch, outside both totals
         out[vm]['total_lane_pipeline'] = sum(v for k, v in out[vm]['lane'].items() if k != 'g2chk')

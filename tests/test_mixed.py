@@ -233,6 +233,50 @@ def test_mixed_device_path_equals_separate_verifiers_and_oracle(zkv, mixed, real
     r0v.close(); spv.close()
 
 
+@pytest.mark.gpu
+def test_all_sp1_batch_then_synchronize_without_reserve(zkv, real_proofs):
+    """A FRESH mixed verifier (no reserve), one batch that holds SP1 proofs only, then MixedVerifier.synchronize() -- not
+    torch.cuda.synchronize(): the statuses must be final when it returns.  (The RISC Zero child of such a verifier is never set up;
+    a synchronize() that waits on that child alone returns at once and the caller reads stale bytes -- on a zero-filled buffer a stale
+    byte is 0 = accept.)  Also: the stage times of that call hold no contribution of the unused child."""
+    import torch
+    from stylus_zkvm_verifiers_amd import synth
+    dev = torch.device('cuda', 0)
+    r, s = real_proofs['risc0'], real_proofs['sp1']
+    n = 20000                                             # lane-pair kernels: long enough that an unsynchronised read would see stale bytes
+    s1, m1, _, f1 = synth.make_batch('sp1', H(s['proof']), n, 0x5A4B56A1, pool=4, mutate_every=5)
+    vk = np.tile(np.frombuffer(H(s['vkey']), dtype=np.uint8), (n, 1))
+    pv = np.tile(np.frombuffer(H(s['public_values']), dtype=np.uint8), (n, 1)); pv[f1, -1] ^= 1
+    d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (np.ones(n, dtype=np.uint8), s1, vk, pv)]
+    d_st = torch.zeros(n, dtype=torch.uint8, device=dev)            # zero-filled on purpose: stale = accept
+    torch.cuda.synchronize()
+    v = zkv.MixedVerifier(H(r['control_root']), H(r['bn254_control_id']))
+    side, other = torch.cuda.Stream(), torch.cuda.Stream()      # two non-blocking streams: work on `other` is NOT ordered after `side`
+    v.verify_batch_dev(n, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 96, 96, d_st.data_ptr(), 0, side.cuda_stream)
+    v.synchronize()
+    with torch.cuda.stream(other):                               # this copy only waits for `other`: it sees what is in HBM right now
+        host = d_st.cpu().numpy()
+    assert ((host == 0) == ~m1).all() and 0 < (host != 0).sum() < n
+    ms = v.last_stage_ms()
+    assert len(ms) == 5 and ms[3] > 0 and ms[4] > 0 and all(x >= 0 for x in ms)
+    # then an all-RISC-Zero batch on the same verifier: the stage times now come from the other child alone
+    k0 = 3000
+    s0, m0, _, f0 = synth.make_batch('risc0', H(r['seal']), k0, 0x5A4B56A2, pool=4, mutate_every=7)
+    ids = np.tile(np.frombuffer(H(r['image_id']), dtype=np.uint8), (k0, 1))
+    jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (k0, 1)); jds[f0, 0] ^= 1
+    e = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (np.zeros(k0, dtype=np.uint8), s0, ids, jds)]
+    e_st = torch.zeros(k0, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    v.verify_batch_dev(k0, e[0].data_ptr(), e[1].data_ptr(), e[2].data_ptr(), e[3].data_ptr(), 32, 0, e_st.data_ptr(), 0, side.cuda_stream)
+    v.synchronize()
+    with torch.cuda.stream(other):
+        host0 = e_st.cpu().numpy()
+    assert ((host0 == 0) == ~m0).all()
+    ms0 = v.last_stage_ms()
+    assert ms0[3] < ms[3]                                  # 3,000 proofs (16-lane kernels) against 20,000: not the sum of both children
+    v.close()
+
+
 def _job_worker(rank, world, port, n0, n1, q):
     """One rank of the config-4 job on a one-GPU box: collectives over gloo on host tensors, compute on cuda:0."""
     import json
@@ -304,12 +348,11 @@ def test_config4_job_world1_and_world2_agree_with_construction(zkv):
     assert ((st1 == 0) == ~mut).all() and (st1 == 0).sum() > 1500
 
 
-@pytest.mark.gpu
-def test_config4_per_gpu_share_2p19_through_properties(zkv, mixed, real_proofs):
-    """The per-GPU share of BASELINE config 4 -- 2^18 RISC Zero + 2^18 SP1 proofs interleaved by the seeded permutation -- through
-    the job's own step function on one GPU, checked by size-independent properties: the batch is a seeded shuffle of copies of a
-    2^12 + 2^12 base batch, so status[i] must equal base_status[source[i]] (permutation equivariance across the demultiplexer),
-    accept <=> not mutated, and a second run returns the same bytes (idempotence)."""
+def _config4_through_properties(zkv, mixed, real_proofs, k):
+    """k RISC Zero + k SP1 proofs interleaved by the seeded permutation through the job's own step function on one GPU, checked by
+    size-independent properties: the batch is a seeded shuffle of copies of a 2^12 + 2^12 base batch, so status[i] must equal
+    base_status[source[i]] (permutation equivariance across the demultiplexer and across chunk boundaries), accept <=> not mutated,
+    and a second run returns the same bytes (idempotence)."""
     import torch
     from stylus_zkvm_verifiers_amd import parallel, synth
     dev = torch.device('cuda', 0)
@@ -322,7 +365,6 @@ def test_config4_per_gpu_share_2p19_through_properties(zkv, mixed, real_proofs):
     jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (nb, 1)); jds[f0, 0] ^= 1
     vk = np.tile(np.frombuffer(H(s['vkey']), dtype=np.uint8), (nb, 1))
     pv = np.tile(np.frombuffer(H(s['public_values']), dtype=np.uint8), (nb, 1)); pv[f1, -1] ^= 1
-    k = 1 << 18
     src0 = np.random.default_rng(0x5A4B5693).permutation(k) % nb
     src1 = np.random.default_rng(0x5A4B5694).permutation(k) % nb
     vm, seals, a, b, perm = parallel.interleave([(0, s0[src0], ids[src0], jds[src0]), (1, s1[src1], vk[src1], pv[src1])], 0x5A4B5603)
@@ -350,6 +392,23 @@ def test_config4_per_gpu_share_2p19_through_properties(zkv, mixed, real_proofs):
     torch.cuda.synchronize()
     base = np.concatenate([bs0.cpu().numpy()[src0], bs1.cpu().numpy()[src1]])[perm]
     assert (st == base).all()
+    d_st.fill_(255)
     out2, _ = parallel.mixed_step(params, root, n, verify_fn, dev, dev, sync=torch.cuda.synchronize)
     assert (out2.cpu().numpy() == st).all()
     r0v.close(); spv.close()
+
+
+@pytest.mark.gpu
+def test_config4_per_gpu_share_2p19_through_properties(zkv, mixed, real_proofs):
+    """The per-GPU share of BASELINE config 4 (2^18 RISC Zero + 2^18 SP1) on one GPU."""
+    _config4_through_properties(zkv, mixed, real_proofs, 1 << 18)
+
+
+@pytest.mark.gpu
+def test_config4_full_2p22_batch_on_one_gpu(zkv, mixed, real_proofs):
+    """BASELINE configs[3] at its FULL size -- 2^21 RISC Zero + 2^21 SP1 proofs, interleaved by the seeded permutation -- through
+    parallel.mixed_step on one MI355X: the demultiplexer splits it into two 2^21-proof sub-batches, each of which takes two 2^20-proof
+    chunks of the stage pipeline (four chunks in all); what eight GPUs would each see an eighth of."""
+    from stylus_zkvm_verifiers_amd import _lib
+    assert _lib.lib().zkv_chunk_capacity() <= 1 << 20             # so that the sub-batches really cross chunk boundaries
+    _config4_through_properties(zkv, mixed, real_proofs, 1 << 21)

@@ -87,3 +87,78 @@ def test_broadcast_scatter_gather_world2(n):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_context_blob_round_trip():
+    """pack_context / unpack_context for every verifier kind; wrong shapes are refused."""
+    cr, cid = bytes(range(32)), bytes(range(32, 64))
+    for kind in (parallel.CTX_RISC0, parallel.CTX_MIXED):
+        c = parallel.unpack_context(parallel.pack_context(kind, cr, cid))
+        assert (c['kind'], c['control_root'], c['bn254_control_id']) == (kind, cr, cid)
+    assert parallel.unpack_context(parallel.pack_context(parallel.CTX_SP1))['kind'] == parallel.CTX_SP1
+    vk = bytes((7 * i) & 255 for i in range(448 + 64 * 3))
+    c = parallel.unpack_context(parallel.pack_context(parallel.CTX_GROTH16, vk=vk, n_ic=3, vm_type=0))
+    assert (c['kind'], c['vk'], c['n_ic'], c['vm_type']) == (parallel.CTX_GROTH16, vk, 3, 0)
+    pk = bytes(1056)
+    c = parallel.unpack_context(parallel.pack_context(parallel.CTX_PLONK, vk=pk, verifier_hash=bytes(range(32))))
+    assert (c['kind'], c['vk'], c['verifier_hash']) == (parallel.CTX_PLONK, pk, bytes(range(32)))
+    with pytest.raises(ValueError):
+        parallel.pack_context(parallel.CTX_GROTH16, vk=vk, n_ic=2)
+    with pytest.raises(ValueError):
+        parallel.pack_context(parallel.CTX_RISC0, cr, cid[:31])
+    with pytest.raises(ValueError):
+        parallel.unpack_context(parallel.pack_context(parallel.CTX_SP1) + b'x')
+
+
+def _sharded_worker(rank, world, port, n, first_piece, out_q):
+    """A generic-Groth16-shaped job (caller-supplied key in the context blob, 256-byte proofs + k x 32-byte signals) through
+    sharded_step; the stand-in verifier folds the KEY BYTES it received into every status, so a rank that did not get the
+    broadcast key cannot produce the expected bytes."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cpu')
+    vk = bytes((11 * i + 3) & 255 for i in range(448 + 64 * 3))
+    blob = parallel.pack_context(parallel.CTX_GROTH16, vk=vk, n_ic=3, vm_type=0) if rank == 0 else None
+    root = None
+    if rank == 0:
+        g = torch.Generator().manual_seed(9)
+        root = [torch.randint(0, 256, (n, 256), dtype=torch.uint8, generator=g), torch.randint(0, 256, (n, 64), dtype=torch.uint8, generator=g)]
+    calls = []
+
+    def fold(b, proofs, signals):
+        c = parallel.unpack_context(b)
+        key = sum(c['vk']) + 1000 * c['n_ic'] + 7 * c['vm_type'] + c['kind']
+        return ((proofs.to(torch.int64).sum(1) + 3 * signals.to(torch.int64).sum(1) + key) % 251).to(torch.uint8)
+
+    def verify_fn(b, proofs, signals):
+        calls.append(int(proofs.shape[0]))
+        return fold(b, proofs, signals)
+
+    out, t = parallel.sharded_step(blob, root, n, verify_fn, dev, dev, first_piece=first_piece)
+    lo, hi = parallel.shard_bounds(n, world, rank)
+    want_calls = [b - a for a, b in parallel._pieces_of(lo, hi, first_piece) if b > a]
+    ok = calls == want_calls and set(t) == {'distribute', 'verify', 'collect'}
+    if rank == 0:
+        ok = ok and out is not None and bool((out == fold(blob, root[0], root[1])).all())
+    else:
+        ok = ok and out is None
+    out_q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n,first_piece', [(2, 50, 1 << 16), (2, 50, 4), (3, 41, 3), (2, 1, 4)])
+def test_sharded_step_broadcasts_caller_keys_and_pipelines_the_scatter(world, n, first_piece):
+    """sharded_step over gloo: the caller-supplied key (generic Groth16 blob) reaches every rank, shards arrive in one piece or in
+    two (first_piece smaller than half a shard: the second piece's transfer is posted before the first is verified), statuses come
+    back in the original order; also three ranks and a batch smaller than the world."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, n, first_piece, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)]
