@@ -153,6 +153,31 @@ int zkv_mixed_verify_batch(zkv_ctx* ctx, size_t n, const uint8_t* vm, const uint
 int zkv_mixed_verify_batch_dev(zkv_ctx* ctx, size_t n, const uint8_t* d_vm, const uint8_t* d_seals, const uint8_t* d_in_a, const uint8_t* d_in_b,
                                size_t b_stride, size_t pv_len, uint8_t* d_status, uint8_t* d_recv_selector, void* stream);
 
+/* ------------------------------------------------------------------ sharded (multi-device) contexts
+ * `zkv_risc0_ctx_create(control_root, bn254_control_id, device_mask)` -- one verifier over several GPUs of a node.
+ * A sharded context is a set of single-device contexts of ONE verifier (same kind, same parameters) behind the ordinary batch entry
+ * points: proofs are independent (the reference verifies one per call: risc0/verifier.rs:78-92, sp1/verifier.rs:39-46), so a batch is
+ * split into contiguous ranges, one per shard, and nothing is exchanged between shards; statuses land in the caller's order.
+ *   - host-buffer batches (zkv_*_verify_batch, zkv_groth16_verify_batch, zkv_*_eth_call_batch): one host thread per shard runs the
+ *     single-device entry point on its range of the caller's buffers -- every GPU pulls its rows over its own PCIe link;
+ *   - device-resident batches (zkv_*_verify_batch_dev): the rows may live on any GPU; each shard on another GPU receives its range with
+ *     hipMemcpyPeerAsync (one direct xGMI link per peer) in two pieces, the second behind the first piece's kernels, and copies its
+ *     statuses back the same way.  With a non-NULL `stream` (a stream of the GPU holding the rows) the shards start after what that
+ *     stream has enqueued and the stream continues after all statuses are back; with NULL use zkv_ctx_synchronize.
+ * Shards with fewer than ZKV_SHARD_MIN proofs (environment, default 1,024) are not used: a single proof runs on shard 0.  Getters
+ * answer for the common parameters; entry points that are not listed above run on shard 0.  The function return value stays a
+ * library / runtime result (the first failing shard's). */
+/* Takes ownership of the contexts in `shards` on success (destroy only the returned context).  Their kind must be one of RISC0, SP1,
+ * MIXED, GROTH16, SP1_PLONK, identical across shards, initialised, with identical parameters; a device may carry several shards.
+ * NULL on any violation (the shards are then still the caller's). */
+zkv_ctx* zkv_ctx_create_sharded(zkv_ctx* const* shards, size_t n_shards);
+size_t zkv_ctx_shard_count(const zkv_ctx* ctx);       /* 0 for a single-device context */
+int zkv_ctx_shard_device(const zkv_ctx* ctx, size_t shard);
+/* One shard per set bit of device_mask (bit d = HIP device d). */
+zkv_ctx* zkv_risc0_ctx_create_multi(const uint8_t control_root[32], const uint8_t bn254_control_id[32], uint64_t device_mask);
+zkv_ctx* zkv_sp1_ctx_create_multi(uint64_t device_mask);
+zkv_ctx* zkv_mixed_ctx_create_multi(const uint8_t control_root[32], const uint8_t bn254_control_id[32], uint64_t device_mask);
+
 /* ------------------------------------------------------------------ SP1 PLONK verifier (BASELINE.json configs[4])
  * `ISp1Verifier::verify_proof` (sp1/verifier.rs:16-29, 39-46, 58-111) with the PLONK proof system behind it -- the path the reference
  * marks "in progress" (README.md:25, contracts/src/lib.rs:11) and for which it holds no code, key or proof: PARITY UNPINNED BY

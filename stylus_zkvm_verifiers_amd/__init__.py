@@ -11,8 +11,9 @@ from .bn254 import Bn254Precompiles
 from .groth16 import Groth16Verifier
 from .mixed import MixedVerifier
 from . import wire
+from .sharded import shard, shard_count, shard_devices
 
-__all__ = ['RiscZeroVerifier', 'RiscZeroVerifierSet', 'Sp1Verifier', 'Sp1PlonkVerifier', 'Bn254Precompiles', 'Groth16Verifier', 'MixedVerifier', 'VerifierError', 'errors', 'wire', 'device_count']
+__all__ = ['RiscZeroVerifier', 'RiscZeroVerifierSet', 'Sp1Verifier', 'Sp1PlonkVerifier', 'Bn254Precompiles', 'Groth16Verifier', 'MixedVerifier', 'VerifierError', 'errors', 'wire', 'device_count', 'shard', 'shard_count', 'shard_devices']
 
 
 def device_count():

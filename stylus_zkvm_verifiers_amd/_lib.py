@@ -60,6 +60,12 @@ SYMBOLS = {
     'zkv_ctx_vk_x_batch': (_i, [_vp, _sz, _vp, _vp]),
     'zkv_diag_mulmod_rate': (_i, [_i, _i, _i, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'zkv_diag_issue_rate': (_i, [_i, _i, _i, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    'zkv_ctx_create_sharded': (_vp, [C.POINTER(_vp), _sz]),
+    'zkv_ctx_shard_count': (_sz, [_vp]),
+    'zkv_ctx_shard_device': (_i, [_vp, _sz]),
+    'zkv_risc0_ctx_create_multi': (_vp, [_cp, _cp, C.c_uint64]),
+    'zkv_sp1_ctx_create_multi': (_vp, [C.c_uint64]),
+    'zkv_mixed_ctx_create_multi': (_vp, [_cp, _cp, C.c_uint64]),
     'zkv_ctx_vm': (_i, [_vp]),
     'zkv_ctx_set_lanes_per_proof': (_i, [_vp, _i]),
     'zkv_ctx_reserve': (_i, [_vp, _sz]),

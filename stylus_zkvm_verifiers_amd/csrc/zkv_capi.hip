@@ -6,6 +6,9 @@
 #include <new>
 #include <stdlib.h>
 #include <string.h>
+#include <system_error>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/zkv.h"
@@ -62,6 +65,18 @@ struct zkv_ctx {
     PlonkKeyRaw pk_raw; uint8_t pk_g2[256] = {0}, plonk_hash[32] = {0};
     PlonkKey* d_pkey = nullptr;
     // ZKV_VM_MIXED: one RISC Zero and one SP1 verifier behind a per-proof VM tag; mx[] are the demultiplexing buffers
+    // Sharded (multi-device) context: `shards` single-device contexts of one verifier behind the ordinary batch entry points
+    // (zkv_ctx_create_sharded).  sh[] is the per-shard state of device-resident batches: staging rows on the shard's device, a copy
+    // stream (the transfer of piece k + 1 runs behind the kernels of piece k), the shard's compute stream and its events.
+    struct ShardDev {
+        uint8_t* row[4] = {nullptr, nullptr, nullptr, nullptr}; size_t row_cap[4] = {0, 0, 0, 0};
+        uint8_t *st = nullptr, *rv = nullptr; size_t st_cap = 0, rv_cap = 0;
+        hipStream_t copy = nullptr, run = nullptr;
+        hipEvent_t ev_piece[2] = {nullptr, nullptr}, ev_done = nullptr;
+    };
+    std::vector<zkv_ctx*> shards;
+    std::vector<ShardDev> sh;
+    std::vector<hipEvent_t> ev_in;                       // per source device: "the caller's stream has produced the inputs"
     zkv_ctx* kid[2] = {nullptr, nullptr};
     bool kid_ran[2] = {false, false};        // which sub-batch of the most recent mixed call was non-empty (zkv_ctx_last_stage_ms)
     uint8_t* mx[20] = {nullptr};
@@ -483,6 +498,203 @@ static int run_records(zkv_ctx* c, size_t m_total, const uint8_t* seals, const u
     return mark_done(c, s);
 }
 
+// ------------------------------------------------------------------ sharded (multi-device) contexts (SURVEY 8b `device_mask`, 8e)
+// One single-device context per shard behind the ordinary batch entry points; proofs are independent, so a batch splits into
+// contiguous ranges and nothing is exchanged between shards.  Host-buffer batches: one host thread per shard calls the single-device
+// entry point on its range of the caller's buffers, so every GPU pulls its rows over its own PCIe link (no bounce through a root
+// GPU).  Device-resident batches: rows are copied from the GPU that holds them to each shard's GPU with hipMemcpyPeerAsync (one direct
+// xGMI link per peer) in two pieces -- the second piece travels behind the first piece's kernels -- and the statuses return the same way.
+static inline bool is_sharded(const zkv_ctx* c) { return c && !c->shards.empty(); }
+static size_t env_size(const char* name, size_t dflt) {
+    const char* e = getenv(name);
+    return e && *e ? (size_t)strtoull(e, nullptr, 10) : dflt;
+}
+// shards that get work: at least ZKV_SHARD_MIN (default 1,024) proofs each -- a single proof stays on one GPU
+static size_t shards_used(const zkv_ctx* c, size_t n) {
+    size_t mn = env_size("ZKV_SHARD_MIN", 1024);
+    if (mn < 1) mn = 1;
+    size_t k = (n + mn - 1) / mn;
+    if (k < 1) k = 1;
+    return k < c->shards.size() ? k : c->shards.size();
+}
+static inline void shard_range(size_t n, size_t used, size_t k, size_t* lo, size_t* hi) {      // contiguous, remainder to the low shards
+    const size_t q = n / used, r = n % used;
+    *lo = k * q + (k < r ? k : r);
+    *hi = *lo + q + (k < r ? 1 : 0);
+}
+// per_shard(child, lo, hi) -> ZKV_*; shard 0 runs on the calling thread
+template <class F> static int run_sharded(zkv_ctx* c, size_t n, F per_shard) {
+    const size_t used = shards_used(c, n);
+    std::vector<int> rc(used, ZKV_OK);
+    std::vector<std::thread> th;
+    auto one = [&](size_t k) { size_t lo, hi; shard_range(n, used, k, &lo, &hi); rc[k] = per_shard(c->shards[k], lo, hi); };
+    for (size_t k = 1; k < used; k++) {
+        try { th.emplace_back(one, k); } catch (const std::system_error&) { one(k); }          // no thread to be had: run it here
+    }
+    one(0);
+    for (auto& t : th) t.join();
+    for (int r : rc) if (r != ZKV_OK) return r;
+    return ZKV_OK;
+}
+static int shard_dev_setup(zkv_ctx::ShardDev& d, int device) {
+    if (d.run) return ZKV_OK;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&d.run, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&d.copy, hipStreamNonBlocking));
+    for (auto& e : d.ev_piece) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d.ev_done, hipEventDisableTiming));
+    return ZKV_OK;
+}
+struct DevRow { const uint8_t* p; size_t stride; };
+// child_call(child, m, rows[4] (device pointers on the child's GPU), status, recv (may be null), stream) -> ZKV_*
+template <class F>
+static int run_sharded_dev(zkv_ctx* c, size_t n, const DevRow* rows, int n_rows, uint8_t* d_status, uint8_t* d_recv, void* stream, F child_call) {
+    if (!n) return ZKV_OK;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, rows[0].p) != hipSuccess) { (void)hipGetLastError(); return ZKV_ERR_INVALID_ARG; }
+    const int sdev = at.device;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (sdev < 0 || sdev >= ndev) return ZKV_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->ev_in.size() < (size_t)ndev) c->ev_in.resize(ndev, nullptr);
+    hipStream_t caller = (hipStream_t)stream;
+    if (caller) {                                     // the shards' streams start after what the caller's stream has enqueued so far
+        HIP_TRY(hipSetDevice(sdev));
+        if (!c->ev_in[sdev]) HIP_TRY(hipEventCreateWithFlags(&c->ev_in[sdev], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->ev_in[sdev], caller));
+    }
+    const size_t used = shards_used(c, n);
+    const bool force = env_size("ZKV_SHARD_FORCE_STAGING", 0) != 0;         // tests: take the peer-copy path on a one-GPU box
+    const size_t first = env_size("ZKV_SHARD_FIRST_PIECE", (size_t)1 << 16);
+    std::vector<int> rc(used, ZKV_OK);
+    auto one = [&](size_t k) -> int {
+        zkv_ctx* kid = c->shards[k];
+        zkv_ctx::ShardDev& d = c->sh[k];
+        size_t lo, hi; shard_range(n, used, k, &lo, &hi);
+        const size_t m = hi - lo;
+        if (!m) return ZKV_OK;
+        int r = shard_dev_setup(d, kid->device);
+        if (r != ZKV_OK) return r;
+        HIP_TRY(hipSetDevice(kid->device));
+        const bool staged = force || kid->device != sdev;
+        if (caller) { HIP_TRY(hipStreamWaitEvent(d.run, c->ev_in[sdev], 0)); HIP_TRY(hipStreamWaitEvent(d.copy, c->ev_in[sdev], 0)); }
+        if (staged) {
+            if (kid->device != sdev) { (void)hipDeviceEnablePeerAccess(sdev, 0); (void)hipGetLastError(); }     // direct xGMI copies where the platform allows
+            for (int j = 0; j < n_rows; j++) if ((r = grow(&d.row[j], &d.row_cap[j], m * rows[j].stride + 8)) != ZKV_OK) return r;
+            if ((r = grow(&d.st, &d.st_cap, m)) != ZKV_OK || (d_recv && (r = grow(&d.rv, &d.rv_cap, 4 * m)) != ZKV_OK)) return r;
+        }
+        // two pieces: the first (at most `first` proofs) is what the kernels wait for, the rest travels behind its kernels
+        size_t pc[3] = {0, m, m};
+        int np = 1;
+        if (staged && first && m > 2 * first) { pc[1] = first; np = 2; }
+        if (staged) {
+            for (int q = 0; q < np; q++) {
+                for (int j = 0; j < n_rows; j++)
+                    HIP_TRY(hipMemcpyPeerAsync(d.row[j] + pc[q] * rows[j].stride, kid->device, rows[j].p + (lo + pc[q]) * rows[j].stride, sdev,
+                                               (pc[q + 1] - pc[q]) * rows[j].stride, d.copy));
+                HIP_TRY(hipEventRecord(d.ev_piece[q], d.copy));
+            }
+        }
+        for (int q = 0; q < np; q++) {
+            const uint8_t* rp[4] = {nullptr, nullptr, nullptr, nullptr};
+            for (int j = 0; j < n_rows; j++) rp[j] = (staged ? d.row[j] : rows[j].p + lo * rows[j].stride) + pc[q] * rows[j].stride;
+            if (staged) HIP_TRY(hipStreamWaitEvent(d.run, d.ev_piece[q], 0));
+            uint8_t* st = (staged ? d.st : d_status + lo) + pc[q];
+            uint8_t* rv = d_recv ? (staged ? d.rv : d_recv + 4 * lo) + 4 * pc[q] : nullptr;
+            if ((r = child_call(kid, pc[q + 1] - pc[q], rp, st, rv, d.run)) != ZKV_OK) return r;
+            HIP_TRY(hipSetDevice(kid->device));
+        }
+        if (staged) {
+            HIP_TRY(hipMemcpyPeerAsync(d_status + lo, sdev, d.st, kid->device, m, d.run));
+            if (d_recv) HIP_TRY(hipMemcpyPeerAsync(d_recv + 4 * lo, sdev, d.rv, kid->device, 4 * m, d.run));
+        }
+        HIP_TRY(hipEventRecord(d.ev_done, d.run));
+        return ZKV_OK;
+    };
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < used; k++) {
+        try { th.emplace_back([&, k] { rc[k] = one(k); }); } catch (const std::system_error&) { rc[k] = one(k); }
+    }
+    rc[0] = one(0);
+    for (auto& t : th) t.join();
+    for (int r : rc) if (r != ZKV_OK) return r;
+    if (caller) {                                     // ... and the caller's stream continues after every shard has delivered its statuses
+        HIP_TRY(hipSetDevice(sdev));
+        for (size_t k = 0; k < used; k++) { size_t lo, hi; shard_range(n, used, k, &lo, &hi); if (hi > lo) HIP_TRY(hipStreamWaitEvent(caller, c->sh[k].ev_done, 0)); }
+    }
+    return ZKV_OK;
+}
+static void shards_free(zkv_ctx* c) {
+    for (size_t k = 0; k < c->sh.size(); k++) {
+        zkv_ctx::ShardDev& d = c->sh[k];
+        if (!d.run) continue;
+        (void)hipSetDevice(c->shards[k]->device);
+        (void)hipStreamSynchronize(d.run); (void)hipStreamSynchronize(d.copy);
+        for (auto& r : d.row) { if (r) (void)hipFree(r); r = nullptr; }
+        if (d.st) (void)hipFree(d.st);
+        if (d.rv) (void)hipFree(d.rv);
+        for (auto& e : d.ev_piece) if (e) (void)hipEventDestroy(e);
+        if (d.ev_done) (void)hipEventDestroy(d.ev_done);
+        (void)hipStreamDestroy(d.copy); (void)hipStreamDestroy(d.run);
+        d = zkv_ctx::ShardDev();
+    }
+    for (auto& e : c->ev_in) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    for (auto& k : c->shards) { if (k) zkv_ctx_destroy(k); k = nullptr; }
+    c->shards.clear(); c->sh.clear();
+}
+ZKV_EXPORT zkv_ctx* zkv_ctx_create_sharded(zkv_ctx* const* shards, size_t n_shards) {
+    if (!shards || !n_shards || n_shards > 64) return nullptr;
+    for (size_t k = 0; k < n_shards; k++) {
+        const zkv_ctx* s = shards[k];
+        if (!s || is_sharded(s) || s->vm != shards[0]->vm) return nullptr;
+        for (size_t j = 0; j < k; j++) if (shards[j] == s) return nullptr;
+        if (s->vm != ZKV_VM_RISC0 && s->vm != ZKV_VM_SP1 && s->vm != ZKV_VM_MIXED && s->vm != ZKV_VM_GROTH16 && s->vm != ZKV_VM_SP1_PLONK) return nullptr;
+        // shards of one verifier: the same parameters everywhere (the host-visible state of shard 0 answers the getters)
+        if (!s->initialized || memcmp(s->selector, shards[0]->selector, 4) || memcmp(s->control_id, shards[0]->control_id, 32) ||
+            memcmp(s->gvk, shards[0]->gvk, sizeof s->gvk) || s->g_n_ic != shards[0]->g_n_ic || s->g_negate != shards[0]->g_negate ||
+            memcmp(s->plonk_hash, shards[0]->plonk_hash, 32)) return nullptr;
+        if (s->vm == ZKV_VM_SP1_PLONK && (memcmp(&s->pk_raw, &shards[0]->pk_raw, sizeof s->pk_raw) || memcmp(s->pk_g2, shards[0]->pk_g2, sizeof s->pk_g2))) return nullptr;
+        if (s->vm == ZKV_VM_MIXED && memcmp(s->kid[0]->selector, shards[0]->kid[0]->selector, 4)) return nullptr;
+    }
+    zkv_ctx* c = new (std::nothrow) zkv_ctx();
+    if (!c) return nullptr;
+    const zkv_ctx* s0 = shards[0];
+    c->vm = s0->vm; c->device = s0->device; c->initialized = s0->initialized; c->id_ge_r = s0->id_ge_r;
+    memcpy(c->control_root_0, s0->control_root_0, 16); memcpy(c->control_root_1, s0->control_root_1, 16);
+    memcpy(c->control_id, s0->control_id, 32); memcpy(c->selector, s0->selector, 4);
+    c->consts = s0->consts; c->g_n_ic = s0->g_n_ic; c->g_negate = s0->g_negate; memcpy(c->gvk, s0->gvk, sizeof c->gvk);
+    memcpy(c->plonk_hash, s0->plonk_hash, 32);
+    c->shards.assign(shards, shards + n_shards);
+    c->sh.resize(n_shards);
+    return c;
+}
+ZKV_EXPORT size_t zkv_ctx_shard_count(const zkv_ctx* c) { return c ? c->shards.size() : 0; }
+ZKV_EXPORT int zkv_ctx_shard_device(const zkv_ctx* c, size_t k) { return c && k < c->shards.size() ? c->shards[k]->device : ZKV_ERR_INVALID_ARG; }
+// one shard per set bit of device_mask (bit d = HIP device d), lowest device first
+template <class Mk> static zkv_ctx* create_multi(uint64_t device_mask, Mk mk) {
+    std::vector<zkv_ctx*> kids;
+    for (int d = 0; d < 64; d++) {
+        if (!((device_mask >> d) & 1u)) continue;
+        zkv_ctx* k = mk(d);
+        if (!k) { for (auto* x : kids) zkv_ctx_destroy(x); return nullptr; }
+        kids.push_back(k);
+    }
+    if (kids.empty()) return nullptr;
+    zkv_ctx* c = zkv_ctx_create_sharded(kids.data(), kids.size());
+    if (!c) for (auto* x : kids) zkv_ctx_destroy(x);
+    return c;
+}
+ZKV_EXPORT zkv_ctx* zkv_risc0_ctx_create_multi(const uint8_t control_root[32], const uint8_t bn254_control_id[32], uint64_t device_mask) {
+    if (!control_root || !bn254_control_id) return nullptr;
+    return create_multi(device_mask, [&](int d) { return zkv_risc0_ctx_create(control_root, bn254_control_id, d); });
+}
+ZKV_EXPORT zkv_ctx* zkv_sp1_ctx_create_multi(uint64_t device_mask) { return create_multi(device_mask, [](int d) { return zkv_sp1_ctx_create(d); }); }
+ZKV_EXPORT zkv_ctx* zkv_mixed_ctx_create_multi(const uint8_t control_root[32], const uint8_t bn254_control_id[32], uint64_t device_mask) {
+    if (!control_root || !bn254_control_id) return nullptr;
+    return create_multi(device_mask, [&](int d) { return zkv_mixed_ctx_create(control_root, bn254_control_id, d); });
+}
+
 // ------------------------------------------------------------------ mixed batches: per-proof VMType (common/types.rs:24-26)
 ZKV_EXPORT zkv_ctx* zkv_mixed_ctx_create(const uint8_t control_root[32], const uint8_t bn254_control_id[32], int device) {
     if (!control_root || !bn254_control_id) return nullptr;
@@ -495,8 +707,8 @@ ZKV_EXPORT zkv_ctx* zkv_mixed_ctx_create(const uint8_t control_root[32], const u
     if (!c->kid[0] || !c->kid[1]) { zkv_ctx_destroy(c); return nullptr; }
     return c;
 }
-ZKV_EXPORT zkv_ctx* zkv_mixed_ctx_risc0(zkv_ctx* c) { return c && c->vm == ZKV_VM_MIXED ? c->kid[0] : nullptr; }
-ZKV_EXPORT zkv_ctx* zkv_mixed_ctx_sp1(zkv_ctx* c) { return c && c->vm == ZKV_VM_MIXED ? c->kid[1] : nullptr; }
+ZKV_EXPORT zkv_ctx* zkv_mixed_ctx_risc0(zkv_ctx* c) { if (is_sharded(c)) c = c->shards[0]; return c && c->vm == ZKV_VM_MIXED ? c->kid[0] : nullptr; }
+ZKV_EXPORT zkv_ctx* zkv_mixed_ctx_sp1(zkv_ctx* c) { if (is_sharded(c)) c = c->shards[0]; return c && c->vm == ZKV_VM_MIXED ? c->kid[1] : nullptr; }
 
 enum { MX_CNT = 0, MX_TOT, MX_POS, MX_IDX, MX_SEALS, MX_LEN, MX_A, MX_B, MX_PVOFF, MX_PVLEN, MX_ST, MX_RV,
        MX_H_VM, MX_H_SEALS, MX_H_SOFF, MX_H_A, MX_H_B, MX_H_BOFF, MX_H_ST, MX_H_RV };
@@ -541,6 +753,11 @@ ZKV_EXPORT int zkv_mixed_verify_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d
     if (n && (!d_vm || !d_seals || !d_in_a || !d_in_b || !d_status || b_stride < 32 || pv_len > b_stride || b_stride > 0xFFFFFFFFu)) return ZKV_ERR_INVALID_ARG;
     if (!n) return ZKV_OK;
     if (n > 0xFFFFFFF0u) return ZKV_ERR_INVALID_ARG;
+    if (is_sharded(c)) {
+        const DevRow rows[4] = {{d_vm, 1}, {d_seals, ZKV_SEAL_BYTES}, {d_in_a, 32}, {d_in_b, b_stride}};
+        return run_sharded_dev(c, n, rows, 4, d_status, d_recv, stream, [&](zkv_ctx* k, size_t m, const uint8_t* const* r, uint8_t* st, uint8_t* rv, hipStream_t s) {
+            return zkv_mixed_verify_batch_dev(k, m, r[0], r[1], r[2], r[3], b_stride, pv_len, st, rv, s); });
+    }
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_device_init(c);
     if (rc != ZKV_OK) return rc;
@@ -555,6 +772,9 @@ ZKV_EXPORT int zkv_mixed_verify_batch(zkv_ctx* c, size_t n, const uint8_t* vm, c
     if (n > 0xFFFFFFF0u || !offsets_ok(seal_off, n) || !offsets_ok(in_b_off, n)) return ZKV_ERR_INVALID_ARG;
     for (size_t i = 0; i < n; i++)                   // journal_digest is a B256 in the reference (risc0/verifier.rs:82)
         if (vm[i] == ZKV_VM_RISC0 && in_b_off[i + 1] - in_b_off[i] != 32) return ZKV_ERR_INVALID_ARG;
+    if (is_sharded(c))
+        return run_sharded(c, n, [&](zkv_ctx* k, size_t lo, size_t hi) {
+            return zkv_mixed_verify_batch(k, hi - lo, vm + lo, seal_blob, seal_off + lo, in_a + 32 * lo, in_b_blob, in_b_off + lo, status + lo, recv ? recv + 4 * lo : nullptr); });
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_device_init(c);
     if (rc != ZKV_OK) return rc;
@@ -611,6 +831,7 @@ ZKV_EXPORT zkv_ctx* zkv_risc0_ctx_create(const uint8_t control_root[32], const u
 }
 ZKV_EXPORT void zkv_ctx_destroy(zkv_ctx* c) {
     if (!c) return;
+    if (is_sharded(c)) shards_free(c);
     for (auto& k : c->kid) { if (k) zkv_ctx_destroy(k); k = nullptr; }
     ctx_free_device(c);
     delete c;
@@ -637,12 +858,22 @@ ZKV_EXPORT int zkv_risc0_verify_batch(zkv_ctx* c, size_t n, const uint8_t* seal_
                                       const uint8_t* journal_digests, uint8_t* status, uint8_t* recv) {
     if (!c || c->vm != ZKV_VM_RISC0) return ZKV_ERR_WRONG_CTX;
     if (n && (!image_ids || !journal_digests)) return ZKV_ERR_INVALID_ARG;
+    if (is_sharded(c)) {
+        if (n && (!seal_blob || !seal_off || !status)) return ZKV_ERR_INVALID_ARG;
+        return run_sharded(c, n, [&](zkv_ctx* k, size_t lo, size_t hi) {
+            return zkv_risc0_verify_batch(k, hi - lo, seal_blob, seal_off + lo, image_ids + 32 * lo, journal_digests + 32 * lo, status + lo, recv ? recv + 4 * lo : nullptr); });
+    }
     return run_host_batch(c, n, seal_blob, seal_off, image_ids, journal_digests, nullptr, nullptr, status, recv);
 }
 ZKV_EXPORT int zkv_risc0_verify_integrity_batch(zkv_ctx* c, size_t n, const uint8_t* seal_blob, const uint64_t* seal_off,
                                                 const uint8_t* claim_digests, uint8_t* status, uint8_t* recv) {
     if (!c || c->vm != ZKV_VM_RISC0) return ZKV_ERR_WRONG_CTX;
     if (n && !claim_digests) return ZKV_ERR_INVALID_ARG;
+    if (is_sharded(c)) {
+        if (n && (!seal_blob || !seal_off || !status)) return ZKV_ERR_INVALID_ARG;
+        return run_sharded(c, n, [&](zkv_ctx* k, size_t lo, size_t hi) {
+            return zkv_risc0_verify_integrity_batch(k, hi - lo, seal_blob, seal_off + lo, claim_digests + 32 * lo, status + lo, recv ? recv + 4 * lo : nullptr); });
+    }
     return run_host_batch(c, n, seal_blob, seal_off, claim_digests, nullptr, nullptr, nullptr, status, recv);
 }
 ZKV_EXPORT int zkv_risc0_verify(zkv_ctx* c, const uint8_t* seal, size_t seal_len, const uint8_t image_id[32], const uint8_t journal_digest[32],
@@ -663,6 +894,12 @@ ZKV_EXPORT int zkv_risc0_verify_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d
                                           const uint8_t* d_journal_digests, uint8_t* d_status, uint8_t* d_recv, void* stream) {
     if (!c || c->vm != ZKV_VM_RISC0) return ZKV_ERR_WRONG_CTX;
     if (n && !d_journal_digests) return ZKV_ERR_INVALID_ARG;
+    if (is_sharded(c)) {
+        if (n && (!d_seals || !d_image_ids || !d_status)) return ZKV_ERR_INVALID_ARG;
+        const DevRow rows[3] = {{d_seals, ZKV_SEAL_BYTES}, {d_image_ids, 32}, {d_journal_digests, 32}};
+        return run_sharded_dev(c, n, rows, 3, d_status, d_recv, stream, [&](zkv_ctx* k, size_t m, const uint8_t* const* r, uint8_t* st, uint8_t* rv, hipStream_t s) {
+            return zkv_risc0_verify_batch_dev(k, m, r[0], r[1], r[2], st, rv, s); });
+    }
     return run_dev_batch(c, n, d_seals, d_image_ids, d_journal_digests, nullptr, 0, d_status, d_recv, stream);
 }
 
@@ -784,6 +1021,11 @@ ZKV_EXPORT int zkv_sp1_verify_batch(zkv_ctx* c, size_t n, const uint8_t* vkeys, 
                                     const uint8_t* proof_blob, const uint64_t* proof_off, uint8_t* status, uint8_t* recv) {
     if (!c || c->vm != ZKV_VM_SP1) return ZKV_ERR_WRONG_CTX;
     if (n && (!vkeys || !pv_blob || !pv_off)) return ZKV_ERR_INVALID_ARG;
+    if (is_sharded(c)) {
+        if (n && (!proof_blob || !proof_off || !status)) return ZKV_ERR_INVALID_ARG;
+        return run_sharded(c, n, [&](zkv_ctx* k, size_t lo, size_t hi) {
+            return zkv_sp1_verify_batch(k, hi - lo, vkeys + 32 * lo, pv_blob, pv_off + lo, proof_blob, proof_off + lo, status + lo, recv ? recv + 4 * lo : nullptr); });
+    }
     return run_host_batch(c, n, proof_blob, proof_off, vkeys, nullptr, pv_blob, pv_off, status, recv);
 }
 ZKV_EXPORT int zkv_sp1_verify_proof(zkv_ctx* c, const uint8_t vkey[32], const uint8_t* pv, size_t pv_len, const uint8_t* proof, size_t proof_len,
@@ -797,6 +1039,12 @@ ZKV_EXPORT int zkv_sp1_verify_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d_v
                                         uint8_t* d_status, uint8_t* d_recv, void* stream) {
     if (!c || c->vm != ZKV_VM_SP1) return ZKV_ERR_WRONG_CTX;
     if (n && !d_pv) return ZKV_ERR_INVALID_ARG;
+    if (is_sharded(c)) {
+        if (n && (!d_proofs || !d_vkeys || !d_status)) return ZKV_ERR_INVALID_ARG;
+        const DevRow rows[3] = {{d_vkeys, 32}, {d_pv, pv_len}, {d_proofs, ZKV_SEAL_BYTES}};
+        return run_sharded_dev(c, n, rows, 3, d_status, d_recv, stream, [&](zkv_ctx* k, size_t m, const uint8_t* const* r, uint8_t* st, uint8_t* rv, hipStream_t s) {
+            return zkv_sp1_verify_batch_dev(k, m, r[0], r[1], pv_len, r[2], st, rv, s); });
+    }
     return run_dev_batch(c, n, d_proofs, d_vkeys, nullptr, d_pv, pv_len, d_status, d_recv, stream);
 }
 
@@ -832,6 +1080,11 @@ ZKV_EXPORT int zkv_sp1_plonk_verify_batch(zkv_ctx* c, size_t n, const uint8_t* v
                                           const uint8_t* proof_blob, const uint64_t* proof_off, uint8_t* status, uint8_t* recv) {
     if (!c || c->vm != ZKV_VM_SP1_PLONK) return ZKV_ERR_WRONG_CTX;
     if (n && (!vkeys || !pv_blob || !pv_off)) return ZKV_ERR_INVALID_ARG;
+    if (is_sharded(c)) {
+        if (n && (!proof_blob || !proof_off || !status)) return ZKV_ERR_INVALID_ARG;
+        return run_sharded(c, n, [&](zkv_ctx* k, size_t lo, size_t hi) {
+            return zkv_sp1_plonk_verify_batch(k, hi - lo, vkeys + 32 * lo, pv_blob, pv_off + lo, proof_blob, proof_off + lo, status + lo, recv ? recv + 4 * lo : nullptr); });
+    }
     return run_host_batch(c, n, proof_blob, proof_off, vkeys, nullptr, pv_blob, pv_off, status, recv);
 }
 ZKV_EXPORT int zkv_sp1_plonk_verify_proof(zkv_ctx* c, const uint8_t vkey[32], const uint8_t* pv, size_t pv_len, const uint8_t* proof, size_t proof_len,
@@ -845,6 +1098,12 @@ ZKV_EXPORT int zkv_sp1_plonk_verify_batch_dev(zkv_ctx* c, size_t n, const uint8_
                                               uint8_t* d_status, uint8_t* d_recv, void* stream) {
     if (!c || c->vm != ZKV_VM_SP1_PLONK) return ZKV_ERR_WRONG_CTX;
     if (n && !d_pv) return ZKV_ERR_INVALID_ARG;
+    if (is_sharded(c)) {
+        if (n && (!d_proofs || !d_vkeys || !d_status)) return ZKV_ERR_INVALID_ARG;
+        const DevRow rows[3] = {{d_vkeys, 32}, {d_pv, pv_len}, {d_proofs, ZKV_PLONK_PROOF_BYTES}};
+        return run_sharded_dev(c, n, rows, 3, d_status, d_recv, stream, [&](zkv_ctx* k, size_t m, const uint8_t* const* r, uint8_t* st, uint8_t* rv, hipStream_t s) {
+            return zkv_sp1_plonk_verify_batch_dev(k, m, r[0], r[1], pv_len, r[2], st, rv, s); });
+    }
     return run_dev_batch(c, n, d_proofs, d_vkeys, nullptr, d_pv, pv_len, d_status, d_recv, stream);
 }
 
@@ -1035,16 +1294,27 @@ static int run_eth_call_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const u
 ZKV_EXPORT int zkv_risc0_eth_call_batch(zkv_ctx* c, size_t n, const uint8_t* calldata_blob, const uint64_t* calldata_off, uint8_t* reverted,
                                         uint8_t* returndata, uint32_t* returndata_len, uint8_t* status) {
     if (!c || c->vm != ZKV_VM_RISC0) return ZKV_ERR_WRONG_CTX;
+    if (is_sharded(c)) {
+        if (n && (!calldata_blob || !calldata_off || !reverted || !returndata || !returndata_len)) return ZKV_ERR_INVALID_ARG;
+        return run_sharded(c, n, [&](zkv_ctx* k, size_t lo, size_t hi) {
+            return zkv_risc0_eth_call_batch(k, hi - lo, calldata_blob, calldata_off + lo, reverted + lo, returndata + lo * ZKV_RETURNDATA_STRIDE, returndata_len + lo, status ? status + lo : nullptr); });
+    }
     return run_eth_call_batch(c, n, calldata_blob, calldata_off, reverted, returndata, returndata_len, status);
 }
 ZKV_EXPORT int zkv_sp1_eth_call_batch(zkv_ctx* c, size_t n, const uint8_t* calldata_blob, const uint64_t* calldata_off, uint8_t* reverted,
                                       uint8_t* returndata, uint32_t* returndata_len, uint8_t* status) {
     if (!c || c->vm != ZKV_VM_SP1) return ZKV_ERR_WRONG_CTX;
+    if (is_sharded(c)) {
+        if (n && (!calldata_blob || !calldata_off || !reverted || !returndata || !returndata_len)) return ZKV_ERR_INVALID_ARG;
+        return run_sharded(c, n, [&](zkv_ctx* k, size_t lo, size_t hi) {
+            return zkv_sp1_eth_call_batch(k, hi - lo, calldata_blob, calldata_off + lo, reverted + lo, returndata + lo * ZKV_RETURNDATA_STRIDE, returndata_len + lo, status ? status + lo : nullptr); });
+    }
     return run_eth_call_batch(c, n, calldata_blob, calldata_off, reverted, returndata, returndata_len, status);
 }
 // Device-resident calldata: verify-class calls only, statuses stay on the device.
 ZKV_EXPORT int zkv_eth_call_batch_dev(zkv_ctx* c, size_t n, const uint8_t* d_calldata, const uint64_t* d_calldata_off, uint64_t calldata_bytes,
                                       uint8_t* d_status, uint8_t* d_recv, void* stream) {
+    if (is_sharded(c)) c = c->shards[0];                 // calldata offsets are absolute into one blob: this entry point stays on one GPU
     if (!c || (c->vm != ZKV_VM_RISC0 && c->vm != ZKV_VM_SP1)) return ZKV_ERR_WRONG_CTX;
     if (n && (!d_calldata || !d_calldata_off || !d_status)) return ZKV_ERR_INVALID_ARG;
     if (!n) return ZKV_OK;
@@ -1072,6 +1342,7 @@ ZKV_EXPORT int zkv_eth_call_returndata(const zkv_ctx* c, uint8_t status, const u
     return ZKV_OK;
 }
 ZKV_EXPORT int zkv_ctx_last_wire_ms(zkv_ctx* c, float* out_ms) {
+    if (is_sharded(c)) c = c->shards[0];
     if (!c || !out_ms) return ZKV_ERR_INVALID_ARG;
     if (!c->dev_ready || !c->wire_timed) return ZKV_ERR_NO_DEVICE;
     HIP_TRY(hipSetDevice(c->device));
@@ -1137,6 +1408,9 @@ ZKV_EXPORT int zkv_groth16_verify_batch(zkv_ctx* c, size_t n, const uint8_t* pro
     const uint32_t n_sig = c->g_n_ic - 1;
     if (n && (!proofs || !verified || (n_sig && !signals))) return ZKV_ERR_INVALID_ARG;
     if (!n) return ZKV_OK;
+    if (is_sharded(c))
+        return run_sharded(c, n, [&](zkv_ctx* k, size_t lo, size_t hi) {
+            return zkv_groth16_verify_batch(k, hi - lo, proofs + 256 * lo, n_sig ? signals + (size_t)32 * n_sig * lo : signals, verified + lo); });
     std::lock_guard<std::mutex> lk(c->mu);
     int rc = ctx_ready(c, n);
     if (rc != ZKV_OK) return rc;
@@ -1164,6 +1438,7 @@ ZKV_EXPORT int zkv_groth16_verify_batch(zkv_ctx* c, size_t n, const uint8_t* pro
 
 // ------------------------------------------------------------------ Groth16 core pieces
 ZKV_EXPORT int zkv_ctx_vk_x_batch(zkv_ctx* c, size_t n, const uint8_t* var_signals, uint8_t* out) {
+    if (is_sharded(c)) c = c->shards[0];
     if (!c || c->vm == ZKV_VM_BN254 || c->vm == ZKV_VM_RISC0_SET || c->vm == ZKV_VM_MIXED || c->vm == ZKV_VM_SP1_PLONK) return ZKV_ERR_WRONG_CTX;
     if (c->vm == ZKV_VM_RISC0 && !c->initialized) return ZKV_ERR_INVALID_ARG;
     if (n && (!var_signals || !out)) return ZKV_ERR_INVALID_ARG;
@@ -1237,12 +1512,18 @@ ZKV_EXPORT int zkv_diag_issue_rate(int device, int kind, int waves_per_simd, uin
 ZKV_EXPORT int zkv_ctx_vm(const zkv_ctx* c) { return c ? c->vm : ZKV_ERR_INVALID_ARG; }
 ZKV_EXPORT int zkv_ctx_set_lanes_per_proof(zkv_ctx* c, int lanes) {
     if (!c || (lanes != 0 && lanes != 2 && lanes != 16)) return ZKV_ERR_INVALID_ARG;
+    if (is_sharded(c)) { for (auto* k : c->shards) { const int rc = zkv_ctx_set_lanes_per_proof(k, lanes); if (rc != ZKV_OK) return rc; } return ZKV_OK; }
     std::lock_guard<std::mutex> lk(c->mu);
     c->lanes = lanes;
     return ZKV_OK;
 }
 ZKV_EXPORT int zkv_ctx_reserve(zkv_ctx* c, size_t n) {
     if (!c) return ZKV_ERR_INVALID_ARG;
+    if (is_sharded(c)) {                                 // every shard for its share of an n-proof batch
+        const size_t used = shards_used(c, n ? n : 1);
+        for (size_t k = 0; k < used; k++) { size_t lo, hi; shard_range(n ? n : 1, used, k, &lo, &hi); const int rc = zkv_ctx_reserve(c->shards[k], hi - lo); if (rc != ZKV_OK) return rc; }
+        return ZKV_OK;
+    }
     if (c->vm == ZKV_VM_MIXED) {                         // either VM may own the whole batch
         int rc = zkv_ctx_reserve(c->kid[0], n);
         if (rc == ZKV_OK) rc = zkv_ctx_reserve(c->kid[1], n);
@@ -1255,6 +1536,14 @@ ZKV_EXPORT int zkv_ctx_reserve(zkv_ctx* c, size_t n) {
 }
 ZKV_EXPORT int zkv_ctx_synchronize(zkv_ctx* c) {
     if (!c) return ZKV_ERR_INVALID_ARG;
+    if (is_sharded(c)) {                                 // every shard's device, and the shards' own streams (status copies back to the source GPU)
+        for (size_t k = 0; k < c->shards.size(); k++) {
+            const int rc = zkv_ctx_synchronize(c->shards[k]);
+            if (rc != ZKV_OK) return rc;
+            if (c->sh[k].run) { HIP_TRY(hipSetDevice(c->shards[k]->device)); HIP_TRY(hipStreamSynchronize(c->sh[k].run)); }
+        }
+        return ZKV_OK;
+    }
     // a mixed context has work in flight as soon as ANY of its three contexts is set up (an all-SP1 batch never touches the RISC Zero child)
     const bool any = c->dev_ready || (c->vm == ZKV_VM_MIXED && ((c->kid[0] && c->kid[0]->dev_ready) || (c->kid[1] && c->kid[1]->dev_ready)));
     if (!any) return ZKV_OK;
@@ -1264,6 +1553,7 @@ ZKV_EXPORT int zkv_ctx_synchronize(zkv_ctx* c) {
 }
 ZKV_EXPORT int zkv_ctx_last_stage_ms(zkv_ctx* c, float out_ms[5]) {
     if (!c || !out_ms) return ZKV_ERR_INVALID_ARG;
+    if (is_sharded(c)) return zkv_ctx_last_stage_ms(c->shards[0], out_ms);          // shards run side by side: shard 0 stands for all
     if (c->vm == ZKV_VM_MIXED) {
         // the two sub-batches run one after the other: stage times add up.  Only the children that ran in the MOST RECENT mixed call
         // count (an unused child is either not set up or still holds the event times of an earlier batch).
