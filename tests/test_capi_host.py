@@ -174,3 +174,22 @@ def test_chunk_capacity_is_clamped(z):
         got = int(out.stdout.strip().splitlines()[-1])
         assert got == want, (env, got, want)
         assert (8 * got + got) * 4 < 1 << 32                      # the largest lane offset k_miller2 forms
+
+
+def test_bench_self_launches_its_ranks_and_propagates_failure(z):
+    """`python bench.py --gpus 2` with no launcher (no WORLD_SIZE in the environment) starts the two ranks itself, as child processes;
+    on a box without a GPU both fail loudly, the failure is propagated as the exit code and nothing that looks like a result is printed."""
+    import subprocess
+    import sys
+    if z.device_count() > 0:
+        pytest.skip('a gfx950 device is present')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--workload', 'risc0_2p16', '--proofs', '64',
+                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0
+    assert 'no HIP device' in p.stderr
+    assert '"metric"' not in p.stdout
+    # under a launcher whose WORLD_SIZE disagrees with --gpus the mismatch is an explicit message, not an assertion trace
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--workload', 'risc0_2p16', '--proofs', '64'],
+                       capture_output=True, text=True, timeout=600, env=dict(env, WORLD_SIZE='1', RANK='0'))
+    assert p.returncode != 0 and 'launch one process per GPU' in p.stderr
