@@ -18,6 +18,7 @@ LIB = os.path.join(HERE, 'libzkv_mi355x.so')
 UNITS = ['k_setup', 'k_prep', 'k_msm', 'k_pair', 'k_wide', 'k_precompile', 'k_wire', 'k_mixed', 'k_diag', 'k_plonk', 'zkv_capi']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-DZKV_FP_MUL_NOINLINE',
          '-Rpass-analysis=kernel-resource-usage']
+UNIT_FLAGS = {}          # per-unit extra flags (none at present)
 COMPILE_TIMEOUT_S = 1500
 EXTRA = os.environ.get('ZKV_EXTRA_FLAGS', '').split()
 
@@ -40,7 +41,7 @@ def _compile(unit, force, dep_m):
     log = os.path.join(BUILD, unit + '.log')
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), dep_m):
         return unit, 'cached'
-    cmd = [_hipcc()] + FLAGS + EXTRA + ['-c', src, '-o', obj]
+    cmd = [_hipcc()] + FLAGS + UNIT_FLAGS.get(unit, []) + EXTRA + ['-c', src, '-o', obj]
     with open(log, 'w') as lf:
         try:
             rc = subprocess.run(cmd, stdout=lf, stderr=subprocess.STDOUT, timeout=COMPILE_TIMEOUT_S, cwd=CSRC).returncode

@@ -12,7 +12,11 @@
 
 namespace zkv {
 
-// ---------------------------------------------------------------- scalar field Fr: 8 x 32-bit Montgomery form (R = 2^256), canonical
+// ---------------------------------------------------------------- scalar field Fr: Montgomery form with R = 2^261, CANONICAL (< r)
+// Stored as 8 x 32-bit limbs like Fp and multiplied on the same 9 x 29-bit column form (zkv_field.h: one v_mad_u64_u32 per term, no
+// carry handling inside a column); round 2 ran an 8 x 32-bit CIOS loop here -- about 600 instructions per product against 300, 13 %
+// of the PLONK stage.  Unlike Fp the results are kept canonical (one conditional subtraction after the reduction, whose output is
+// below V / 2^261 + r < 2r for V < r^2): the transcripts hash canonical bytes and there are few additions to save.
 struct Fr { uint32_t v[8]; };
 ZKV_HD Fr fr_zero() { Fr r; for (int i = 0; i < 8; i++) r.v[i] = 0; return r; }
 ZKV_HD Fr fr_one() { Fr r = ZKV_FR_ONE; return r; }
@@ -20,41 +24,70 @@ ZKV_HD bool fr_is_zero(const Fr& a) { uint32_t o = 0; for (int i = 0; i < 8; i++
 ZKV_HD Fr fr_add(const Fr& a, const Fr& b) {
     const uint32_t M[8] = ZKV_FR_R_LIMBS;
     Fr t, s; uint32_t c = 0, br = 0;
+#pragma unroll
     for (int i = 0; i < 8; i++) t.v[i] = addc(a.v[i], b.v[i], c);          // < 2r < 2^255: no carry out
+#pragma unroll
     for (int i = 0; i < 8; i++) s.v[i] = subb(t.v[i], M[i], br);
+#pragma unroll
     for (int i = 0; i < 8; i++) t.v[i] = br ? t.v[i] : s.v[i];
     return t;
 }
 ZKV_HD Fr fr_sub(const Fr& a, const Fr& b) {
     const uint32_t M[8] = ZKV_FR_R_LIMBS;
     Fr t; uint32_t br = 0, c = 0;
+#pragma unroll
     for (int i = 0; i < 8; i++) t.v[i] = subb(a.v[i], b.v[i], br);
     const uint32_t mask = 0u - br;
+#pragma unroll
     for (int i = 0; i < 8; i++) t.v[i] = addc(t.v[i], M[i] & mask, c);
     return t;
 }
 ZKV_HD Fr fr_neg(const Fr& a) { return fr_sub(fr_zero(), a); }
-// CIOS Montgomery product on 32-bit limbs (a few hundred of these per proof: not worth the column form of fp_mul)
+#if defined(ZKV_COUNT_FP_MUL)
+static thread_local unsigned long long zkv_fr_mul_counter = 0;     // host-only op counter (tests/host_sim)
+#endif
+// a b 2^-261 mod r, canonical.  Operands: any values below 2^256 whose product stays below r 2^261 (canonical values, and the raw
+// 256-bit integers fr_from_raw / fr_to_raw pass in).
 ZKV_HD_NI Fr fr_mul(Fr a, Fr b) {
+#if defined(ZKV_COUNT_FP_MUL)
+    zkv_fr_mul_counter++;
+#endif
     const uint32_t M[8] = ZKV_FR_R_LIMBS;
-    uint32_t t[10];
-    for (int i = 0; i < 10; i++) t[i] = 0;
-#pragma unroll 1
-    for (int i = 0; i < 8; i++) {
-        uint64_t c = 0;
-        for (int j = 0; j < 8; j++) { c += (uint64_t)a.v[j] * b.v[i] + t[j]; t[j] = (uint32_t)c; c >>= 32; }
-        c += t[8]; t[8] = (uint32_t)c; t[9] = (uint32_t)(c >> 32);
-        const uint32_t m = t[0] * ZKV_FR_INV32;
-        c = (uint64_t)m * M[0] + t[0]; c >>= 32;
-        for (int j = 1; j < 8; j++) { c += (uint64_t)m * M[j] + t[j]; t[j - 1] = (uint32_t)c; c >>= 32; }
-        c += t[8]; t[7] = (uint32_t)c; t[8] = t[9] + (uint32_t)(c >> 32);
+    const uint32_t R29[9] = ZKV_FR_R29_LIMBS;
+    const uint32_t M29 = 0x1fffffffu;
+    uint32_t x[9], y[9];
+    { Fp t; for (int i = 0; i < 8; i++) t.v[i] = a.v[i]; fp_unpack29(t, x); for (int i = 0; i < 8; i++) t.v[i] = b.v[i]; fp_unpack29(t, y); }
+    uint64_t col[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) col[k] = 0;
+    fp_mac81(col, x, y);
+    ZKV_COUNT_MADS(81);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {                 // Montgomery reduction, one 29-bit digit per step (fp_reduce_cols with r's limbs)
+        const uint32_t m = ((uint32_t)col[i] * ZKV_FR_INV29) & M29;
+#pragma unroll
+        for (int j = 0; j < 9; j++) col[i + j] += (uint64_t)m * R29[j];
+        col[i + 1] += col[i] >> 29;
     }
-    Fr r, s; uint32_t br = 0;
-    for (int i = 0; i < 8; i++) r.v[i] = t[i];
-    for (int i = 0; i < 8; i++) s.v[i] = subb(r.v[i], M[i], br);
-    const bool keep = br && !t[8];
-    for (int i = 0; i < 8; i++) r.v[i] = keep ? r.v[i] : s.v[i];
-    return r;
+    uint32_t r9[9];
+#pragma unroll
+    for (int k = 9; k < 17; k++) { r9[k - 9] = (uint32_t)col[k] & M29; col[k + 1] += col[k] >> 29; }
+    r9[8] = (uint32_t)col[17];
+    Fr o, s;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {                 // pack 9 x 29 -> 8 x 32 (the value is < 2r < 2^255)
+        const int bit = 32 * w, k = bit / 29, sh = bit - 29 * k, got = 29 - sh;
+        uint32_t v = r9[k] >> sh;
+        if (k + 1 < 9) v |= r9[k + 1] << got;
+        if (got + 29 < 32 && k + 2 < 9) v |= r9[k + 2] << (got + 29);
+        o.v[w] = v;
+    }
+    uint32_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s.v[i] = subb(o.v[i], M[i], br);
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.v[i] = br ? o.v[i] : s.v[i];
+    return o;
 }
 ZKV_HD Fr fr_from_raw(const uint32_t* limbs) {               // canonical value < r -> Montgomery form
     Fr t, r2 = ZKV_FR_R2;
@@ -293,14 +326,18 @@ ZKV_HD void plonk_msm_table(MsmTable& tb, const MsmTerm& t) {
     tb.m[6] = g1j_add_affine(tb.m[5], t.x, t.y);
     tb.m[7] = g1j_dbl(tb.m[3]);
 }
-template <int N> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&t)[N], int n) {
-    MsmTable tab[N];
+// NV: how many of the N terms can be proof points (the others take the key's joint tables): only those get a per-proof table, which
+// is what lives in the lane's private memory (round 2 sized it by N: 7.7 of the kernel's 14.8 KB per lane).
+template <int N, int NV> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&t)[N], int n) {
+    MsmTable tab[NV];
     uint32_t dig[N][2][5];                                // per half 33 signed digits, packed 4 bits each as d + 8 (0..15)
     uint32_t negs[N];                                     // bit 0 / 1: the first / second half is negative
+    int slot[N];                                          // term -> its table in tab[] (proof points), -1 otherwise
+    { int nv = 0; for (int i = 0; i < N; i++) slot[i] = (i < n && !t[i].fixed && nv < NV) ? nv++ : -1; }
 #pragma unroll 1
     for (int i = 0; i < n; i++) {
         if (t[i].inf) continue;
-        if (!t[i].fixed) plonk_msm_table(tab[i], t[i]);
+        if (!t[i].fixed) plonk_msm_table(tab[slot[i]], t[i]);
         uint32_t m1[5], m2[5], n1, n2;
         glv_split(t[i].k, m1, n1, m2, n2);
         glv_digits(m1, dig[i][0]); glv_digits(m2, dig[i][1]);
@@ -311,28 +348,30 @@ template <int N> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&t)[N], i
     // (11 instead of 16 multiplications).  Entries are never infinity: G1 has prime order.  z then holds beta * x.
     {
         const Fp beta = ZKV_GLV_BETA;
-        Fp pre[N][7];
+        Fp pre[NV][7];
         Fp run = fp_one();
 #pragma unroll 1
         for (int i = 0; i < n; i++) {
             if (t[i].inf || t[i].fixed) continue;
+            const int s = slot[i];
 #pragma unroll 1
-            for (int m = 1; m < 8; m++) { pre[i][m - 1] = run; run = fp_mul(run, tab[i].m[m].z); }
+            for (int m = 1; m < 8; m++) { pre[s][m - 1] = run; run = fp_mul(run, tab[s].m[m].z); }
         }
         Fp inv = fp_inv(run);
 #pragma unroll 1
         for (int i = n - 1; i >= 0; i--) {
             if (t[i].inf || t[i].fixed) continue;
+            const int s = slot[i];
 #pragma unroll 1
             for (int m = 7; m >= 1; m--) {
-                const Fp zi = fp_mul(inv, pre[i][m - 1]);
-                inv = fp_mul(inv, tab[i].m[m].z);
+                const Fp zi = fp_mul(inv, pre[s][m - 1]);
+                inv = fp_mul(inv, tab[s].m[m].z);
                 const Fp zi2 = fp_sqr(zi);
-                tab[i].m[m].x = fp_mul(tab[i].m[m].x, zi2);
-                tab[i].m[m].y = fp_mul(tab[i].m[m].y, fp_mul(zi2, zi));
-                tab[i].m[m].z = fp_mul(tab[i].m[m].x, beta);
+                tab[s].m[m].x = fp_mul(tab[s].m[m].x, zi2);
+                tab[s].m[m].y = fp_mul(tab[s].m[m].y, fp_mul(zi2, zi));
+                tab[s].m[m].z = fp_mul(tab[s].m[m].x, beta);
             }
-            tab[i].m[0].z = fp_mul(tab[i].m[0].x, beta);
+            tab[s].m[0].z = fp_mul(tab[s].m[0].x, beta);
         }
     }
     G1J acc = g1j_infinity();
@@ -352,8 +391,9 @@ template <int N> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&t)[N], i
                 acc = g1j_add_affine(acc, e.x, flip ? fp_neg(e.y) : e.y);
                 continue;
             }
-            if (e1) { const int m = (e1 < 0 ? -e1 : e1) - 1; acc = g1j_add_affine(acc, tab[i].m[m].x, e1 < 0 ? fp_neg(tab[i].m[m].y) : tab[i].m[m].y); }
-            if (e2) { const int m = (e2 < 0 ? -e2 : e2) - 1; acc = g1j_add_affine(acc, tab[i].m[m].z, e2 < 0 ? fp_neg(tab[i].m[m].y) : tab[i].m[m].y); }
+            const int s = slot[i];
+            if (e1) { const int m = (e1 < 0 ? -e1 : e1) - 1; acc = g1j_add_affine(acc, tab[s].m[m].x, e1 < 0 ? fp_neg(tab[s].m[m].y) : tab[s].m[m].y); }
+            if (e2) { const int m = (e2 < 0 ? -e2 : e2) - 1; acc = g1j_add_affine(acc, tab[s].m[m].z, e2 < 0 ? fp_neg(tab[s].m[m].y) : tab[s].m[m].y); }
         }
     }
     return g1j_add(acc, start);
@@ -486,7 +526,7 @@ ZKV_HD_NI bool plonk_prepare(const PlonkKey& key, const uint32_t (&w)[27][8], co
         plonk_key_term(t[4], key, PK_S3, _s1); plonk_term(t[5], pp[6], pinf[6], coeff_z);
         plonk_term(t[6], pp[3], pinf[3], k0); plonk_term(t[7], pp[4], pinf[4], k1); plonk_term(t[8], pp[5], pinf[5], k2);
         if (n_c) plonk_term(t[9], pp[9], pinf[9], qcpz);
-        plonk_affine(plonk_msm(qk, t, n_c ? 10 : 9), lin_a, lin_inf, lin_b);
+        plonk_affine((plonk_msm<10, 5>(qk, t, n_c ? 10 : 9)), lin_a, lin_inf, lin_b);
     }
     // ---- fold the openings at zeta: gamma_kzg = H("gamma" || zeta || digests || values || zu)
     uint32_t zr[8], ch[8];
@@ -514,7 +554,7 @@ ZKV_HD_NI bool plonk_prepare(const PlonkKey& key, const uint32_t (&w)[27][8], co
         if (n_c) plonk_key_term(t[5], key, PK_QCP, g6);
         G1J linj = g1j_infinity();
         if (!lin_inf) { linj.x = lin_a.x; linj.y = lin_a.y; linj.z = fp_one(); }
-        plonk_affine(plonk_msm(linj, t, n_c ? 6 : 5), fold_a, fold_inf, fold_b);
+        plonk_affine((plonk_msm<6, 3>(linj, t, n_c ? 6 : 5)), fold_a, fold_inf, fold_b);
     }
     // ---- batch the two openings: lambda = H(folded digest || H_zeta || Z || H_zeta_omega || zeta || gamma_kzg) mod r
     s.init();
@@ -534,12 +574,12 @@ ZKV_HD_NI bool plonk_prepare(const PlonkKey& key, const uint32_t (&w)[27][8], co
         plonk_term(t[3], pp[8], pinf[8], fr_mul(lam, fr_mul(zeta, key.gen)));
         G1J fj = g1j_infinity();
         if (!fold_inf) { fj.x = fold_a.x; fj.y = fold_a.y; fj.z = fp_one(); }
-        dj = plonk_msm(fj, t, 4);
+        dj = plonk_msm<4, 3>(fj, t, 4);
         MsmTerm u1[1];
         plonk_term(u1[0], pp[8], pinf[8], lam);
         G1J hz = g1j_infinity();
         if (!pinf[7]) { hz.x = pp[7].x; hz.y = pp[7].y; hz.z = fp_one(); }
-        qj = plonk_msm(hz, u1, 1);
+        qj = plonk_msm<1, 1>(hz, u1, 1);
         qj.y = fp_neg(qj.y);
     }
     g1j_to_affine(dj, out.d, out.d_inf);

@@ -1,6 +1,7 @@
 // Host build of the PLONK pre-pairing stage (stylus_zkvm_verifiers_amd/csrc/zkv_plonk.h) for CPU-side tests.  TEST ONLY: the
 // shipped library never runs this on the host; it lets `-m "not gpu"` tests check the exact function k_plonk_prep executes
 // (transcript, scalar algebra, MSMs) against oracle/plonk_model.py.
+#define ZKV_COUNT_FP_MUL 1
 #include <stdint.h>
 #include <string.h>
 #include "../../stylus_zkvm_verifiers_amd/csrc/zkv_host_vk.h"
@@ -10,7 +11,11 @@ using namespace zkv;
 
 static void wr_be(uint8_t* p, const uint32_t l[8]) { for (int i = 0; i < 8; i++) for (int k = 0; k < 4; k++) p[31 - 4 * i - k] = (uint8_t)(l[i] >> (8 * k)); }
 
+static unsigned long long g_counts[3];
 extern "C" {
+// work of the last hsp_prepare call inside plonk_prepare: Fp multiplications, Fr multiplications, and the 32 x 32 + 64 multiply-adds
+// (v_mad_u64_u32 on the device) both are made of -- the figures behind roofline.mulmod / roofline.achieved of bench.py --workload plonk_2p18
+void hsp_prepare_counts(unsigned long long* out) { for (int i = 0; i < 3; i++) out[i] = g_counts[i]; }
 // vk: the serialisation of include/zkv.h (7 words, 8 + n_c points, 256 bytes of G2); proof: 27 x 32 bytes; pub: 2 x 32 bytes.
 // Returns -1 for a malformed key, 0 when the stage rejects, 1 when it produced the pairing inputs: out = D.x D.y Q.x Q.y (128 bytes,
 // (0,0) = infinity).
@@ -30,7 +35,10 @@ int hsp_prepare(const uint8_t* vk, size_t vk_len, const uint8_t* proof, const ui
     for (int k = 0; k < 27; k++) host::be_to_limbs(w[k], proof + 32 * k);
     host::be_to_limbs(pb[0], pub); host::be_to_limbs(pb[1], pub + 32);
     PlonkOut o;
-    if (!plonk_prepare(key, w, pb, o)) return 0;
+    const unsigned long long c0 = zkv_fp_mul_counter, d0 = zkv_mad_counter, e0 = zkv_fr_mul_counter;
+    const bool okp = plonk_prepare(key, w, pb, o);
+    g_counts[0] = zkv_fp_mul_counter - c0; g_counts[1] = zkv_fr_mul_counter - e0; g_counts[2] = zkv_mad_counter - d0;
+    if (!okp) return 0;
     memset(out128, 0, 128);
     uint32_t r[8];
     if (!o.d_inf) { fp_to_raw(r, o.d.x); wr_be(out128, r); fp_to_raw(r, o.d.y); wr_be(out128 + 32, r); }

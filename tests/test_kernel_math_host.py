@@ -386,6 +386,12 @@ def _stage_mul_counts(hs, hs_pair, real_proofs):
         # from the one-proof-per-lane build, miller and finalexp from the lane-pair build (both lanes)
         out[vm]['mads_pair_pipeline'] = {'prep': int(lane_mads[0]), 'msm': int(lane_mads[1]), 'miller': int(pair_mads[1]), 'finalexp': int(pair_mads[2])}
         out[vm]['total_pair_pipeline_mads'] = sum(out[vm]['mads_pair_pipeline'].values())
+        if vm == 'sp1':
+            # the pairing part of a PLONK verification on the same kernels: two FIXED pairs, no variable pair (flags A_INF | B_INF); the
+            # product is not 1 for these inputs, which changes nothing about the work
+            assert hs_pair.hs2_pairing(t, fl.value | 2 | 4, norm, b, C.byref(sub)) in (0, 1)
+            hs_pair.hs2_stage_mads(pair_mads); hs_pair.hs2_stage_muls(pair)
+            out['fixed_pairs_only'] = {'miller_mads': int(pair_mads[1]), 'finalexp_mads': int(pair_mads[2]), 'miller_muls': int(pair[1]), 'finalexp_muls': int(pair[2])}
         # the pipeline has no separate subgroup check (the Miller loop's closing test does it: 12 / 16 multiplications inside
         # 'miller'); 'g2chk' is the classical test that only the 16-lane kernels of small chunks still launch, outside both totals
         out[vm]['total_lane_pipeline'] = sum(v for k, v in out[vm]['lane'].items() if k != 'g2chk')

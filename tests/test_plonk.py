@@ -132,6 +132,27 @@ def test_kernel_math_on_the_host_matches_the_model(cases, hsp):
     assert n > 60
 
 
+def test_prep_stage_op_counts(cases, pool, hsp):
+    """Fp / Fr multiplications and multiply-adds of the pre-pairing stage for a valid proof, counted by the host build of the function
+    k_plonk_prep runs (tests/golden/plonk_stage_counts.json; regenerate with ZKV_WRITE_MUL_COUNTS=1): the work figure of the PLONK bench
+    line's roofline.  The pairing part is the Groth16 pipeline's (two fixed pairs, no variable pair): counted by the lane-pair host build."""
+    vk = H(pool['vk'])
+    p0 = pool['proofs'][0]
+    pub = H(p0['vkey']) + m.be32(m.sp1_hash_public_values(H(p0['public_values'])))
+    out = C.create_string_buffer(128)
+    assert hsp.hsp_prepare(vk, len(vk), H(p0['proof'])[4:], pub, out) == 1
+    cnt = (C.c_ulonglong * 3)(); hsp.hsp_prepare_counts(cnt)
+    got = {'prep_fp_muls': int(cnt[0]), 'prep_fr_muls': int(cnt[1]), 'prep_mads': int(cnt[2])}
+    path = os.path.join(HERE, 'golden', 'plonk_stage_counts.json')
+    if os.environ.get('ZKV_WRITE_MUL_COUNTS'):
+        json.dump(got, open(path, 'w'), indent=1, sort_keys=True)
+    want = json.load(open(path))
+    # data-dependent parts (window digits that are zero skip an addition): a few per cent between proofs
+    for k in got:
+        assert abs(got[k] - want[k]) <= 0.05 * want[k], (k, got[k], want[k])
+    assert 10000 < got['prep_fp_muls'] < 25000 and 100 < got['prep_fr_muls'] < 3000
+
+
 def test_plonk_entry_points_without_a_device(cases):
     from stylus_zkvm_verifiers_amd import _lib
     L = _lib.lib()

@@ -29,6 +29,20 @@ __global__ void k(uint32_t* out, uint32_t seed) {
             if (OP == 10) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a[u]) : "v"(b[u]));
             if (OP == 11) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(a[u]) : "v"(b[u]));
             if (OP == 12) asm volatile("v_dot4_u32_u8 %0, %0, %1, %0" : "+v"(a[u]) : "v"(b[u]));
+            // round 3: is the lone-wave mad rate (10.5 cycles against 6.9 for v_mul_lo) a WAW stall on the carry-out SGPR pair?
+            if (OP == 13) {
+                if ((u & 3) == 0) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(acc[u]) : "v"(a[u]), "v"(b[u]) : "s20", "s21");
+                if ((u & 3) == 1) asm volatile("v_mad_u64_u32 %0, s[22:23], %1, %2, %0" : "+v"(acc[u]) : "v"(a[u]), "v"(b[u]) : "s22", "s23");
+                if ((u & 3) == 2) asm volatile("v_mad_u64_u32 %0, s[24:25], %1, %2, %0" : "+v"(acc[u]) : "v"(a[u]), "v"(b[u]) : "s24", "s25");
+                if ((u & 3) == 3) asm volatile("v_mad_u64_u32 %0, s[26:27], %1, %2, %0" : "+v"(acc[u]) : "v"(a[u]), "v"(b[u]) : "s26", "s27");
+            }
+            if (OP == 14) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(acc[u]) : "v"(a[u]), "v"(b[u]) : "s20", "s21");
+            if (OP == 15) asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(acc[u]));
+            if (OP == 16) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[u]) : "v"(acc[(u + 1) % U]));
+            if (OP == 17) asm volatile("v_alignbit_b32 %0, %0, %1, 29" : "+v"(a[u]) : "v"(b[u]));
+            if (OP == 18) asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(a[u]));
+            if (OP == 19) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[u]) : "v"(b[u]));
+            if (OP == 20) asm volatile("v_mad_u64_u32 %0, vcc, %1, s30, %0" : "+v"(acc[u]) : "v"(a[u]) : "vcc");
         }
     }
     uint32_t r = 0;
@@ -77,5 +91,13 @@ int main() {
     run<6, 4>("v_fma_f64", 1, d_out, clk);
     run<11, 4>("v_pk_mul_lo_u16", 1, d_out, clk);
     run<12, 4>("v_dot4_u32_u8", 1, d_out, clk);
+    run<14, 8>("v_mad_u64 sdst fixed s[20:21]", 1, d_out, clk);
+    run<13, 8>("v_mad_u64 sdst rotating x4", 1, d_out, clk);
+    run<20, 8>("v_mad_u64 sgpr multiplier", 1, d_out, clk);
+    run<15, 8>("v_lshrrev_b64", 1, d_out, clk);
+    run<16, 8>("v_lshl_add_u64", 1, d_out, clk);
+    run<17, 8>("v_alignbit_b32", 1, d_out, clk);
+    run<18, 8>("v_and_b32 (VOP2 literal)", 1, d_out, clk);
+    run<19, 8>("v_mov_b32_dpp", 1, d_out, clk);
     return 0;
 }
