@@ -8,17 +8,19 @@
 
 namespace zkv {
 
-constexpr int WIDE_GROUP = 16;                          // lanes per proof
-constexpr int WIDE_PER_BLOCK = ZKV_BLOCK / WIDE_GROUP;  // proofs per wavefront
-
-struct WideLane { size_t i; uint32_t g, half; int q; };
-__device__ __forceinline__ WideLane wide_lane() {
+// SLICES = 1: 16 lanes per proof, four proofs per wavefront (chunks of at most ZKV_WIDE_BELOW proofs).
+// SLICES = 4: 64 lanes per proof -- one proof per wavefront, the mapping BASELINE.json's north star names -- for chunks of at most
+// ZKV_WAVE_BELOW proofs (default 1,024: one wavefront per SIMD), where nothing but the proof's own latency is left to win.
+struct WideLane { size_t i; uint32_t g, half; WL w; };
+template <int SLICES> __device__ __forceinline__ WideLane wide_lane() {
+    constexpr int GROUP = 16 * SLICES, PER_BLOCK = ZKV_BLOCK / GROUP;
     WideLane w;
-    w.g = threadIdx.x / WIDE_GROUP;
+    w.g = threadIdx.x / GROUP;
     w.half = threadIdx.x & 1u;
-    w.q = (int)((threadIdx.x >> 1) & 7u);
-    if (w.q >= 6) w.q -= 6;                             // pairs 6 and 7 shadow pairs 0 and 1
-    w.i = (size_t)blockIdx.x * WIDE_PER_BLOCK + w.g;
+    w.w.q = (int)((threadIdx.x >> 1) & 7u);
+    if (w.w.q >= 6) w.w.q -= 6;                         // pairs 6 and 7 shadow pairs 0 and 1
+    w.w.s = (int)((threadIdx.x % GROUP) >> 4);
+    w.i = (size_t)blockIdx.x * PER_BLOCK + w.g;
     return w;
 }
 __device__ __forceinline__ Fp2 ld_b_w(const Workspace& ws, int word0, size_t i, uint32_t half) {
@@ -26,48 +28,72 @@ __device__ __forceinline__ Fp2 ld_b_w(const Workspace& ws, int word0, size_t i, 
     return r;
 }
 
-__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller_w(size_t n, const VkTables* __restrict__ vk, Workspace ws) {
-    constexpr int SLOT = 96 + 48 + 13 * 16;                // per proof: f (6 Fp2), T (3 Fp2), 13 scratch Fp2, both components
-    __shared__ uint32_t lds[WIDE_PER_BLOCK * SLOT];
-    const WideLane w = wide_lane();
+template <int SLICES> __device__ __forceinline__ void miller_w_body(size_t n, const VkTables* __restrict__ vk, const Workspace& ws, uint32_t* lds) {
+    constexpr int SLOT = 96 + 48 + 13 * 16 + (SLICES > 1 ? SLICES * 96 : 0);   // per proof: f (6 Fp2), T (3 Fp2), 13 scratch Fp2, the slices' rows
+    const WideLane w = wide_lane<SLICES>();
     if (w.i >= n) return;
     const uint32_t flags = ws.flags[w.i];
-    if (!(flags & FL_ALIVE)) return;        // the subgroup check of B may still be running: its verdict is read by k_finalexp_w
+    if (!(flags & FL_ALIVE)) return;        // the subgroup check of B may still be running: its verdict is read by the final exponentiation
     G1Norm nm;
     nm.axs = ws_ld(ws.norm, ws.cap, 0, w.i); nm.ays = ws_ld(ws.norm, ws.cap, 8, w.i);
     nm.lxs = ws_ld(ws.norm, ws.cap, 16, w.i); nm.lys = ws_ld(ws.norm, ws.cap, 24, w.i);
     nm.cxs = ws_ld(ws.norm, ws.cap, 32, w.i); nm.cys = ws_ld(ws.norm, ws.cap, 40, w.i);
     Fp2 bx = ld_b_w(ws, 32, w.i, w.half), by = ld_b_w(ws, 48, w.i, w.half);
     uint32_t* base = lds + w.g * SLOT + 8 * w.half;
-    MRef fm = m_ref(base, 1, 16), tm = m_ref(base + 96, 1, 16), sc = m_ref(base + 144, 1, 16);
-    miller_loop_w(*vk, flags, nm, bx, by, fm, tm, sc, w.q);
+    MRef fm = m_ref(base, 1, 16), tm = m_ref(base + 96, 1, 16), sc = m_ref(base + 144, 1, 16), red = m_ref(base + 352, 1, 16);
+    miller_loop_w<SLICES>(*vk, flags, nm, bx, by, fm, tm, sc, w.w, red);
     MRef ab = m_ref((uint32_t*)(vk->f_alpha_beta) + 8 * w.half, 1, 16);
     MRef out = m_ref(ws.f + (size_t)(8 * w.half) * ws.cap + w.i, (uint32_t)ws.cap, 16);
-    w12_mul(out, fm, ab, w.q, false);
+    w12_mul<SLICES>(out, fm, ab, w.w, false, red);
 }
-
-__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_finalexp_w(size_t n, Workspace ws, uint8_t* __restrict__ status) {
-    __shared__ uint32_t lds[WIDE_PER_BLOCK * 96];
-    const WideLane w = wide_lane();
+template <int SLICES> __device__ __forceinline__ void finalexp_w_body(size_t n, const Workspace& ws, uint8_t* __restrict__ status, uint32_t* lds) {
+    constexpr int SLOT = 96 + (SLICES > 1 ? SLICES * 96 : 0);
+    const WideLane w = wide_lane<SLICES>();
     if (w.i >= n) return;
     const uint32_t flags = ws.flags[w.i];
     if (!(flags & FL_ALIVE) || ws.g2bad[w.i]) return;
     const uint32_t st = (uint32_t)ws.cap;
-    MRef acc = m_ref(lds + w.g * 96 + 8 * w.half, 1, 16);
+    MRef acc = m_ref(lds + w.g * SLOT + 8 * w.half, 1, 16), red = m_ref(lds + w.g * SLOT + 96 + 8 * w.half, 1, 16);
     MRef F = m_ref(ws.f + (size_t)(8 * w.half) * ws.cap + w.i, st, 16);
     MRef E = m_ref(ws.fe + (size_t)(8 * w.half) * ws.cap + w.i, st, 16);
-    const bool one = final_exp_is_one_w(F, E, m_off(E, 96), m_off(E, 192), m_off(E, 288), m_off(E, 384), acc, w.q);
-    if ((threadIdx.x & (WIDE_GROUP - 1)) == 0) status[w.i] = one ? ST_OK : ST_VERIFICATION_FAILED;
+    const bool one = final_exp_is_one_w<SLICES>(F, E, m_off(E, 96), m_off(E, 192), m_off(E, 288), m_off(E, 384), acc, w.w, red);
+    if ((threadIdx.x & (16 * SLICES - 1)) == 0) status[w.i] = one ? ST_OK : ST_VERIFICATION_FAILED;
 }
 
-static inline unsigned wide_grid(size_t n) { return (unsigned)((n + WIDE_PER_BLOCK - 1) / WIDE_PER_BLOCK); }
+__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller_w(size_t n, const VkTables* __restrict__ vk, Workspace ws) {
+    __shared__ uint32_t lds[4 * (96 + 48 + 13 * 16)];
+    miller_w_body<1>(n, vk, ws, lds);
+}
+__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_finalexp_w(size_t n, Workspace ws, uint8_t* __restrict__ status) {
+    __shared__ uint32_t lds[4 * 96];
+    finalexp_w_body<1>(n, ws, status, lds);
+}
+// one proof per wavefront: a chunk of at most 1,024 proofs is one wavefront per SIMD, so the whole register file is the kernel's
+__global__ __launch_bounds__(ZKV_BLOCK, 1) void k_miller_w64(size_t n, const VkTables* __restrict__ vk, Workspace ws) {
+    __shared__ uint32_t lds[96 + 48 + 13 * 16 + 4 * 96];
+    miller_w_body<4>(n, vk, ws, lds);
+}
+__global__ __launch_bounds__(ZKV_BLOCK, 1) void k_finalexp_w64(size_t n, Workspace ws, uint8_t* __restrict__ status) {
+    __shared__ uint32_t lds[96 + 4 * 96];
+    finalexp_w_body<4>(n, ws, status, lds);
+}
+
+static inline unsigned wide_grid(size_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 void launch_miller_w(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_miller_w, dim3(wide_grid(n)), dim3(ZKV_BLOCK), 0, s, n, d_tab, ws);
+    hipLaunchKernelGGL(k_miller_w, dim3(wide_grid(n, 4)), dim3(ZKV_BLOCK), 0, s, n, d_tab, ws);
 }
 void launch_finalexp_w(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_finalexp_w, dim3(wide_grid(n)), dim3(ZKV_BLOCK), 0, s, n, ws, status);
+    hipLaunchKernelGGL(k_finalexp_w, dim3(wide_grid(n, 4)), dim3(ZKV_BLOCK), 0, s, n, ws, status);
+}
+void launch_miller_w64(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_miller_w64, dim3(wide_grid(n, 1)), dim3(ZKV_BLOCK), 0, s, n, d_tab, ws);
+}
+void launch_finalexp_w64(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_finalexp_w64, dim3(wide_grid(n, 1)), dim3(ZKV_BLOCK), 0, s, n, ws, status);
 }
 
 }  // namespace zkv

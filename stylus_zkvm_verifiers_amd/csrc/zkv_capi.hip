@@ -112,6 +112,12 @@ static size_t wide_below() {
     const char* e = getenv("ZKV_WIDE_BELOW");
     return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)8192;
 }
+// Chunks of at most this many proofs run the Miller loop and the final exponentiation with ONE PROOF PER WAVEFRONT (k_miller_w64 /
+// k_finalexp_w64: four slices of 16 lanes; 1,024 proofs are one wavefront on every SIMD of the chip).  ZKV_WAVE_BELOW=0 disables it.
+static size_t wave_below() {
+    const char* e = getenv("ZKV_WAVE_BELOW");
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1024;
+}
 
 static bool device_is_gfx950(int dev) {
     hipDeviceProp_t p;
@@ -300,10 +306,11 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
         launch_plonk_prep(a, c->d_pkey, c->ws, s);
         if (timed) { (void)hipEventRecord(c->ev[1], s); (void)hipEventRecord(c->ev[2], s); (void)hipEventRecord(c->ev[3], s); }
         const int pl = c->lanes ? c->lanes : 2;
-        const bool wide_p = pl == 16 || (c->lanes == 0 && a.n <= wide_below());
-        if (wide_p) launch_miller_w(a.n, c->d_tab, c->ws, s); else launch_miller2(a.n, c->d_tab, c->ws, a.status, s);
+        const bool wave_p = pl == 64 || (c->lanes == 0 && a.n <= wave_below());
+        const bool wide_p = wave_p || pl == 16 || (c->lanes == 0 && a.n <= wide_below());
+        if (wave_p) launch_miller_w64(a.n, c->d_tab, c->ws, s); else if (wide_p) launch_miller_w(a.n, c->d_tab, c->ws, s); else launch_miller2(a.n, c->d_tab, c->ws, a.status, s);
         if (timed) (void)hipEventRecord(c->ev[4], s);
-        if (wide_p) launch_finalexp_w(a.n, c->ws, a.status, s); else launch_finalexp2(a.n, c->ws, a.status, s);
+        if (wave_p) launch_finalexp_w64(a.n, c->ws, a.status, s); else if (wide_p) launch_finalexp_w(a.n, c->ws, a.status, s); else launch_finalexp2(a.n, c->ws, a.status, s);
         if (timed) (void)hipEventRecord(c->ev[5], s);
         return;
     }
@@ -311,8 +318,9 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     else if (c->vm == ZKV_VM_GROTH16) launch_prep_groth16(a, c->ws, s);
     else launch_prep_sp1(a, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[1], s);
-    const int lanes = c->lanes ? c->lanes : 2;       // 2 = one proof per lane pair; 16 = one proof per 16 lanes (small chunks)
-    const bool wide = lanes == 16 || (c->lanes == 0 && a.n <= wide_below());
+    const int lanes = c->lanes ? c->lanes : 2;       // 2 = one proof per lane pair; 16 = one proof per 16 lanes (small chunks); 64 = per wavefront (smallest)
+    const bool wave = lanes == 64 || (c->lanes == 0 && a.n <= wave_below());
+    const bool wide = wave || lanes == 16 || (c->lanes == 0 && a.n <= wide_below());
     // Lane-pair kernels: the Miller loop itself is the subgroup test of B (miller_loop_p), there is no separate check; stage time
     // [2] is then 0.  16-lane kernels (small chunks, most of the chip idle): the check (k_g2chk2) only needs the PREP output and only
     // its verdict (ws.g2bad; the MSM owns ws.flags) is needed, by the final exponentiation, so it runs on a second stream beside the
@@ -329,11 +337,13 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     if (timed) (void)hipEventRecord(c->ev[2], s);
     if (wide && !fork) launch_g2chk2(a.n, c->ws, a.status, s);
     if (timed) (void)hipEventRecord(c->ev[3], s);
-    if (wide) launch_miller_w(a.n, c->d_tab, c->ws, s);
+    if (wave) launch_miller_w64(a.n, c->d_tab, c->ws, s);
+    else if (wide) launch_miller_w(a.n, c->d_tab, c->ws, s);
     else launch_miller2(a.n, c->d_tab, c->ws, a.status, s);
     if (timed) (void)hipEventRecord(c->ev[4], s);
     if (fork) (void)hipStreamWaitEvent(s, c->ev_join, 0);     // the final exponentiation reads the verdict of the subgroup check
-    if (wide) launch_finalexp_w(a.n, c->ws, a.status, s);
+    if (wave) launch_finalexp_w64(a.n, c->ws, a.status, s);
+    else if (wide) launch_finalexp_w(a.n, c->ws, a.status, s);
     else launch_finalexp2(a.n, c->ws, a.status, s);
     if (timed) (void)hipEventRecord(c->ev[5], s);
 }
@@ -1511,7 +1521,7 @@ ZKV_EXPORT int zkv_diag_issue_rate(int device, int kind, int waves_per_simd, uin
 // ------------------------------------------------------------------ shared
 ZKV_EXPORT int zkv_ctx_vm(const zkv_ctx* c) { return c ? c->vm : ZKV_ERR_INVALID_ARG; }
 ZKV_EXPORT int zkv_ctx_set_lanes_per_proof(zkv_ctx* c, int lanes) {
-    if (!c || (lanes != 0 && lanes != 2 && lanes != 16)) return ZKV_ERR_INVALID_ARG;
+    if (!c || (lanes != 0 && lanes != 2 && lanes != 16 && lanes != 64)) return ZKV_ERR_INVALID_ARG;
     if (is_sharded(c)) { for (auto* k : c->shards) { const int rc = zkv_ctx_set_lanes_per_proof(k, lanes); if (rc != ZKV_OK) return rc; } return ZKV_OK; }
     std::lock_guard<std::mutex> lk(c->mu);
     c->lanes = lanes;

@@ -87,6 +87,9 @@ void launch_finalexp2(size_t n, const Workspace& ws, uint8_t* status, hipStream_
 // coefficient-parallel small-batch variants (k_wide.hip): one proof per 16 lanes
 void launch_miller_w(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
 void launch_finalexp_w(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
+// one proof per wavefront (k_wide.hip, four slices of 16 lanes): the smallest chunks
+void launch_miller_w64(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
+void launch_finalexp_w64(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
 
 // mixed batches (k_mixed.hip): per-proof VM tag, device-side demultiplexing into two homogeneous sub-batches
 struct MixedArgs {

@@ -13,6 +13,12 @@
 // The line functions spread their independent products over the pairs round by round; the one inversion of the final
 // exponentiation is executed redundantly by every pair from the same inputs, which needs no data exchange at all.  Pairs 6 and 7 of a group shadow
 // pairs 0 and 1 (same loads, same stores).
+//
+// Round 3: ONE PROOF PER WAVEFRONT (the mapping BASELINE.json's north star names) is the same code with S = 4 SLICES of 16 lanes: slice s
+// of pair q forms every S-th term of coefficient q, the partial sums meet in S scratch rows (`red`, LDS) and every slice adds them up --
+// an Fp12 multiplication is 2 rounds of Fp2 products instead of 6, squarings and sparse products 1 instead of 4 / 2 / 3, and the
+// per-proof scalings of the line coefficients (four Fp products per step for the fixed pairs, two for the variable one) run side by
+// side in the slices instead of in sequence.  S = 1 is the 16-lane kernel unchanged (no reduction step is compiled in).
 #pragma once
 #include "zkv_verify.h"
 
@@ -53,6 +59,40 @@ ZKV_HD void wide_sync() {
 #endif
 }
 
+// A lane's place in its proof's group: coefficient q (0..5; pairs 6 and 7 shadow 0 and 1) and slice s (0..S-1).
+struct WL { int q, s; };
+// Sum over the slices of one Fp2 per (slice, pair): every slice parks its part in row s of `red` (S rows of one Fp12 slot each,
+// full layout) and reads all S rows back.  Compiled out for S = 1.
+template <int S> ZKV_HD Fp2 w_reduce(MRef red, const Fp2& part, WL w) {
+    if (S == 1) return part;
+    wide_sync();                                          // the previous readers of these rows are done
+    m_st_f2(m_off(red, 96 * w.s), w.q, part);
+    wide_fence();
+    Fp2 r = m_ld_f2(red, w.q);
+#pragma unroll
+    for (int k = 1; k < S; k++) r = f2_add(r, m_ld_f2(m_off(red, 96 * k), w.q));
+    return r;
+}
+// Up to S values of the form v * k (Fp2 times Fp: one Fp product per lane), one per slice, handed to every slice: out[j] = v[j] * k[j].
+// S = 1 computes them one after the other.
+template <int S, int N> ZKV_HD void w_scale_many(MRef red, const Fp2 (&v)[N], const Fp (&k)[N], Fp2 (&out)[N], WL w) {
+    if (S == 1) {
+#pragma unroll
+        for (int j = 0; j < N; j++) out[j] = f2_mul_fp(v[j], k[j]);
+        return;
+    }
+    static_assert(N <= 4, "one product per slice");
+    Fp2 mv = v[0]; Fp mk = k[0];
+#pragma unroll
+    for (int j = 1; j < N; j++) { mv = f2_sel(w.s == j, v[j], mv); mk = fp_sel(w.s == j, k[j], mk); }
+    const Fp2 p = f2_mul_fp(mv, mk);                      // slices >= N repeat product 0 and park it in a row nobody reads
+    wide_sync();
+    m_st_f2(m_off(red, 96 * w.s), w.q, p);
+    wide_fence();
+#pragma unroll
+    for (int j = 0; j < N; j++) out[j] = m_ld_f2(m_off(red, 96 * j), w.q);
+}
+
 ZKV_HD void w12_set_one(MRef d, int q) { wide_sync(); m_st_f2(d, q, f2_sel(q == 0, f2_one(), f2_zero())); wide_fence(); }
 ZKV_HD void w12_copy(MRef d, MRef a, int q) { Fp2 c = m_ld_f2(a, q); wide_sync(); m_st_f2(d, q, c); wide_fence(); }
 ZKV_HD void w12_conj(MRef d, int q) {                     // in place: negate the h coefficients
@@ -61,13 +101,16 @@ ZKV_HD void w12_conj(MRef d, int q) {                     // in place: negate th
     m_st_f2(d, q, f2_sel(q >= 3, f2_neg(c), c));
     wide_fence();
 }
-// d <- a * b, or a * conj(b) (d may alias a or b)
-ZKV_W_NI void w12_mul(MRef d, MRef a, MRef b, int q, bool conj_b) {
-    const int e = w_pow(q);
+// d <- a * b, or a * conj(b) (d may alias a or b).  Slice s takes the terms i = s, s + S, ...: 6 rounds for S = 1, 2 for S = 4.
+template <int S> ZKV_W_NI void w12_mul(MRef d, MRef a, MRef b, WL w, bool conj_b, MRef red) {
+    const int q = w.q, e = w_pow(q);
     Fp2 accn = f2_zero(), accw = f2_zero();
     const Fp2 zero = f2_zero();
 #pragma unroll 1
-    for (int i = 0; i < 6; i++) {
+    for (int k = 0; k < (6 + S - 1) / S; k++) {
+        const int it = w.s + k * S;
+        const bool valid = it < 6;
+        const int i = valid ? it : 0;
         int j = e - i;
         if (j < 0) j += 6;
         const bool wrap = i + j >= 6;
@@ -75,22 +118,25 @@ ZKV_W_NI void w12_mul(MRef d, MRef a, MRef b, int q, bool conj_b) {
         Fp2 x = m_ld_f2(a, w_mem(i)), y = m_ld_f2(b, mj);
         if (conj_b) y = f2_sel(mj >= 3, f2_neg(y), y);
         Fp2 p = f2_mul(x, y);
-        accw = f2_add(accw, f2_sel(wrap, p, zero));
-        accn = f2_add(accn, f2_sel(wrap, zero, p));
+        accw = f2_add(accw, f2_sel(wrap && valid, p, zero));
+        accn = f2_add(accn, f2_sel(wrap || !valid, zero, p));
     }
+    const Fp2 r = w_reduce<S>(red, f2_add(accn, f2_mul_xi(accw)), w);
     wide_sync();
-    m_st_f2(d, q, f2_add(accn, f2_mul_xi(accw)));
+    m_st_f2(d, q, r);
     wide_fence();
 }
 // f <- f^2 (generic): c_e = sum over unordered {i, j}, i + j = e mod 6, of a_i a_j (twice when i != j): at most four products per
 // pair.  Table entry = i | j << 3 | doubled << 6 | wrapped << 7 | valid << 8 for output power e, term t (index 4 e + t).
-ZKV_W_NI void w12_sqr(MRef f, int q) {
+template <int S> ZKV_W_NI void w12_sqr(MRef f, WL wl, MRef red) {
     const uint16_t TERMS[24] = {256, 489, 482, 411, 328, 490, 483, 0, 336, 265, 491, 420, 344, 337, 492, 0, 352, 345, 274, 429, 360, 353, 346, 0};
-    const int e = w_pow(q);
+    const int q = wl.q, e = w_pow(q);
     Fp2 accn = f2_zero(), accw = f2_zero();
     const Fp2 zero = f2_zero();
+    static_assert(S == 1 || S == 4, "four terms per coefficient: one slice each, or all in one");
 #pragma unroll 1
-    for (int t = 0; t < 4; t++) {
+    for (int k = 0; k < 4 / S; k++) {
+        const int t = wl.s + k * S;
         const uint32_t w = TERMS[4 * e + t];
         Fp2 p = f2_mul(m_ld_f2(f, w_mem((int)(w & 7u))), m_ld_f2(f, w_mem((int)((w >> 3) & 7u))));
         p = f2_sel(((w >> 6) & 1u) != 0, f2_dbl(p), p);
@@ -99,18 +145,31 @@ ZKV_W_NI void w12_sqr(MRef f, int q) {
         accw = f2_add(accw, f2_sel(wrap, p, zero));
         accn = f2_add(accn, f2_sel(wrap, zero, p));
     }
+    const Fp2 r = w_reduce<S>(red, f2_add(accn, f2_mul_xi(accw)), wl);
     wide_sync();
-    m_st_f2(f, q, f2_add(accn, f2_mul_xi(accw)));
+    m_st_f2(f, q, r);
     wide_fence();
 }
 // f <- f^2 for f in the cyclotomic subgroup (Granger-Scott): pair q needs one Fp4 squaring (A + B y)^2, y^2 = xi.
-ZKV_W_NI void w12_cyclo_sqr(MRef f, int q) {
+// S = 4: the two products of the Fp4 squaring (A B and (A + B)(xi B + A)) are formed by the even and the odd slices side by side.
+template <int S> ZKV_W_NI void w12_cyclo_sqr(MRef f, WL w, MRef red) {
+    const int q = w.q;
     const int ia = (q == 0 || q == 4) ? 0 : (q == 2 || q == 3) ? 1 : 3;
     const int ib = ia == 0 ? 4 : ia == 1 ? 5 : 2;
     const bool odd = q >= 3;                              // this pair's result uses 2AB, otherwise A^2 + xi B^2
     Fp2 A = m_ld_f2(f, ia), B = m_ld_f2(f, ib), z = m_ld_f2(f, q);
-    Fp2 ab = f2_mul(A, B);
-    Fp2 s = f2_mul(f2_add(A, B), f2_add(f2_mul_xi(B), A));
+    Fp2 ab, s;
+    if (S == 1) {
+        ab = f2_mul(A, B);
+        s = f2_mul(f2_add(A, B), f2_add(f2_mul_xi(B), A));
+    } else {
+        const bool second = (w.s & 1) != 0;
+        const Fp2 p = f2_mul(f2_sel(second, f2_add(A, B), A), f2_sel(second, f2_add(f2_mul_xi(B), A), B));
+        wide_sync();
+        m_st_f2(m_off(red, 96 * (w.s & 1)), q, p);          // slices 0 and 2 (1 and 3) write the same value
+        wide_fence();
+        ab = m_ld_f2(red, q); s = m_ld_f2(m_off(red, 96), q);
+    }
     Fp2 te = f2_sub(f2_sub(s, ab), f2_mul_xi(ab));
     Fp2 T = f2_sel(odd, f2_dbl(ab), te);
     T = f2_sel(q == 3, f2_mul_xi(T), T);
@@ -120,16 +179,29 @@ ZKV_W_NI void w12_cyclo_sqr(MRef f, int q) {
     wide_fence();
 }
 // f <- f * (c0 + c3 w + c4 w^3); with `one` the constant coefficient is 1 and c0 is not read
-ZKV_W_NI void w12_mul_sparse(MRef f, const Fp2* c0, const Fp2* c3, const Fp2* c4, int q, bool one) {
-    const int e = w_pow(q);
+// S = 4: slice 0 forms a0 c0 (or passes a0 on), slice 1 a1 c3, slice 2 a3 c4, slice 3 contributes zero: one round.
+template <int S> ZKV_W_NI void w12_mul_sparse(MRef f, const Fp2* c0, const Fp2* c3, const Fp2* c4, WL w, bool one, MRef red) {
+    const int q = w.q, e = w_pow(q);
     const int e1 = e >= 1 ? e - 1 : e + 5, e3 = e >= 3 ? e - 3 : e + 3;
     Fp2 a0 = m_ld_f2(f, q), a1 = m_ld_f2(f, w_mem(e1)), a3 = m_ld_f2(f, w_mem(e3));
-    Fp2 t = one ? a0 : f2_mul(a0, *c0);
-    Fp2 p3 = f2_mul(a1, *c3), p4 = f2_mul(a3, *c4);
-    p3 = f2_sel(e < 1, f2_mul_xi(p3), p3);
-    p4 = f2_sel(e < 3, f2_mul_xi(p4), p4);
+    Fp2 r;
+    if (S == 1) {
+        Fp2 t = one ? a0 : f2_mul(a0, *c0);
+        Fp2 p3 = f2_mul(a1, *c3), p4 = f2_mul(a3, *c4);
+        p3 = f2_sel(e < 1, f2_mul_xi(p3), p3);
+        p4 = f2_sel(e < 3, f2_mul_xi(p4), p4);
+        r = f2_add(f2_add(t, p3), p4);
+    } else {
+        const Fp2 x = f2_sel(w.s == 1, a1, f2_sel(w.s == 2, a3, a0));
+        const Fp2 y = f2_sel(w.s == 1, *c3, f2_sel(w.s == 2, *c4, *c0));          // with `one`, c0 aliases c3: slice 0's product is dropped
+        Fp2 p = f2_mul(x, y);
+        p = f2_sel(w.s == 0 && one, a0, p);
+        p = f2_sel((w.s == 1 && e < 1) || (w.s == 2 && e < 3), f2_mul_xi(p), p);
+        p = f2_sel(w.s == 3, f2_zero(), p);
+        r = w_reduce<S>(red, p, w);
+    }
     wide_sync();
-    m_st_f2(f, q, f2_add(f2_add(t, p3), p4));
+    m_st_f2(f, q, r);
     wide_fence();
 }
 // d <- pi^k(a), k = 1, 2, 3
@@ -237,16 +309,27 @@ ZKV_W_NI void w_line_add(MRef Tm, MRef sc, const Fp2* qx, const Fp2* qy, Fp2* l0
 }
 
 // ---------------------------------------------------------------- Miller loop and final exponentiation on wide slots
-ZKV_HD void fixed_line_mul_w(MRef fm, const LineAffC& L, const Fp& xs, const Fp& ys, int q) {
-    Fp2 c3 = f2_mul_fp(f2_const(L.nl), xs), c4 = f2_mul_fp(f2_const(L.c), ys);
-    w12_mul_sparse(fm, &c3, &c3, &c4, q, true);
+// c3 = nl * xs, c4 = c * ys for BOTH fixed pairs of a step in one go (S = 4: one product per slice), then the two sparse products
+template <int S> ZKV_HD void fixed_lines_mul_w(MRef fm, const LineAffC& L0, const LineAffC& L1, const G1Norm& n, bool do_l, bool do_c, WL w, MRef red) {
+    if (!do_l && !do_c) return;
+    const Fp2 v[4] = {f2_const(L0.nl), f2_const(L0.c), f2_const(L1.nl), f2_const(L1.c)};
+    const Fp k[4] = {n.lxs, n.lys, n.cxs, n.cys};
+    Fp2 c[4];
+    w_scale_many<S, 4>(red, v, k, c, w);
+    if (do_l) w12_mul_sparse<S>(fm, &c[0], &c[0], &c[1], w, true, red);
+    if (do_c) w12_mul_sparse<S>(fm, &c[2], &c[2], &c[3], w, true, red);
 }
-ZKV_HD void var_line_mul_w(MRef fm, const Fp2& l0, const Fp2& l1, const Fp2& l3, const Fp& xs, const Fp& ys, int q) {
-    Fp2 c3 = f2_mul_fp(l1, xs), c4 = f2_mul_fp(l3, ys);
-    w12_mul_sparse(fm, &l0, &c3, &c4, q, false);
+template <int S> ZKV_HD void var_line_mul_w(MRef fm, const Fp2& l0, const Fp2& l1, const Fp2& l3, const Fp& xs, const Fp& ys, WL w, MRef red) {
+    const Fp2 v[2] = {l1, l3};
+    const Fp k[2] = {xs, ys};
+    Fp2 c[2];
+    w_scale_many<S, 2>(red, v, k, c, w);
+    w12_mul_sparse<S>(fm, &l0, &c[0], &c[1], w, false, red);
 }
-// Same schedule as miller_loop_m; the running point T lives in the full-layout slot tm, `sc` is the line functions' scratch.
-ZKV_HD void miller_loop_w(const VkTables& vk, uint32_t flags, const G1Norm& n, const Fp2& bx, const Fp2& by, MRef fm, MRef tm, MRef sc, int q) {
+// Same schedule as miller_loop_m; the running point T lives in the full-layout slot tm, `sc` is the line functions' scratch, `red` the
+// S rows of the slices' partial results (unused for S = 1).
+template <int S> ZKV_HD void miller_loop_w(const VkTables& vk, uint32_t flags, const G1Norm& n, const Fp2& bx, const Fp2& by, MRef fm, MRef tm, MRef sc, WL w, MRef red) {
+    const int q = w.q;
     const bool do_ab = !(flags & (FL_A_INF | FL_B_INF));
     const bool do_l = !(flags & FL_L_INF) && !vk.skip_fixed[0], do_c = !(flags & FL_C_INF) && !vk.skip_fixed[1];
     w12_set_one(fm, q);
@@ -256,23 +339,21 @@ ZKV_HD void miller_loop_w(const VkTables& vk, uint32_t flags, const G1Norm& n, c
     int li = 0;
 #pragma unroll 1
     for (int i = ZKV_ATE_NAF_LEN - 2; i >= 0; i--) {
-        if (i != ZKV_ATE_NAF_LEN - 2) w12_sqr(fm, q);
+        if (i != ZKV_ATE_NAF_LEN - 2) w12_sqr<S>(fm, w, red);
         if (do_ab) {
             w_line_dbl(tm, sc, &l0, &l1, &l3, q);
-            var_line_mul_w(fm, l0, l1, l3, n.axs, n.ays, q);
+            var_line_mul_w<S>(fm, l0, l1, l3, n.axs, n.ays, w, red);
         }
-        if (do_l) fixed_line_mul_w(fm, vk.lines[0][li], n.lxs, n.lys, q);
-        if (do_c) fixed_line_mul_w(fm, vk.lines[1][li], n.cxs, n.cys, q);
+        fixed_lines_mul_w<S>(fm, vk.lines[0][li], vk.lines[1][li], n, do_l, do_c, w, red);
         li++;
         int d = ate_naf(i);
         if (d != 0) {
             if (do_ab) {
                 Fp2 qy = d > 0 ? by : nby;
                 w_line_add(tm, sc, &bx, &qy, &l0, &l1, &l3, q);
-                var_line_mul_w(fm, l0, l1, l3, n.axs, n.ays, q);
+                var_line_mul_w<S>(fm, l0, l1, l3, n.axs, n.ays, w, red);
             }
-            if (do_l) fixed_line_mul_w(fm, vk.lines[0][li], n.lxs, n.lys, q);
-            if (do_c) fixed_line_mul_w(fm, vk.lines[1][li], n.cxs, n.cys, q);
+            fixed_lines_mul_w<S>(fm, vk.lines[0][li], vk.lines[1][li], n, do_l, do_c, w, red);
             li++;
         }
     }
@@ -284,10 +365,9 @@ ZKV_HD void miller_loop_w(const VkTables& vk, uint32_t flags, const G1Norm& n, c
     for (int s = 0; s < 2; s++) {
         if (do_ab) {
             w_line_add(tm, sc, &qx[s], &qy[s], &l0, &l1, &l3, q);
-            var_line_mul_w(fm, l0, l1, l3, n.axs, n.ays, q);
+            var_line_mul_w<S>(fm, l0, l1, l3, n.axs, n.ays, w, red);
         }
-        if (do_l) fixed_line_mul_w(fm, vk.lines[0][li], n.lxs, n.lys, q);
-        if (do_c) fixed_line_mul_w(fm, vk.lines[1][li], n.cxs, n.cys, q);
+        fixed_lines_mul_w<S>(fm, vk.lines[0][li], vk.lines[1][li], n, do_l, do_c, w, red);
         li++;
     }
 }
@@ -307,53 +387,55 @@ ZKV_HD void f12m_inv_w(MRef F) {
     wide_fence();
 }
 // acc <- x^u, same digit schedule as exp_u_m
-ZKV_HD void exp_u_w(MRef acc, MRef x, MRef W, int q) {
+template <int S> ZKV_HD void exp_u_w(MRef acc, MRef x, MRef W, WL w, MRef red) {
+    const int q = w.q;
     const MRef X17 = W, X35 = m_off(W, 96);
     w12_copy(acc, x, q);
 #pragma unroll 1
-    for (int k = 0; k < 4; k++) w12_cyclo_sqr(acc, q);
-    w12_mul(X17, acc, x, q, false);
-    w12_copy(acc, X17, q); w12_cyclo_sqr(acc, q);
-    w12_mul(X35, acc, x, q, false);
+    for (int k = 0; k < 4; k++) w12_cyclo_sqr<S>(acc, w, red);
+    w12_mul<S>(X17, acc, x, w, false, red);
+    w12_copy(acc, X17, q); w12_cyclo_sqr<S>(acc, w, red);
+    w12_mul<S>(X35, acc, x, w, false, red);
     { const int t = u_digit(ZKV_U_DIG_LEN - 1); w12_copy(acc, t == 1 ? x : t == 17 ? X17 : X35, q); }
 #pragma unroll 1
     for (int i = ZKV_U_DIG_LEN - 2; i >= 0; i--) {
-        w12_cyclo_sqr(acc, q);
+        w12_cyclo_sqr<S>(acc, w, red);
         const int d = u_digit(i);
         if (d == 0) continue;
         const int m = d < 0 ? -d : d;
-        const MRef S = m == 1 ? x : m == 17 ? X17 : X35;
-        w12_mul(acc, acc, S, q, d < 0);
+        const MRef Sx = m == 1 ? x : m == 17 ? X17 : X35;
+        w12_mul<S>(acc, acc, Sx, w, d < 0, red);
     }
 }
 // Same chain as final_exp_is_one_m.  The inversion and the final comparison run redundantly on every pair.
-ZKV_HD bool final_exp_is_one_w(MRef F, MRef E, MRef Y1, MRef Y3, MRef Y4, MRef W, MRef acc, int q) {
+template <int S> ZKV_HD bool final_exp_is_one_w(MRef F, MRef E, MRef Y1, MRef Y3, MRef Y4, MRef W, MRef acc, WL w, MRef red) {
+    const int q = w.q;
     w12_copy(acc, F, q); w12_conj(acc, q);
     f12m_inv_w(F);
-    w12_mul(acc, acc, F, q, false);          // f^(p^6-1)
+    w12_mul<S>(acc, acc, F, w, false, red);          // f^(p^6-1)
     w12_frob(F, acc, 2, q);
-    w12_mul(E, F, acc, q, false);            // e = ^(p^2+1)
-    exp_u_w(acc, E, W, q); w12_conj(acc, q);              // y0
-    w12_cyclo_sqr(acc, q); w12_copy(Y1, acc, q);          // y1
-    w12_cyclo_sqr(acc, q);                                // y2
-    w12_mul(acc, acc, Y1, q, false); w12_copy(Y3, acc, q);        // y3
-    exp_u_w(acc, Y3, W, q); w12_conj(acc, q); w12_copy(Y4, acc, q);   // y4
-    w12_cyclo_sqr(acc, q); w12_copy(F, acc, q);           // y5
-    exp_u_w(acc, F, W, q);                                // y6
+    w12_mul<S>(E, F, acc, w, false, red);            // e = ^(p^2+1)
+    exp_u_w<S>(acc, E, W, w, red); w12_conj(acc, q);              // y0
+    w12_cyclo_sqr<S>(acc, w, red); w12_copy(Y1, acc, q);          // y1
+    w12_cyclo_sqr<S>(acc, w, red);                                // y2
+    w12_mul<S>(acc, acc, Y1, w, false, red); w12_copy(Y3, acc, q);        // y3
+    exp_u_w<S>(acc, Y3, W, w, red); w12_conj(acc, q); w12_copy(Y4, acc, q);   // y4
+    w12_cyclo_sqr<S>(acc, w, red); w12_copy(F, acc, q);           // y5
+    exp_u_w<S>(acc, F, W, w, red);                                // y6
     w12_conj(Y3, q);
-    w12_mul(acc, acc, Y4, q, false);                      // y7
-    w12_mul(acc, acc, Y3, q, false); w12_copy(Y3, acc, q);        // y8
-    w12_mul(F, acc, Y1, q, false);                        // y9
-    w12_mul(acc, acc, Y4, q, false);                      // y10
-    w12_mul(acc, acc, E, q, false);                       // y11
+    w12_mul<S>(acc, acc, Y4, w, false, red);                      // y7
+    w12_mul<S>(acc, acc, Y3, w, false, red); w12_copy(Y3, acc, q);        // y8
+    w12_mul<S>(F, acc, Y1, w, false, red);                        // y9
+    w12_mul<S>(acc, acc, Y4, w, false, red);                      // y10
+    w12_mul<S>(acc, acc, E, w, false, red);                       // y11
     w12_frob(Y1, F, 1, q);
-    w12_mul(acc, Y1, acc, q, false);                      // y13
+    w12_mul<S>(acc, Y1, acc, w, false, red);                      // y13
     w12_frob(Y3, Y3, 2, q);
-    w12_mul(acc, Y3, acc, q, false);                      // y14
+    w12_mul<S>(acc, Y3, acc, w, false, red);                      // y14
     w12_conj(E, q);
-    w12_mul(E, E, F, q, false);
+    w12_mul<S>(E, E, F, w, false, red);
     w12_frob(E, E, 3, q);                                 // y15
-    w12_mul(acc, E, acc, q, false);
+    w12_mul<S>(acc, E, acc, w, false, red);
     return f12m_is_one(acc);
 }
 

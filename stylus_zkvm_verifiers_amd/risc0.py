@@ -129,8 +129,8 @@ class RiscZeroVerifier:
         return [out[64 * i:64 * i + 64].tobytes() for i in range(n)]
 
     def set_lanes_per_proof(self, lanes):
-        """Kernel mapping of the Fp2-heavy stages: 0 = automatic (lane pairs; 16 lanes per proof for small chunks), 2 = lane pairs,
-        16 = sixteen lanes per proof, 1 = one proof per lane; same results."""
+        """Kernel mapping of the Fp2-heavy stages: 0 = automatic (lane pairs; 16 lanes per proof for small chunks, one proof per
+        wavefront for the smallest), 2 = lane pairs, 16 = sixteen lanes per proof, 64 = one proof per wavefront; same results."""
         _lib.check(self._L.zkv_ctx_set_lanes_per_proof(self._h, lanes), 'zkv_ctx_set_lanes_per_proof')
 
     def reserve(self, n):

@@ -10,8 +10,9 @@
 #include <vector>
 #include "../../stylus_zkvm_verifiers_amd/csrc/zkv_verify.h"
 
-static constexpr int PAIRS = 6;
-static thread_local uint32_t tl_par = 0, tl_pair = 0;
+static constexpr int PAIRS = 6, MAX_SLICES = 4;
+static thread_local uint32_t tl_par = 0, tl_pair = 0;          // tl_pair = slice * PAIRS + coefficient
+static int g_threads = 2 * PAIRS;
 struct Barrier {
     std::atomic<int> cnt{0}, gen{0};
     void wait(int n) {
@@ -20,9 +21,9 @@ struct Barrier {
         else while (gen.load(std::memory_order_acquire) == g) std::this_thread::yield();
     }
 };
-static Barrier g_pair_bar[PAIRS], g_group_bar;
-static volatile uint32_t g_xch[PAIRS][2];
-static uint32_t g_pair_tmp[PAIRS][96];
+static Barrier g_pair_bar[PAIRS * MAX_SLICES], g_group_bar;
+static volatile uint32_t g_xch[PAIRS * MAX_SLICES][2];
+static uint32_t g_pair_tmp[PAIRS * MAX_SLICES][96];
 namespace zkv {
 uint32_t zkv_parity() { return tl_par; }
 uint32_t zkv_partner_u32(uint32_t x) {
@@ -30,38 +31,44 @@ uint32_t zkv_partner_u32(uint32_t x) {
     uint32_t r = g_xch[tl_pair][tl_par ^ 1u]; g_pair_bar[tl_pair].wait(2);
     return r;
 }
-void zkv_wide_host_barrier() { g_group_bar.wait(2 * PAIRS); }
+void zkv_wide_host_barrier() { g_group_bar.wait(g_threads); }
 uint32_t* zkv_wide_host_pair_tmp() { return g_pair_tmp[tl_pair]; }
 }
 #include "../../stylus_zkvm_verifiers_amd/csrc/zkv_tower_wide.h"
 using namespace zkv;
 
-struct Job { const VkTables* t; uint32_t flags; const uint32_t* norm48; const uint32_t* b32; int accept[2 * PAIRS]; };
-// group-shared memory: f, T, scratch (LDS on the device) and the eight Fp12 slots of the final exponentiation (HBM on the device)
-static uint32_t g_lds[96 + 48 + 13 * 16], g_acc[96], g_full[8 * 96];
+struct Job { const VkTables* t; uint32_t flags; const uint32_t* norm48; const uint32_t* b32; int accept[2 * PAIRS * MAX_SLICES]; };
+// group-shared memory: f, T, scratch, the slices' rows (LDS on the device) and the eight Fp12 slots of the final exponentiation (HBM on the device)
+static uint32_t g_lds[96 + 48 + 13 * 16 + MAX_SLICES * 96], g_acc[96 + MAX_SLICES * 96], g_full[8 * 96];
 
-static void lane(Job* j, uint32_t pair, uint32_t par) {
-    tl_pair = pair; tl_par = par;
+template <int S> static void lane(Job* j, uint32_t slice, uint32_t pair, uint32_t par) {
+    tl_pair = slice * PAIRS + pair; tl_par = par;
     const int q = (int)pair;
+    const WL w = {q, (int)slice};
     G1Norm n; Fp* nf[6] = {&n.axs, &n.ays, &n.lxs, &n.lys, &n.cxs, &n.cys};
     for (int k = 0; k < 6; k++) memcpy(nf[k]->v, j->norm48 + 8 * k, 32);
     Fp2 bx, by;
     memcpy(bx.h.v, j->b32 + 8 * par, 32); memcpy(by.h.v, j->b32 + 16 + 8 * par, 32);
     MRef fm = m_ref(g_lds + 8 * par, 1, 16), tm = m_ref(g_lds + 96 + 8 * par, 1, 16), sc = m_ref(g_lds + 144 + 8 * par, 1, 16);
-    miller_loop_w(*j->t, j->flags, n, bx, by, fm, tm, sc, q);
+    MRef red = m_ref(g_lds + 352 + 8 * par, 1, 16), red2 = m_ref(g_acc + 96 + 8 * par, 1, 16);
+    miller_loop_w<S>(*j->t, j->flags, n, bx, by, fm, tm, sc, w, red);
     MRef ab = m_ref((uint32_t*)j->t->f_alpha_beta + 8 * par, 1, 16);
     MRef F = m_ref(g_full + 8 * par, 1, 16), E = m_ref(g_full + 96 + 8 * par, 1, 16), acc = m_ref(g_acc + 8 * par, 1, 16);
-    w12_mul(F, fm, ab, q, false);
-    j->accept[2 * pair + par] = final_exp_is_one_w(F, E, m_off(E, 96), m_off(E, 192), m_off(E, 288), m_off(E, 384), acc, q) ? 1 : 0;
+    w12_mul<S>(F, fm, ab, w, false, red);
+    j->accept[2 * (slice * PAIRS + pair) + par] = final_exp_is_one_w<S>(F, E, m_off(E, 96), m_off(E, 192), m_off(E, 288), m_off(E, 384), acc, w, red2) ? 1 : 0;
 }
 
-// Miller loop + final exponentiation of one proof on the emulated 12-lane group; -1 when the lanes disagree.
-extern "C" int hs3_pairing(const void* tables, uint32_t flags, const uint32_t* norm48, const uint32_t* b32) {
+template <int S> static int run_group(const void* tables, uint32_t flags, const uint32_t* norm48, const uint32_t* b32) {
     Job j; j.t = (const VkTables*)tables; j.flags = flags; j.norm48 = norm48; j.b32 = b32;
+    g_threads = 2 * PAIRS * S;
     std::vector<std::thread> ts;
-    for (uint32_t p = 0; p < PAIRS; p++) for (uint32_t h = 0; h < 2; h++) if (p || h) ts.emplace_back(lane, &j, p, h);
-    lane(&j, 0u, 0u);
+    for (uint32_t sl = 0; sl < (uint32_t)S; sl++) for (uint32_t p = 0; p < PAIRS; p++) for (uint32_t h = 0; h < 2; h++) if (sl || p || h) ts.emplace_back(lane<S>, &j, sl, p, h);
+    lane<S>(&j, 0u, 0u, 0u);
     for (auto& t : ts) t.join();
-    for (int k = 1; k < 2 * PAIRS; k++) if (j.accept[k] != j.accept[0]) return -1;
+    for (int k = 1; k < 2 * PAIRS * S; k++) if (j.accept[k] != j.accept[0]) return -1;
     return j.accept[0];
 }
+// Miller loop + final exponentiation of one proof on the emulated 12-lane group (16 lanes per proof); -1 when the lanes disagree.
+extern "C" int hs3_pairing(const void* tables, uint32_t flags, const uint32_t* norm48, const uint32_t* b32) { return run_group<1>(tables, flags, norm48, b32); }
+// ... and on the emulated one-proof-per-wavefront group: four slices of six pairs, 48 threads
+extern "C" int hs3_pairing_w64(const void* tables, uint32_t flags, const uint32_t* norm48, const uint32_t* b32) { return run_group<4>(tables, flags, norm48, b32); }

@@ -172,6 +172,7 @@ def hs_wide(hs):
         subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wno-unknown-pragmas', '-o', lib, src])
     L = C.CDLL(lib)
     L.hs3_pairing.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.hs3_pairing_w64.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     hs.hs_prepare.restype = C.c_void_p
     return L
 
@@ -203,6 +204,39 @@ def test_sixteen_lane_kernels_on_corpus(hs, hs_pair, hs_wide, verify_corpus, rea
         assert acc3 == acc2 == (1 if c['status'] == 0 else 0), c['name']
         n += 1
     assert n > 30
+
+
+def test_one_proof_per_wavefront_kernels_on_corpus(hs, hs_pair, hs_wide, verify_corpus, real_proofs):
+    """The same code with four slices of 16 lanes -- ONE PROOF PER WAVEFRONT (k_miller_w64 / k_finalexp_w64: every slice forms every
+    fourth term, partial results meet in four scratch rows) -- emulated with 48 host threads: same accept/reject as the lane-pair
+    emulation on both real proofs, on rejects that reach the pairing, and with A or C at infinity."""
+    r0 = real_proofs['risc0']
+    cr, cid = H(r0['control_root']), H(r0['bn254_control_id'])
+    v = m.Risc0Verifier(); v.initialize(cr, cid)
+    n, accepts = 0, 0
+    for c in verify_corpus['cases']:
+        if c['status'] not in (0, 1):
+            continue
+        if c['vm'] == 'risc0':
+            sig = v.signals(m.receipt_claim_ok_digest(H(c['image_id']), H(c['journal_digest'])))
+            args = (0, cr, cid, H(c['seal'])[4:], m.be32(sig[2]), m.be32(sig[3]))
+        else:
+            args = (1, None, None, H(c['proof'])[4:], H(c['vkey']), m.be32(m.sp1_hash_public_values(H(c['public_values']))))
+        fl = C.c_uint32(0); norm = (C.c_uint32 * 48)(); b = (C.c_uint32 * 32)(); sub = C.c_int(0)
+        t = hs.hs_prepare(*args, C.byref(fl), norm, b)
+        if not t:
+            continue
+        acc2 = hs_pair.hs2_pairing(t, fl.value, norm, b, C.byref(sub))
+        if not sub.value:
+            continue
+        if n >= 12 and c['status'] != 0:          # 48 threads in lock step are slow: all accepts, a dozen rejects
+            continue
+        assert hs_wide.hs3_pairing_w64(t, fl.value, norm, b) == acc2 == (1 if c['status'] == 0 else 0), c['name']
+        n += 1; accepts += acc2
+        if accepts == 1:                          # the same proof with A at infinity / with C at infinity: both mappings must still agree
+            for extra in (2, 8):
+                assert hs_wide.hs3_pairing_w64(t, fl.value | extra, norm, b) == hs_pair.hs2_pairing(t, fl.value | extra, norm, b, C.byref(sub))
+    assert n >= 8 and accepts >= 2
 
 
 def test_lane_pair_kernels_on_corpus(hs, hs_pair, verify_corpus, real_proofs):
