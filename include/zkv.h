@@ -293,7 +293,7 @@ int zkv_diag_issue_rate(int device, int kind, int waves_per_simd, uint32_t iters
 int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_* */
 /* Tuning knob (no reference counterpart): kernel mapping of the G2 / Miller / final-exponentiation stages.
  * 0 = automatic (default): one proof per pair of lanes; for chunks of at most ZKV_WIDE_BELOW proofs (environment, default 8192)
- * one proof per 16 lanes, which halves the latency of a small batch; for chunks of at most ZKV_WAVE_BELOW proofs (default 1024)
+ * one proof per 16 lanes, which halves the latency of a small batch; for chunks of at most ZKV_WAVE_BELOW proofs (default 2048)
  * one proof per WAVEFRONT (64 lanes), the lowest latency -- the case of the reference's own API, one proof per call
  * (risc0/verifier.rs:78-92).  2 = always lane pairs; 16 = always 16 lanes per proof; 64 = always one proof per wavefront.  Results
  * are identical.  (The round-1 one-proof-per-lane kernels were retired: 2.53 against 3.11 M proofs/s.) */

@@ -113,10 +113,12 @@ static size_t wide_below() {
     return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)8192;
 }
 // Chunks of at most this many proofs run the Miller loop and the final exponentiation with ONE PROOF PER WAVEFRONT (k_miller_w64 /
-// k_finalexp_w64: four slices of 16 lanes; 1,024 proofs are one wavefront on every SIMD of the chip).  ZKV_WAVE_BELOW=0 disables it.
+// k_finalexp_w64: four slices of 16 lanes; 1,024 proofs are one wavefront on every SIMD of the chip, 2,048 two).  Measured (RISC Zero,
+// profiles/round3_e_latency_threshold_sweep.txt), one proof per wavefront against 16 lanes per proof: 1 proof 2.07 / 3.50 ms, 1,024
+// proofs 2.56 / 3.65, 1,536 3.03 / 3.69, 2,048 3.61 / 3.78, 3,072 5.07 / 3.71.  ZKV_WAVE_BELOW=0 disables it.
 static size_t wave_below() {
     const char* e = getenv("ZKV_WAVE_BELOW");
-    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1024;
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)2048;
 }
 
 static bool device_is_gfx950(int dev) {
