@@ -49,7 +49,8 @@ __global__ __launch_bounds__(ZKV_BLOCK, ZKV_PLONK_WAVES) void k_plonk_prep(PrepA
         h[0] &= 0x1fffffffu;                                                        // & (2^253 - 1), sp1/types.rs:34-38
         for (int j = 0; j < 8; j++) pub[1][7 - j] = h[j];
         PlonkOut o;
-        if (plonk_prepare(*key, w, pub, o)) {
+        const TabRef tab = {a.plonk_tab + i * (size_t)PLONK_TAB_WORDS};             // this proof's contiguous table region (3,840 bytes)
+        if (plonk_prepare(*key, w, pub, o, tab)) {
             // x/y and 1/y of the two points (one inversion), as the Miller loop's fixed pairs expect them
             const Fp one = fp_one();
             const Fp yd = o.d_inf ? one : o.d.y, yq = o.q_inf ? one : o.q.y;

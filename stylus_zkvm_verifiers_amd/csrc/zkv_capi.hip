@@ -64,6 +64,7 @@ struct zkv_ctx {
     // ZKV_VM_SP1_PLONK: parsed verifying key, the SRS's two G2 points (reference word order) and the verifier hash
     PlonkKeyRaw pk_raw; uint8_t pk_g2[256] = {0}, plonk_hash[32] = {0};
     PlonkKey* d_pkey = nullptr;
+    uint32_t* d_plonk_tab = nullptr;                           // per-proof window tables of the PLONK stage (PLONK_TAB_WORDS words per proof in flight)
     // ZKV_VM_MIXED: one RISC Zero and one SP1 verifier behind a per-proof VM tag; mx[] are the demultiplexing buffers
     // Sharded (multi-device) context: `shards` single-device contexts of one verifier behind the ordinary batch entry points
     // (zkv_ctx_create_sharded).  sh[] is the per-shard state of device-resident batches: staging rows on the shard's device, a copy
@@ -146,7 +147,7 @@ static void ctx_free_device(zkv_ctx* c) {
                      (void**)&c->ws.g2bad, (void**)&c->d_blob, (void**)&c->d_a, (void**)&c->d_b, (void**)&c->d_pv, (void**)&c->d_status,
                      (void**)&c->d_recv, (void**)&c->d_off, (void**)&c->d_pvoff, (void**)&c->d_cd[0], (void**)&c->d_cd[1], (void**)&c->d_kind,
                      (void**)&c->d_cdoff[0], (void**)&c->d_cdoff[1], (void**)&c->d_len, (void**)&c->d_pvlen, (void**)&c->d_st_all,
-                     (void**)&c->d_rv_all, (void**)&c->d_inst, (void**)&c->d_inst_idx, (void**)&c->d_pkey};
+                     (void**)&c->d_rv_all, (void**)&c->d_inst, (void**)&c->d_inst_idx, (void**)&c->d_pkey, (void**)&c->d_plonk_tab};
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     for (int k = 0; k < 6; k++) { if (c->hb[k]) (void)hipFree(c->hb[k]); c->hb[k] = nullptr; c->hb_cap[k] = 0; }
     for (int k = 0; k < 20; k++) { if (c->mx[k]) (void)hipFree(c->mx[k]); c->mx[k] = nullptr; c->mx_cap[k] = 0; }
@@ -251,7 +252,8 @@ static int ctx_reserve(zkv_ctx* c, size_t want) {
     if (cap > limit) cap = limit;
     void** bufs[] = {(void**)&c->ws.prep, (void**)&c->ws.norm, (void**)&c->ws.f, (void**)&c->ws.fe, (void**)&c->ws.flags, (void**)&c->ws.g2bad,
                      (void**)&c->d_a, (void**)&c->d_b, (void**)&c->d_status, (void**)&c->d_recv, (void**)&c->d_off, (void**)&c->d_pvoff,
-                     (void**)&c->d_inst_idx, (void**)&c->d_len, (void**)&c->d_pvlen, (void**)&c->d_kind, (void**)&c->d_cdoff[0], (void**)&c->d_cdoff[1]};
+                     (void**)&c->d_inst_idx, (void**)&c->d_len, (void**)&c->d_pvlen, (void**)&c->d_kind, (void**)&c->d_cdoff[0], (void**)&c->d_cdoff[1],
+                     (void**)&c->d_plonk_tab};
     for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
     c->ws.cap = 0;
     if (hipMalloc(&c->ws.prep, sizeof(uint32_t) * WS_PREP_WORDS * cap) != hipSuccess ||
@@ -266,7 +268,8 @@ static int ctx_reserve(zkv_ctx* c, size_t want) {
         hipMalloc(&c->d_inst_idx, sizeof(uint32_t) * cap) != hipSuccess ||
         hipMalloc(&c->d_len, sizeof(uint32_t) * cap) != hipSuccess || hipMalloc(&c->d_pvlen, sizeof(uint32_t) * cap) != hipSuccess ||
         hipMalloc(&c->d_kind, cap) != hipSuccess || hipMalloc(&c->d_cdoff[0], sizeof(uint64_t) * (cap + 1)) != hipSuccess ||
-        hipMalloc(&c->d_cdoff[1], sizeof(uint64_t) * (cap + 1)) != hipSuccess) {
+        hipMalloc(&c->d_cdoff[1], sizeof(uint64_t) * (cap + 1)) != hipSuccess ||
+        (c->vm == ZKV_VM_SP1_PLONK && hipMalloc(&c->d_plonk_tab, sizeof(uint32_t) * PLONK_TAB_WORDS * cap) != hipSuccess)) {
         (void)hipGetLastError();
         return ZKV_ERR_OOM;
     }
@@ -305,7 +308,9 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     if (c->vm == ZKV_VM_SP1_PLONK) {
         // PLONK: the prep stage does everything up to the two G1 points of the final check (transcript, scalar algebra, MSMs);
         // no per-proof G2 point, so no subgroup check, and no vk_x stage
-        launch_plonk_prep(a, c->d_pkey, c->ws, s);
+        PrepArgs ap = a;
+        ap.plonk_tab = c->d_plonk_tab;
+        launch_plonk_prep(ap, c->d_pkey, c->ws, s);
         if (timed) { (void)hipEventRecord(c->ev[1], s); (void)hipEventRecord(c->ev[2], s); (void)hipEventRecord(c->ev[3], s); }
         const int pl = c->lanes ? c->lanes : 2;
         const bool wave_p = pl == 64 || (c->lanes == 0 && a.n <= wave_below());
@@ -578,7 +583,9 @@ static int run_sharded_dev(zkv_ctx* c, size_t n, const DevRow* rows, int n_rows,
     }
     const size_t used = shards_used(c, n);
     const bool force = env_size("ZKV_SHARD_FORCE_STAGING", 0) != 0;         // tests: take the peer-copy path on a one-GPU box
-    const size_t first = env_size("ZKV_SHARD_FIRST_PIECE", (size_t)1 << 16);
+    // first piece of a staged range: ZKV_SHARD_FIRST_PIECE when set, else half the range for ranges of at least 2^17 proofs (small
+    // launches run the stage kernels below their rate, which costs more than the transfer a smaller first piece would hide)
+    const size_t first_env = env_size("ZKV_SHARD_FIRST_PIECE", 0);
     std::vector<int> rc(used, ZKV_OK);
     auto one = [&](size_t k) -> int {
         zkv_ctx* kid = c->shards[k];
@@ -599,7 +606,8 @@ static int run_sharded_dev(zkv_ctx* c, size_t n, const DevRow* rows, int n_rows,
         // two pieces: the first (at most `first` proofs) is what the kernels wait for, the rest travels behind its kernels
         size_t pc[3] = {0, m, m};
         int np = 1;
-        if (staged && first && m > 2 * first) { pc[1] = first; np = 2; }
+        const size_t first = first_env ? first_env : (m >= ((size_t)1 << 17) ? m / 2 : 0);
+        if (staged && first && m >= 2 * first) { pc[1] = first; np = 2; }
         if (staged) {
             for (int q = 0; q < np; q++) {
                 for (int j = 0; j < n_rows; j++)

@@ -52,6 +52,7 @@ struct PrepArgs {
     const uint32_t* pv_len;
     // verifier sets (zkv_risc0_set_*): per-proof instance index; selector and context-level failure come from the table
     const uint32_t* inst; const InstTab* inst_tab; uint32_t n_inst;
+    uint32_t* plonk_tab;        // PLONK batches: PLONK_TAB_WORDS words per proof for the per-proof window tables of the MSMs (zkv_plonk.h)
     uint32_t not_initialized;   // wire-layer batches on an un-initialised RISC Zero verifier: decodable calls get InvalidInitialization
     uint8_t* status; uint8_t* recv;
 };

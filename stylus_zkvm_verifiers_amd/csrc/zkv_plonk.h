@@ -314,22 +314,51 @@ ZKV_HD void glv_digits(const uint32_t (&m)[5], uint32_t (&dig)[5]) {
 // into two halves below 2^128, so the shared doubling chain has 33 windows = 132 doublings instead of 256, and every window adds
 // +-(|d| P) and +-(|d'| phi(P)) for every term -- every lane of the wavefront takes the same path (a one-bit-per-step loop executes
 // each chord addition for all lanes although only half of them need it).
-struct MsmTable { G1J m[8]; };
-ZKV_HD void plonk_msm_table(MsmTable& tb, const MsmTerm& t) {
+// The per-proof tables of the proof points live in ONE CONTIGUOUS REGION PER LANE (PLONK_TAB_WORDS words; global memory on the device,
+// where the kernel gets it from the context): entry e of table `slot` is 24 consecutive words -- Jacobian (x, y, z) while the table
+// is being built, then affine [x | y | beta x] -- so that a lookup with a lane-dependent digit reads 64 contiguous bytes.  Round 2 kept
+// them in the kernel's private memory, which the hardware interleaves dword by dword across the 64 lanes of a wavefront: a lookup
+// whose digit differs from lane to lane then touches 16 x 64 different cache lines, and the kernel moved 61 GB of HBM traffic per
+// 2^18 proofs (profiles/round3_f_plonk_2p18_rocprofv3_pmc_summary.md) for 0.26 GB of input.
+constexpr int PLONK_TAB_SLOTS = 5;                       // the most proof points any of the four multi-scalar multiplications has
+constexpr int PLONK_TAB_WORDS = PLONK_TAB_SLOTS * 8 * 24;
+struct TabRef { uint32_t* p; };
+ZKV_HD Fp tab_ld(const TabRef& t, int slot, int e, int field) {
+    const uint32_t* q = t.p + ((slot * 8 + e) * 3 + field) * 8;
+    Fp r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 a = ((const uint4*)q)[0], b = ((const uint4*)q)[1];       // 16-byte aligned: the region starts on a 256-byte boundary
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+#else
+    for (int i = 0; i < 8; i++) r.v[i] = q[i];
+#endif
+    return r;
+}
+ZKV_HD void tab_st(const TabRef& t, int slot, int e, int field, const Fp& v) {
+    uint32_t* q = t.p + ((slot * 8 + e) * 3 + field) * 8;
+#if defined(__HIP_DEVICE_COMPILE__)
+    ((uint4*)q)[0] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]); ((uint4*)q)[1] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+#else
+    for (int i = 0; i < 8; i++) q[i] = v.v[i];
+#endif
+}
+ZKV_HD G1J tab_ld_j(const TabRef& t, int slot, int e) { G1J r; r.x = tab_ld(t, slot, e, 0); r.y = tab_ld(t, slot, e, 1); r.z = tab_ld(t, slot, e, 2); return r; }
+ZKV_HD void tab_st_j(const TabRef& t, int slot, int e, const G1J& p) { tab_st(t, slot, e, 0, p.x); tab_st(t, slot, e, 1, p.y); tab_st(t, slot, e, 2, p.z); }
+// multiples P .. 8P of one proof point, Jacobian
+ZKV_HD void plonk_msm_table(const TabRef& tb, int slot, const MsmTerm& t) {
     G1J p; p.x = t.x; p.y = t.y; p.z = fp_one();
-    tb.m[0] = p;
-    tb.m[1] = g1j_dbl(p);
-    tb.m[2] = g1j_add_affine(tb.m[1], t.x, t.y);
-    tb.m[3] = g1j_dbl(tb.m[1]);
-    tb.m[4] = g1j_add_affine(tb.m[3], t.x, t.y);
-    tb.m[5] = g1j_dbl(tb.m[2]);
-    tb.m[6] = g1j_add_affine(tb.m[5], t.x, t.y);
-    tb.m[7] = g1j_dbl(tb.m[3]);
+    const G1J m1 = g1j_dbl(p), m3 = g1j_dbl(m1), m2 = g1j_add_affine(m1, t.x, t.y);
+    tab_st_j(tb, slot, 0, p); tab_st_j(tb, slot, 1, m1); tab_st_j(tb, slot, 2, m2); tab_st_j(tb, slot, 3, m3);
+    tab_st_j(tb, slot, 4, g1j_add_affine(m3, t.x, t.y));
+    const G1J m5 = g1j_dbl(m2);
+    tab_st_j(tb, slot, 5, m5);
+    tab_st_j(tb, slot, 6, g1j_add_affine(m5, t.x, t.y));
+    tab_st_j(tb, slot, 7, g1j_dbl(m3));
 }
 // NV: how many of the N terms can be proof points (the others take the key's joint tables): only those get a per-proof table, which
 // is what lives in the lane's private memory (round 2 sized it by N: 7.7 of the kernel's 14.8 KB per lane).
-template <int N, int NV> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&t)[N], int n) {
-    MsmTable tab[NV];
+template <int N, int NV> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&t)[N], int n, const TabRef& tab) {
+    static_assert(NV <= PLONK_TAB_SLOTS, "table region too small");
     uint32_t dig[N][2][5];                                // per half 33 signed digits, packed 4 bits each as d + 8 (0..15)
     uint32_t negs[N];                                     // bit 0 / 1: the first / second half is negative
     int slot[N];                                          // term -> its table in tab[] (proof points), -1 otherwise
@@ -337,7 +366,7 @@ template <int N, int NV> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&
 #pragma unroll 1
     for (int i = 0; i < n; i++) {
         if (t[i].inf) continue;
-        if (!t[i].fixed) plonk_msm_table(tab[slot[i]], t[i]);
+        if (!t[i].fixed) plonk_msm_table(tab, slot[i], t[i]);
         uint32_t m1[5], m2[5], n1, n2;
         glv_split(t[i].k, m1, n1, m2, n2);
         glv_digits(m1, dig[i][0]); glv_digits(m2, dig[i][1]);
@@ -355,7 +384,7 @@ template <int N, int NV> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&
             if (t[i].inf || t[i].fixed) continue;
             const int s = slot[i];
 #pragma unroll 1
-            for (int m = 1; m < 8; m++) { pre[s][m - 1] = run; run = fp_mul(run, tab[s].m[m].z); }
+            for (int m = 1; m < 8; m++) { pre[s][m - 1] = run; run = fp_mul(run, tab_ld(tab, s, m, 2)); }
         }
         Fp inv = fp_inv(run);
 #pragma unroll 1
@@ -365,13 +394,14 @@ template <int N, int NV> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&
 #pragma unroll 1
             for (int m = 7; m >= 1; m--) {
                 const Fp zi = fp_mul(inv, pre[s][m - 1]);
-                inv = fp_mul(inv, tab[s].m[m].z);
+                inv = fp_mul(inv, tab_ld(tab, s, m, 2));
                 const Fp zi2 = fp_sqr(zi);
-                tab[s].m[m].x = fp_mul(tab[s].m[m].x, zi2);
-                tab[s].m[m].y = fp_mul(tab[s].m[m].y, fp_mul(zi2, zi));
-                tab[s].m[m].z = fp_mul(tab[s].m[m].x, beta);
+                const Fp ax = fp_mul(tab_ld(tab, s, m, 0), zi2);
+                tab_st(tab, s, m, 0, ax);
+                tab_st(tab, s, m, 1, fp_mul(tab_ld(tab, s, m, 1), fp_mul(zi2, zi)));
+                tab_st(tab, s, m, 2, fp_mul(ax, beta));
             }
-            tab[s].m[0].z = fp_mul(tab[s].m[0].x, beta);
+            tab_st(tab, s, 0, 2, fp_mul(tab_ld(tab, s, 0, 0), beta));
         }
     }
     G1J acc = g1j_infinity();
@@ -392,8 +422,8 @@ template <int N, int NV> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&
                 continue;
             }
             const int s = slot[i];
-            if (e1) { const int m = (e1 < 0 ? -e1 : e1) - 1; acc = g1j_add_affine(acc, tab[s].m[m].x, e1 < 0 ? fp_neg(tab[s].m[m].y) : tab[s].m[m].y); }
-            if (e2) { const int m = (e2 < 0 ? -e2 : e2) - 1; acc = g1j_add_affine(acc, tab[s].m[m].z, e2 < 0 ? fp_neg(tab[s].m[m].y) : tab[s].m[m].y); }
+            if (e1) { const int m = (e1 < 0 ? -e1 : e1) - 1; const Fp y = tab_ld(tab, s, m, 1); acc = g1j_add_affine(acc, tab_ld(tab, s, m, 0), e1 < 0 ? fp_neg(y) : y); }
+            if (e2) { const int m = (e2 < 0 ? -e2 : e2) - 1; const Fp y = tab_ld(tab, s, m, 1); acc = g1j_add_affine(acc, tab_ld(tab, s, m, 2), e2 < 0 ? fp_neg(y) : y); }
         }
     }
     return g1j_add(acc, start);
@@ -441,7 +471,7 @@ ZKV_HD Fr plonk_hash_to_field(const uint32_t x[8], const uint32_t y[8]) {
 // words: the 27 proof words as canonical limbs.  pub: the two public inputs (program vkey unreduced, public-values hash).
 // Returns false => VerificationFailed.  On success D and Q are the pairing's G1 inputs (Q already negated), either may be infinity.
 struct PlonkOut { G1A d, q; uint32_t d_inf, q_inf; };
-ZKV_HD_NI bool plonk_prepare(const PlonkKey& key, const uint32_t (&w)[27][8], const uint32_t (&pub)[2][8], PlonkOut& out) {
+ZKV_HD_NI bool plonk_prepare(const PlonkKey& key, const uint32_t (&w)[27][8], const uint32_t (&pub)[2][8], PlonkOut& out, const TabRef& tab) {
     if (!key.valid) return false;
     if (!raw_lt_r(pub[0]) || !raw_lt_r(pub[1])) return false;
     const int SC[7] = {12, 13, 14, 15, 16, 19, 24};
@@ -526,7 +556,7 @@ ZKV_HD_NI bool plonk_prepare(const PlonkKey& key, const uint32_t (&w)[27][8], co
         plonk_key_term(t[4], key, PK_S3, _s1); plonk_term(t[5], pp[6], pinf[6], coeff_z);
         plonk_term(t[6], pp[3], pinf[3], k0); plonk_term(t[7], pp[4], pinf[4], k1); plonk_term(t[8], pp[5], pinf[5], k2);
         if (n_c) plonk_term(t[9], pp[9], pinf[9], qcpz);
-        plonk_affine((plonk_msm<10, 5>(qk, t, n_c ? 10 : 9)), lin_a, lin_inf, lin_b);
+        plonk_affine((plonk_msm<10, 5>(qk, t, n_c ? 10 : 9, tab)), lin_a, lin_inf, lin_b);
     }
     // ---- fold the openings at zeta: gamma_kzg = H("gamma" || zeta || digests || values || zu)
     uint32_t zr[8], ch[8];
@@ -554,7 +584,7 @@ ZKV_HD_NI bool plonk_prepare(const PlonkKey& key, const uint32_t (&w)[27][8], co
         if (n_c) plonk_key_term(t[5], key, PK_QCP, g6);
         G1J linj = g1j_infinity();
         if (!lin_inf) { linj.x = lin_a.x; linj.y = lin_a.y; linj.z = fp_one(); }
-        plonk_affine((plonk_msm<6, 3>(linj, t, n_c ? 6 : 5)), fold_a, fold_inf, fold_b);
+        plonk_affine((plonk_msm<6, 3>(linj, t, n_c ? 6 : 5, tab)), fold_a, fold_inf, fold_b);
     }
     // ---- batch the two openings: lambda = H(folded digest || H_zeta || Z || H_zeta_omega || zeta || gamma_kzg) mod r
     s.init();
@@ -574,12 +604,12 @@ ZKV_HD_NI bool plonk_prepare(const PlonkKey& key, const uint32_t (&w)[27][8], co
         plonk_term(t[3], pp[8], pinf[8], fr_mul(lam, fr_mul(zeta, key.gen)));
         G1J fj = g1j_infinity();
         if (!fold_inf) { fj.x = fold_a.x; fj.y = fold_a.y; fj.z = fp_one(); }
-        dj = plonk_msm<4, 3>(fj, t, 4);
+        dj = plonk_msm<4, 3>(fj, t, 4, tab);
         MsmTerm u1[1];
         plonk_term(u1[0], pp[8], pinf[8], lam);
         G1J hz = g1j_infinity();
         if (!pinf[7]) { hz.x = pp[7].x; hz.y = pp[7].y; hz.z = fp_one(); }
-        qj = plonk_msm<1, 1>(hz, u1, 1);
+        qj = plonk_msm<1, 1>(hz, u1, 1, tab);
         qj.y = fp_neg(qj.y);
     }
     g1j_to_affine(dj, out.d, out.d_inf);

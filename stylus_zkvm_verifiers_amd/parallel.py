@@ -240,9 +240,15 @@ def make_verifier(blob, device_index=0):
 
 # ---------------------------------------------------------------- one sharded pass: broadcast context, scatter rows in pieces, verify, gather
 def _pieces_of(lo, hi, first_piece):
-    """Split a shard [lo, hi) into (at most) two contiguous pieces: a first piece of `first_piece` rows whose transfer is exposed, then
-    the rest, whose transfer runs behind the first piece's kernels."""
+    """Split a shard [lo, hi) into (at most) two contiguous pieces: a first piece whose transfer is exposed, then the rest, whose
+    transfer runs behind the first piece's kernels.  first_piece = None picks HALF the shard for shards of at least 2^17 rows and one
+    piece below: the stage kernels lose efficiency on small launches (2^15-proof sub-batches of a mixed piece run at one wavefront per
+    SIMD), which costs more than the transfer a smaller first piece would hide (multi-GPU)."""
     m = hi - lo
+    if first_piece is None:
+        first_piece = m // 2 if m >= (1 << 17) else 0
+        if first_piece:
+            return [(lo, lo + first_piece), (lo + first_piece, hi)]
     if first_piece <= 0 or m <= 2 * first_piece:
         return [(lo, hi)]
     return [(lo, lo + first_piece), (lo + first_piece, hi)]
@@ -271,7 +277,7 @@ def _post_piece(fulls, n_total, widths, device, j, first_piece, src):
     return mine, (dist.batch_isend_irecv(ops) if ops else [])
 
 
-def sharded_step(ctx_blob, root, n_total, verify_fn, dev, cdev, sync=lambda: None, first_piece=1 << 16):
+def sharded_step(ctx_blob, root, n_total, verify_fn, dev, cdev, sync=lambda: None, first_piece=None):
     """One data-parallel pass over a batch held by rank 0.  `ctx_blob` (rank 0; None elsewhere) is broadcast; `root` = list of uint8
     row tensors [n_total, w_k] on `cdev` (rank 0; None elsewhere) is scattered in contiguous shards -- each shard in two pieces, the
     second piece's transfer posted before the first piece is verified --; every rank calls `verify_fn(ctx_blob, *row_tensors_on_dev)`
@@ -325,7 +331,7 @@ def sharded_step(ctx_blob, root, n_total, verify_fn, dev, cdev, sync=lambda: Non
     return out, {'distribute': t1 - t0, 'verify': t2 - t1, 'collect': t3 - t2}
 
 
-def mixed_step(params, root, n_total, verify_fn, dev, cdev, sync=lambda: None, first_piece=1 << 16):
+def mixed_step(params, root, n_total, verify_fn, dev, cdev, sync=lambda: None, first_piece=None):
     """One pass of config 4: rank 0 holds the mixed batch `root` = (vm [n], seals [n,260], in_a [n,32], in_b [n,w]) as uint8
     tensors on `cdev`; the 64 bytes of verifier parameters travel as a CTX_MIXED context blob, the four row arrays are scattered
     (contiguous shards, one direct link per peer, second piece behind the first piece's kernels), every rank verifies its shard with

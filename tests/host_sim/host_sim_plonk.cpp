@@ -36,7 +36,9 @@ int hsp_prepare(const uint8_t* vk, size_t vk_len, const uint8_t* proof, const ui
     host::be_to_limbs(pb[0], pub); host::be_to_limbs(pb[1], pub + 32);
     PlonkOut o;
     const unsigned long long c0 = zkv_fp_mul_counter, d0 = zkv_mad_counter, e0 = zkv_fr_mul_counter;
-    const bool okp = plonk_prepare(key, w, pb, o);
+    static uint32_t tabmem[PLONK_TAB_WORDS];
+    const TabRef tab = {tabmem};
+    const bool okp = plonk_prepare(key, w, pb, o, tab);
     g_counts[0] = zkv_fp_mul_counter - c0; g_counts[1] = zkv_fr_mul_counter - e0; g_counts[2] = zkv_mad_counter - d0;
     if (!okp) return 0;
     memset(out128, 0, 128);

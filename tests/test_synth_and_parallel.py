@@ -147,7 +147,7 @@ def _sharded_worker(rank, world, port, n, first_piece, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,n,first_piece', [(2, 50, 1 << 16), (2, 50, 4), (3, 41, 3), (2, 1, 4)])
+@pytest.mark.parametrize('world,n,first_piece', [(2, 50, 1 << 16), (2, 50, 4), (3, 41, 3), (2, 1, 4), (2, 50, None)])
 def test_sharded_step_broadcasts_caller_keys_and_pipelines_the_scatter(world, n, first_piece):
     """sharded_step over gloo: the caller-supplied key (generic Groth16 blob) reaches every rank, shards arrive in one piece or in
     two (first_piece smaller than half a shard: the second piece's transfer is posted before the first is verified), statuses come
