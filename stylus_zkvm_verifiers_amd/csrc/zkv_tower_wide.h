@@ -18,7 +18,8 @@
 // of pair q forms every S-th term of coefficient q, the partial sums meet in S scratch rows (`red`, LDS) and every slice adds them up --
 // an Fp12 multiplication is 2 rounds of Fp2 products instead of 6, squarings and sparse products 1 instead of 4 / 2 / 3, and the
 // per-proof scalings of the line coefficients (four Fp products per step for the fixed pairs, two for the variable one) run side by
-// side in the slices instead of in sequence.  S = 1 is the 16-lane kernel unchanged (no reduction step is compiled in).
+// side in the PAIRS of a group instead of in sequence on every pair (both mappings).  S = 1 is the 16-lane kernel (no reduction step is
+// compiled in).
 #pragma once
 #include "zkv_verify.h"
 
@@ -73,24 +74,21 @@ template <int S> ZKV_HD Fp2 w_reduce(MRef red, const Fp2& part, WL w) {
     for (int k = 1; k < S; k++) r = f2_add(r, m_ld_f2(m_off(red, 96 * k), w.q));
     return r;
 }
-// Up to S values of the form v * k (Fp2 times Fp: one Fp product per lane), one per slice, handed to every slice: out[j] = v[j] * k[j].
-// S = 1 computes them one after the other.
-template <int S, int N> ZKV_HD void w_scale_many(MRef red, const Fp2 (&v)[N], const Fp (&k)[N], Fp2 (&out)[N], WL w) {
-    if (S == 1) {
-#pragma unroll
-        for (int j = 0; j < N; j++) out[j] = f2_mul_fp(v[j], k[j]);
-        return;
-    }
-    static_assert(N <= 4, "one product per slice");
+// N <= 4 values of the form v * k (Fp2 times Fp: one Fp product per lane) in ONE round: pair q forms product q mod N (every pair of a
+// proof's group needs all N results, and round 2 had every pair form all of them one after the other), parks it in slot q mod N of the
+// line functions' scratch `sc` -- free between a line function and the sparse products -- and reads the N slots back.
+template <int N> ZKV_HD void w_scale_many(MRef sc, const Fp2 (&v)[N], const Fp (&k)[N], Fp2 (&out)[N], int q) {
+    static_assert(N <= 4, "six pairs per group");
+    const int j = q % N;
     Fp2 mv = v[0]; Fp mk = k[0];
 #pragma unroll
-    for (int j = 1; j < N; j++) { mv = f2_sel(w.s == j, v[j], mv); mk = fp_sel(w.s == j, k[j], mk); }
-    const Fp2 p = f2_mul_fp(mv, mk);                      // slices >= N repeat product 0 and park it in a row nobody reads
+    for (int t = 1; t < N; t++) { mv = f2_sel(j == t, v[t], mv); mk = fp_sel(j == t, k[t], mk); }
+    const Fp2 p = f2_mul_fp(mv, mk);
     wide_sync();
-    m_st_f2(m_off(red, 96 * w.s), w.q, p);
+    m_st_f2(sc, j, p);                                    // pairs with the same j (and every slice) write the same value
     wide_fence();
 #pragma unroll
-    for (int j = 0; j < N; j++) out[j] = m_ld_f2(m_off(red, 96 * j), w.q);
+    for (int t = 0; t < N; t++) out[t] = m_ld_f2(sc, t);
 }
 
 ZKV_HD void w12_set_one(MRef d, int q) { wide_sync(); m_st_f2(d, q, f2_sel(q == 0, f2_one(), f2_zero())); wide_fence(); }
@@ -310,20 +308,20 @@ ZKV_W_NI void w_line_add(MRef Tm, MRef sc, const Fp2* qx, const Fp2* qy, Fp2* l0
 
 // ---------------------------------------------------------------- Miller loop and final exponentiation on wide slots
 // c3 = nl * xs, c4 = c * ys for BOTH fixed pairs of a step in one go (S = 4: one product per slice), then the two sparse products
-template <int S> ZKV_HD void fixed_lines_mul_w(MRef fm, const LineAffC& L0, const LineAffC& L1, const G1Norm& n, bool do_l, bool do_c, WL w, MRef red) {
+template <int S> ZKV_HD void fixed_lines_mul_w(MRef fm, MRef sc, const LineAffC& L0, const LineAffC& L1, const G1Norm& n, bool do_l, bool do_c, WL w, MRef red) {
     if (!do_l && !do_c) return;
     const Fp2 v[4] = {f2_const(L0.nl), f2_const(L0.c), f2_const(L1.nl), f2_const(L1.c)};
     const Fp k[4] = {n.lxs, n.lys, n.cxs, n.cys};
     Fp2 c[4];
-    w_scale_many<S, 4>(red, v, k, c, w);
+    w_scale_many<4>(sc, v, k, c, w.q);
     if (do_l) w12_mul_sparse<S>(fm, &c[0], &c[0], &c[1], w, true, red);
     if (do_c) w12_mul_sparse<S>(fm, &c[2], &c[2], &c[3], w, true, red);
 }
-template <int S> ZKV_HD void var_line_mul_w(MRef fm, const Fp2& l0, const Fp2& l1, const Fp2& l3, const Fp& xs, const Fp& ys, WL w, MRef red) {
+template <int S> ZKV_HD void var_line_mul_w(MRef fm, MRef sc, const Fp2& l0, const Fp2& l1, const Fp2& l3, const Fp& xs, const Fp& ys, WL w, MRef red) {
     const Fp2 v[2] = {l1, l3};
     const Fp k[2] = {xs, ys};
     Fp2 c[2];
-    w_scale_many<S, 2>(red, v, k, c, w);
+    w_scale_many<2>(sc, v, k, c, w.q);
     w12_mul_sparse<S>(fm, &l0, &c[0], &c[1], w, false, red);
 }
 // Same schedule as miller_loop_m; the running point T lives in the full-layout slot tm, `sc` is the line functions' scratch, `red` the
@@ -342,18 +340,18 @@ template <int S> ZKV_HD void miller_loop_w(const VkTables& vk, uint32_t flags, c
         if (i != ZKV_ATE_NAF_LEN - 2) w12_sqr<S>(fm, w, red);
         if (do_ab) {
             w_line_dbl(tm, sc, &l0, &l1, &l3, q);
-            var_line_mul_w<S>(fm, l0, l1, l3, n.axs, n.ays, w, red);
+            var_line_mul_w<S>(fm, sc, l0, l1, l3, n.axs, n.ays, w, red);
         }
-        fixed_lines_mul_w<S>(fm, vk.lines[0][li], vk.lines[1][li], n, do_l, do_c, w, red);
+        fixed_lines_mul_w<S>(fm, sc, vk.lines[0][li], vk.lines[1][li], n, do_l, do_c, w, red);
         li++;
         int d = ate_naf(i);
         if (d != 0) {
             if (do_ab) {
                 Fp2 qy = d > 0 ? by : nby;
                 w_line_add(tm, sc, &bx, &qy, &l0, &l1, &l3, q);
-                var_line_mul_w<S>(fm, l0, l1, l3, n.axs, n.ays, w, red);
+                var_line_mul_w<S>(fm, sc, l0, l1, l3, n.axs, n.ays, w, red);
             }
-            fixed_lines_mul_w<S>(fm, vk.lines[0][li], vk.lines[1][li], n, do_l, do_c, w, red);
+            fixed_lines_mul_w<S>(fm, sc, vk.lines[0][li], vk.lines[1][li], n, do_l, do_c, w, red);
             li++;
         }
     }
@@ -365,9 +363,9 @@ template <int S> ZKV_HD void miller_loop_w(const VkTables& vk, uint32_t flags, c
     for (int s = 0; s < 2; s++) {
         if (do_ab) {
             w_line_add(tm, sc, &qx[s], &qy[s], &l0, &l1, &l3, q);
-            var_line_mul_w<S>(fm, l0, l1, l3, n.axs, n.ays, w, red);
+            var_line_mul_w<S>(fm, sc, l0, l1, l3, n.axs, n.ays, w, red);
         }
-        fixed_lines_mul_w<S>(fm, vk.lines[0][li], vk.lines[1][li], n, do_l, do_c, w, red);
+        fixed_lines_mul_w<S>(fm, sc, vk.lines[0][li], vk.lines[1][li], n, do_l, do_c, w, red);
         li++;
     }
 }

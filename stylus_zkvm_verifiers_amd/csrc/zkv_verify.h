@@ -421,7 +421,7 @@ template <class RA> ZKV_HD bool final_exp_is_one_m(MRef F, MRef E, MRef Y1, MRef
 
 #if defined(ZKV_PAIRED)
 // The same final exponentiation for the lane-pair kernel as a PROGRAM of Fp12-level operations (ZKV_FE_PROG, generated from the chain
-// above by gen_constants.py, with x^u on the signed digit set {1, 17, 35}: 269 entries) run by one loop in which every operation body is inlined exactly once -- no Fp12-level calls,
+// above by gen_constants.py, with x^u on the signed digit set {1, 17, 35}: 264 entries) run by one loop in which every operation body is inlined exactly once -- no Fp12-level calls,
 // hence no callee-saved-register frames (see miller_loop_p).  The two hot operations keep the typed-LDS accumulator: the cyclotomic
 // squaring of ACC (189 entries) and ACC <- ACC * S / ACC * conj(S) with S in an HBM slot (48 entries); everything else (32 entries)
 // goes through one generic body in which ACC is addressed through `accm`, a flat view of the same LDS words.
