@@ -79,6 +79,54 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_finalexp_w64(size_t n, Workspa
     finalexp_w_body<4>(n, ws, status, lds);
 }
 
+// Two wavefronts per proof (workgroup of 128 lanes): wavefront 1 steps the running point and tabulates the line coefficients, wavefront 0
+// accumulates f (miller_lines_producer / miller_loop_consumer, zkv_tower_wide.h).  For chunks of at most ZKV_DUAL_BELOW proofs.
+__global__ __launch_bounds__(128, 2) void k_miller_w64d(size_t n, const VkTables* __restrict__ vk, Workspace ws, uint8_t* __restrict__ status) {
+    constexpr int F_WORDS = 96 + 64 + 4 * 96, T_WORDS = 48 + 13 * 16, LINE_WORDS = ZKV_MILLER_STEPS * 48;
+    __shared__ uint32_t lds[F_WORDS + T_WORDS + LINE_WORDS + 4];
+    const size_t i = blockIdx.x;
+    if (i >= n) return;
+    const uint32_t flags = ws.flags[i];
+    if (!(flags & FL_ALIVE)) return;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u, half = lane & 1u;
+    WL w;
+    w.q = (int)((lane >> 1) & 7u);
+    if (w.q >= 6) w.q -= 6;
+    w.s = (int)(lane >> 4);
+    volatile uint32_t* ready = lds + F_WORDS + T_WORDS + LINE_WORDS;
+    MRef lines = m_ref(lds + F_WORDS + T_WORDS + 8 * half, 1, 16);
+    const bool do_ab = !(flags & (FL_A_INF | FL_B_INF));
+    // the counter starts at 0: no barrier is needed for that (LDS is not zeroed), so wavefront 1 clears it and wavefront 0 waits for the
+    // workgroup barrier below -- the only one in the kernel, reached by both wavefronts before anything else
+    if (threadIdx.x == 64) *ready = 0;
+    __syncthreads();
+    if (wave == 1) {
+        if (!do_ab) return;
+        const Fp2 bx = ld_b_w(ws, 32, i, half), by = ld_b_w(ws, 48, i, half);
+        MRef tm = m_ref(lds + F_WORDS + 8 * half, 1, 16), sc = m_ref(lds + F_WORDS + 48 + 8 * half, 1, 16);
+        miller_lines_producer(bx, by, tm, sc, lines, ready, w.q);
+        return;
+    }
+    G1Norm nm;
+    nm.axs = ws_ld(ws.norm, ws.cap, 0, i); nm.ays = ws_ld(ws.norm, ws.cap, 8, i);
+    nm.lxs = ws_ld(ws.norm, ws.cap, 16, i); nm.lys = ws_ld(ws.norm, ws.cap, 24, i);
+    nm.cxs = ws_ld(ws.norm, ws.cap, 32, i); nm.cys = ws_ld(ws.norm, ws.cap, 40, i);
+    uint32_t* base = lds + 8 * half;
+    MRef fm = m_ref(base, 1, 16), sc = m_ref(base + 96, 1, 16), red = m_ref(base + 160, 1, 16);
+    if (!miller_loop_consumer<4>(*vk, flags, nm, fm, sc, lines, ready, w, red)) {
+        if (lane == 0) { ws.g2bad[i] = 1; status[i] = ST_VERIFICATION_FAILED; }     // unreachable unless the producer wavefront died
+        return;
+    }
+    MRef ab = m_ref((uint32_t*)(vk->f_alpha_beta) + 8 * half, 1, 16);
+    MRef out = m_ref(ws.f + (size_t)(8 * half) * ws.cap + i, (uint32_t)ws.cap, 16);
+    w12_mul<4>(out, fm, ab, w, false, red);
+}
+void launch_miller_w64d(size_t n, const VkTables* d_tab, const Workspace& ws, uint8_t* status, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_miller_w64d, dim3((unsigned)n), dim3(128), 0, s, n, d_tab, ws, status);
+}
+
 static inline unsigned wide_grid(size_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 void launch_miller_w(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s) {
     if (!n) return;

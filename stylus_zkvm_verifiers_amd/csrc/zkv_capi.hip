@@ -117,6 +117,12 @@ static size_t wide_below() {
 // k_finalexp_w64: four slices of 16 lanes; 1,024 proofs are one wavefront on every SIMD of the chip, 2,048 two).  Measured (RISC Zero,
 // profiles/round3_e_latency_threshold_sweep.txt), one proof per wavefront against 16 lanes per proof: 1 proof 2.07 / 3.50 ms, 1,024
 // proofs 2.56 / 3.65, 1,536 3.03 / 3.69, 2,048 3.61 / 3.78, 3,072 5.07 / 3.71.  ZKV_WAVE_BELOW=0 disables it.
+// Chunks of at most this many proofs give the Miller loop TWO wavefronts per proof (k_miller_w64d: one steps the running point and
+// tabulates the line coefficients, the other accumulates f).  1,024 proofs are two wavefronts on every SIMD.  ZKV_DUAL_BELOW=0 disables it.
+static size_t dual_below() {
+    const char* e = getenv("ZKV_DUAL_BELOW");
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1024;
+}
 static size_t wave_below() {
     const char* e = getenv("ZKV_WAVE_BELOW");
     return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)2048;
@@ -313,7 +319,7 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
         launch_plonk_prep(ap, c->d_pkey, c->ws, s);
         if (timed) { (void)hipEventRecord(c->ev[1], s); (void)hipEventRecord(c->ev[2], s); (void)hipEventRecord(c->ev[3], s); }
         const int pl = c->lanes ? c->lanes : 2;
-        const bool wave_p = pl == 64 || (c->lanes == 0 && a.n <= wave_below());
+        const bool wave_p = pl == 64 || pl == 128 || (c->lanes == 0 && a.n <= wave_below());      // (no variable pair: nothing for a second wavefront to do)
         const bool wide_p = wave_p || pl == 16 || (c->lanes == 0 && a.n <= wide_below());
         if (wave_p) launch_miller_w64(a.n, c->d_tab, c->ws, s); else if (wide_p) launch_miller_w(a.n, c->d_tab, c->ws, s); else launch_miller2(a.n, c->d_tab, c->ws, a.status, s);
         if (timed) (void)hipEventRecord(c->ev[4], s);
@@ -326,7 +332,8 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     else launch_prep_sp1(a, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[1], s);
     const int lanes = c->lanes ? c->lanes : 2;       // 2 = one proof per lane pair; 16 = one proof per 16 lanes (small chunks); 64 = per wavefront (smallest)
-    const bool wave = lanes == 64 || (c->lanes == 0 && a.n <= wave_below());
+    const bool dual = lanes == 128 || (c->lanes == 0 && a.n <= dual_below());       // 128 = two wavefronts per proof in the Miller loop
+    const bool wave = dual || lanes == 64 || (c->lanes == 0 && a.n <= wave_below());
     const bool wide = wave || lanes == 16 || (c->lanes == 0 && a.n <= wide_below());
     // Lane-pair kernels: the Miller loop itself is the subgroup test of B (miller_loop_p), there is no separate check; stage time
     // [2] is then 0.  16-lane kernels (small chunks, most of the chip idle): the check (k_g2chk2) only needs the PREP output and only
@@ -344,7 +351,8 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     if (timed) (void)hipEventRecord(c->ev[2], s);
     if (wide && !fork) launch_g2chk2(a.n, c->ws, a.status, s);
     if (timed) (void)hipEventRecord(c->ev[3], s);
-    if (wave) launch_miller_w64(a.n, c->d_tab, c->ws, s);
+    if (dual) launch_miller_w64d(a.n, c->d_tab, c->ws, a.status, s);
+    else if (wave) launch_miller_w64(a.n, c->d_tab, c->ws, s);
     else if (wide) launch_miller_w(a.n, c->d_tab, c->ws, s);
     else launch_miller2(a.n, c->d_tab, c->ws, a.status, s);
     if (timed) (void)hipEventRecord(c->ev[4], s);
@@ -1531,7 +1539,7 @@ ZKV_EXPORT int zkv_diag_issue_rate(int device, int kind, int waves_per_simd, uin
 // ------------------------------------------------------------------ shared
 ZKV_EXPORT int zkv_ctx_vm(const zkv_ctx* c) { return c ? c->vm : ZKV_ERR_INVALID_ARG; }
 ZKV_EXPORT int zkv_ctx_set_lanes_per_proof(zkv_ctx* c, int lanes) {
-    if (!c || (lanes != 0 && lanes != 2 && lanes != 16 && lanes != 64)) return ZKV_ERR_INVALID_ARG;
+    if (!c || (lanes != 0 && lanes != 2 && lanes != 16 && lanes != 64 && lanes != 128)) return ZKV_ERR_INVALID_ARG;
     if (is_sharded(c)) { for (auto* k : c->shards) { const int rc = zkv_ctx_set_lanes_per_proof(k, lanes); if (rc != ZKV_OK) return rc; } return ZKV_OK; }
     std::lock_guard<std::mutex> lk(c->mu);
     c->lanes = lanes;

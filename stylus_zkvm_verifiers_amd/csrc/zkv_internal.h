@@ -91,6 +91,8 @@ void launch_finalexp_w(size_t n, const Workspace& ws, uint8_t* status, hipStream
 // one proof per wavefront (k_wide.hip, four slices of 16 lanes): the smallest chunks
 void launch_miller_w64(size_t n, const VkTables* d_tab, const Workspace& ws, hipStream_t s);
 void launch_finalexp_w64(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
+// two wavefronts per proof: one steps the running point and tabulates the lines, the other accumulates f (the very smallest chunks)
+void launch_miller_w64d(size_t n, const VkTables* d_tab, const Workspace& ws, uint8_t* status, hipStream_t s);
 
 // mixed batches (k_mixed.hip): per-proof VM tag, device-side demultiplexing into two homogeneous sub-batches
 struct MixedArgs {

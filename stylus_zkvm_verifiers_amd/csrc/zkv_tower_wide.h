@@ -369,6 +369,76 @@ template <int S> ZKV_HD void miller_loop_w(const VkTables& vk, uint32_t flags, c
         li++;
     }
 }
+// ---------------------------------------------------------------- the Miller loop on TWO wavefronts per proof (k_miller_w64d)
+// The running point T and the tangent / chord coefficients do not depend on the accumulator f: one wavefront (the PRODUCER) steps T
+// through the 88 line steps and leaves every step's coefficients (l0, l1, l3) in a table in LDS, a second wavefront (the CONSUMER)
+// squares f and multiplies the lines in, one proof per wavefront with four slices.  The producer's 3-4 rounds per step were 36 % of the
+// one-wavefront kernel's instructions; it runs ahead (fewer instructions per step than the consumer), so the consumer almost never
+// waits.  The hand-over is a step counter in LDS: the producer writes the coefficients, fences (work-group scope) and publishes
+// `step + 1`; the consumer polls the counter (bounded: a producer that disappeared makes the proof fail, never hang), fences and reads.
+// Both wavefronts derive `do_ab` from the same flags, so either both use the table or neither does.
+template <class RT> ZKV_HD void miller_lines_producer(const Fp2& bx, const Fp2& by, RT tm, MRef sc, MRef lines, volatile uint32_t* ready, int q) {
+    const uint8_t KIND[ZKV_MILLER_STEPS] = ZKV_MILLER_STEP_KIND;
+    m_st_f2(tm, 0, bx); m_st_f2(tm, 1, by); m_st_f2(tm, 2, f2_one());
+    wide_fence();
+    const Fp2 nby = f2_neg(by);
+    Fp2 f1x, f1y, f2x, f2y;
+    g2_frob_affine(f1x, f1y, bx, by);
+    g2_frob2_affine(f2x, f2y, bx, by);
+    f2y = f2_neg(f2y);
+#pragma unroll 1
+    for (int li = 0; li < ZKV_MILLER_STEPS; li++) {
+        const int kind = KIND[li];
+        Fp2 l0, l1, l3;
+        if (kind == 0) w_line_dbl(tm, sc, &l0, &l1, &l3, q);
+        else {
+            const Fp2 qx = f2_sel(kind == 3, f1x, f2_sel(kind == 4, f2x, bx));
+            const Fp2 qy = f2_sel(kind == 1, by, f2_sel(kind == 2, nby, f2_sel(kind == 3, f1y, f2y)));
+            w_line_add(tm, sc, &qx, &qy, &l0, &l1, &l3, q);
+        }
+        const MRef row = m_off(lines, 48 * li);           // three Fp2, full layout; every lane stores its component (same values in every pair)
+        m_st_f2(row, 0, l0); m_st_f2(row, 1, l1); m_st_f2(row, 2, l3);
+        wide_fence();                                     // the coefficients are in LDS before the counter says so
+#if defined(__HIP_DEVICE_COMPILE__)
+        if ((threadIdx.x & 63u) == 0) *ready = (uint32_t)(li + 1);
+#else
+        *ready = (uint32_t)(li + 1);
+#endif
+    }
+}
+// false: the producer never published step `need - 1` (cannot happen unless it died); bounded so that nothing can hang the GPU
+ZKV_HD bool miller_lines_wait(volatile uint32_t* ready, uint32_t need) {
+#pragma unroll 1
+    for (uint32_t spin = 0; spin < (1u << 22); spin++) {
+        if (*ready >= need) return true;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_s_sleep(4);
+#endif
+    }
+    return false;
+}
+template <int S> ZKV_HD bool miller_loop_consumer(const VkTables& vk, uint32_t flags, const G1Norm& n, MRef fm, MRef sc, MRef lines, volatile uint32_t* ready, WL w, MRef red) {
+    const uint8_t KIND[ZKV_MILLER_STEPS] = ZKV_MILLER_STEP_KIND;
+    const int q = w.q;
+    const bool do_ab = !(flags & (FL_A_INF | FL_B_INF));
+    const bool do_l = !(flags & FL_L_INF) && !vk.skip_fixed[0], do_c = !(flags & FL_C_INF) && !vk.skip_fixed[1];
+    w12_set_one(fm, q);
+    bool ok = true;
+#pragma unroll 1
+    for (int li = 0; li < ZKV_MILLER_STEPS; li++) {
+        if (KIND[li] == 0 && li != 0) w12_sqr<S>(fm, w, red);
+        if (do_ab) {
+            ok = miller_lines_wait(ready, (uint32_t)(li + 1)) && ok;
+            wide_fence();
+            const MRef row = m_off(lines, 48 * li);
+            const Fp2 l0 = m_ld_f2(row, 0), l1 = m_ld_f2(row, 1), l3 = m_ld_f2(row, 2);
+            var_line_mul_w<S>(fm, sc, l0, l1, l3, n.axs, n.ays, w, red);
+        }
+        fixed_lines_mul_w<S>(fm, sc, vk.lines[0][li], vk.lines[1][li], n, do_l, do_c, w, red);
+    }
+    return ok;
+}
+
 // F <- F^-1, executed redundantly by every pair (all lanes read the whole value, all write the same result).
 #if !defined(__HIP_DEVICE_COMPILE__)
 uint32_t* zkv_wide_host_pair_tmp();     // host emulation: 96 words shared by the two threads of a pair

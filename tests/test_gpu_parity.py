@@ -207,14 +207,14 @@ def test_both_kernel_mappings_agree_on_a_2p13_batch(zkv, real_proofs):
     jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (n, 1)); jds[flip, 0] ^= 1
     d_seals, d_ids, d_jds = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (seals, ids, jds))
     out = {}
-    for lanes in (2, 16, 64):
+    for lanes in (2, 16, 64, 128):
         v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id'])); v.set_lanes_per_proof(lanes)
         d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
         v.verify_batch_dev(n, d_seals.data_ptr(), d_ids.data_ptr(), d_jds.data_ptr(), d_st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         out[lanes] = d_st.cpu().numpy()
         v.close()
-    assert (out[16] == out[2]).all() and (out[64] == out[2]).all()
+    assert (out[16] == out[2]).all() and (out[64] == out[2]).all() and (out[128] == out[2]).all()
     assert ((out[2] == 0) == ~mut).all()
     k = 1024
     orc = ol.Risc0Oracle(); orc.initialize(H(r['control_root']), H(r['bn254_control_id']))
@@ -774,7 +774,7 @@ def test_sixteen_lanes_per_proof_kernels_match_the_oracle(zkv, real_proofs, veri
     pvs = [H(s['public_values']) if not f else H(s['public_values'])[:-1] + bytes([H(s['public_values'])[-1] ^ 1]) for f in sflip]
     swant, _ = ol.sp1_verify_batch([H(s['vkey'])] * n, pvs, [x.tobytes() for x in proofs], threads=8)
     got = {}
-    for lanes in (16, 64, 2, 0):             # 0 = automatic: these batches are below ZKV_WAVE_BELOW, so one proof per wavefront
+    for lanes in (16, 64, 128, 2, 0):        # 0 = automatic: these batches are below ZKV_DUAL_BELOW, so two wavefronts per proof in the Miller loop
         v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id'])); v.set_lanes_per_proof(lanes)
         st, rv = v.verify_batch([H(c['seal']) for c in rc], [H(c['image_id']) for c in rc], [H(c['journal_digest']) for c in rc])
         assert [int(x) for x in st] == [c['status'] for c in rc], lanes
@@ -787,7 +787,7 @@ def test_sixteen_lanes_per_proof_kernels_match_the_oracle(zkv, real_proofs, veri
         assert (st3 == swant).all(), lanes
         got[lanes] = (st.tobytes(), st3.tobytes(), v.last_stage_ms())
         v.close(); sp.close()
-    assert got[16][:2] == got[2][:2] == got[0][:2] == got[64][:2]
+    assert got[16][:2] == got[2][:2] == got[0][:2] == got[64][:2] == got[128][:2]
     assert ((want == 0) == ~mut).all() and ((swant == 0) == ~smut).all()
 
 
@@ -846,7 +846,7 @@ def test_small_order_g2_points_through_the_pairing_kernels(zkv, r0, sp1, precomp
     seal, proof = H(r['seal']), H(s['proof'])
     seals = [seal[:68] + H(''.join(c['point'])) + seal[196:] for c in pts]
     proofs = [proof[:68] + H(''.join(c['point'])) + proof[196:] for c in pts]
-    for lanes in (2, 16, 64):
+    for lanes in (2, 16, 64, 128):
         r0.set_lanes_per_proof(lanes); sp1.set_lanes_per_proof(lanes)
         st, _ = r0.verify_batch(seals, [H(r['image_id'])] * len(pts), [H(r['journal_digest'])] * len(pts))
         for x, got_st in zip(seals, st):

@@ -190,7 +190,7 @@ def test_plonk_corpus_on_gpu(zkv, cases):
     vk, vh = H(cases['vk']), H(cases['verifier_hash'])
     v = zkv.Sp1PlonkVerifier(vk, vh)
     cs = cases['cases']
-    for lanes in (0, 2, 16, 64):              # automatic (78 cases: one proof per wavefront), lane pairs, 16 lanes, one proof per wavefront
+    for lanes in (0, 2, 16, 64, 128):              # automatic (78 cases: one proof per wavefront), lane pairs, 16 lanes, one proof per wavefront
         v.set_lanes_per_proof(lanes)
         st, rv = v.verify_batch([H(c['vkey']) for c in cs], [H(c['public_values']) for c in cs], [H(c['proof']) for c in cs])
         for c, s, r in zip(cs, st, rv):
