@@ -295,7 +295,7 @@ int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_* */
  * 0 = automatic (default): one proof per pair of lanes; for chunks of at most ZKV_WIDE_BELOW proofs (environment, default 8192)
  * one proof per 16 lanes, which halves the latency of a small batch; for chunks of at most ZKV_WAVE_BELOW proofs (default 2048)
  * one proof per WAVEFRONT (64 lanes), the lowest latency -- the case of the reference's own API, one proof per call
- * (risc0/verifier.rs:78-92) -- and for chunks of at most ZKV_DUAL_BELOW proofs (default 1024) the Miller loop gets a second
+ * (risc0/verifier.rs:78-92) -- and for chunks of at most ZKV_DUAL_BELOW proofs (default 768) the Miller loop gets a second
  * wavefront per proof, which steps the running G2 point ahead of the accumulator.  2 = always lane pairs; 16 = always 16 lanes per
  * proof; 64 = always one proof per wavefront; 128 = always two wavefronts per proof in the Miller loop.  Results are identical.  (The round-1 one-proof-per-lane kernels were retired: 2.53 against 3.11 M proofs/s.) */
 int zkv_ctx_set_lanes_per_proof(zkv_ctx* ctx, int lanes);

@@ -118,10 +118,12 @@ static size_t wide_below() {
 // profiles/round3_e_latency_threshold_sweep.txt), one proof per wavefront against 16 lanes per proof: 1 proof 2.07 / 3.50 ms, 1,024
 // proofs 2.56 / 3.65, 1,536 3.03 / 3.69, 2,048 3.61 / 3.78, 3,072 5.07 / 3.71.  ZKV_WAVE_BELOW=0 disables it.
 // Chunks of at most this many proofs give the Miller loop TWO wavefronts per proof (k_miller_w64d: one steps the running point and
-// tabulates the line coefficients, the other accumulates f).  1,024 proofs are two wavefronts on every SIMD.  ZKV_DUAL_BELOW=0 disables it.
+// tabulates the line coefficients, the other accumulates f).  Measured (RISC Zero, profiles/round3_j_dual_threshold_sweep.txt), two
+// wavefronts against one per proof: 1 proof 1.69 / 2.08 ms, 128 proofs 1.90 / 2.15, 256 1.99 / 2.40, 512 2.10 / 2.49, 768 2.47 / 2.56,
+// 1,024 (two wavefronts on every SIMD from the Miller kernel alone) 2.76 / 2.55.  ZKV_DUAL_BELOW=0 disables it.
 static size_t dual_below() {
     const char* e = getenv("ZKV_DUAL_BELOW");
-    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1024;
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)768;
 }
 static size_t wave_below() {
     const char* e = getenv("ZKV_WAVE_BELOW");
