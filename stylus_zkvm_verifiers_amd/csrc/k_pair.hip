@@ -10,6 +10,13 @@
 
 namespace zkv {
 
+// Wavefronts per workgroup of the two hot kernels.  The wavefronts of a group share nothing (each has its own LDS rows, no barrier);
+// larger groups only mean fewer workgroups for the dispatcher to place (round-3 experiment for the 2^16-proof launch).
+#ifndef ZKV_PAIR_WAVES
+#define ZKV_PAIR_WAVES 1
+#endif
+constexpr int PAIR_BLOCK = ZKV_BLOCK * ZKV_PAIR_WAVES;
+
 __device__ __forceinline__ Fp2 ld_b(const Workspace& ws, int word0, size_t i) {
     Fp2 r; r.h = ws_ld(ws.prep, ws.cap, word0 + 8 * (int)(threadIdx.x & 1u), i);
     return r;
@@ -27,15 +34,16 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_g2chk2(size_t n, Workspace ws,
 
 // The Miller loop is also the subgroup test of B (miller_loop_p, check_b): a proof whose B is outside G2 gets the precompile-failure
 // status here and is skipped by k_finalexp2.  (k_g2chk2 remains for the 16-lane kernels of small chunks.)
-__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller2(size_t n, const VkTables* __restrict__ vk, Workspace ws, uint8_t* __restrict__ status) {
-    __shared__ uint32_t lds[(48 + 24) * ZKV_BLOCK];       // f: 6 Fp per lane, T: 3 Fp per lane, lane-interleaved
-    size_t i = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
+__global__ __launch_bounds__(PAIR_BLOCK, 2) void k_miller2(size_t n, const VkTables* __restrict__ vk, Workspace ws, uint8_t* __restrict__ status) {
+    __shared__ uint32_t lds[(48 + 24) * PAIR_BLOCK];      // per wavefront: f: 6 Fp per lane, T: 3 Fp per lane, lane-interleaved
+    size_t i = ((size_t)blockIdx.x * PAIR_BLOCK + threadIdx.x) >> 1;
     if (i >= n) return;
     uint32_t flags = ws.flags[i];
     if (!(flags & FL_ALIVE)) return;
     const uint32_t par = threadIdx.x & 1u;
-    LRef fm = l_ref(lds + threadIdx.x);
-    LRef tm = l_ref(lds + 48 * ZKV_BLOCK + threadIdx.x);
+    uint32_t* wl = lds + (threadIdx.x >> 6) * ((48 + 24) * ZKV_BLOCK) + (threadIdx.x & 63u);     // this wavefront's rows, this lane's column
+    LRef fm = l_ref(wl);
+    LRef tm = l_ref(wl + 48 * ZKV_BLOCK);
     SoaRef norm = {ws.norm, ws.cap, (uint32_t)i * 4u};                                               // Fp values: both lanes of the pair read them
     SoaRef bsrc = {ws.prep + 32 * ws.cap, ws.cap, (uint32_t)(8 * par * ws.cap + i) * 4u};             // this lane's component of B.x (B.y 16 words on)
     if (!miller_loop_p(vk, flags, norm, bsrc, fm, tm, true)) {
@@ -47,18 +55,19 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller2(size_t n, const VkTabl
     f12m_mul_body(out, fm, ab, false);
 }
 
-__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_finalexp2(size_t n, Workspace ws, uint8_t* __restrict__ status) {
-    __shared__ uint32_t lds[48 * ZKV_BLOCK];
-    size_t i = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
+__global__ __launch_bounds__(PAIR_BLOCK, 2) void k_finalexp2(size_t n, Workspace ws, uint8_t* __restrict__ status) {
+    __shared__ uint32_t lds[48 * PAIR_BLOCK];
+    size_t i = ((size_t)blockIdx.x * PAIR_BLOCK + threadIdx.x) >> 1;
     if (i >= n) return;
     uint32_t flags = ws.flags[i];
     if (!(flags & FL_ALIVE) || ws.g2bad[i]) return;
     const uint32_t par = threadIdx.x & 1u;
     const uint32_t st = (uint32_t)ws.cap;
-    LRef acc = l_ref(lds + threadIdx.x);
+    uint32_t* wl = lds + (threadIdx.x >> 6) * (48 * ZKV_BLOCK) + (threadIdx.x & 63u);
+    LRef acc = l_ref(wl);
     MRef F = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, st, 16);
     MRef E = m_ref(ws.fe + (size_t)(8 * par) * ws.cap + i, st, 16);
-    MRef accm = m_ref(lds + threadIdx.x, 64, 8);          // the accumulator's LDS words through a flat pointer, for the rare generic operations
+    MRef accm = m_ref(wl, 64, 8);                         // the accumulator's LDS words through a flat pointer, for the rare generic operations
     bool one = final_exp_prog_p(F, E, acc, accm);
     if (!par) status[i] = one ? ST_OK : ST_VERIFICATION_FAILED;
 }
@@ -146,6 +155,7 @@ void launch_pairing(size_t n, uint32_t k, const uint8_t* in, const Workspace& ws
 }
 
 static inline unsigned pair_grid(size_t n) { return (unsigned)((2 * n + ZKV_BLOCK - 1) / ZKV_BLOCK); }
+static inline unsigned hot_grid(size_t n) { return (unsigned)((2 * n + PAIR_BLOCK - 1) / PAIR_BLOCK); }
 
 void launch_g2chk2(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s) {
     if (!n) return;
@@ -153,11 +163,11 @@ void launch_g2chk2(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s
 }
 void launch_miller2(size_t n, const VkTables* d_tab, const Workspace& ws, uint8_t* status, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_miller2, dim3(pair_grid(n)), dim3(ZKV_BLOCK), 0, s, n, d_tab, ws, status);
+    hipLaunchKernelGGL(k_miller2, dim3(hot_grid(n)), dim3(PAIR_BLOCK), 0, s, n, d_tab, ws, status);
 }
 void launch_finalexp2(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_finalexp2, dim3(pair_grid(n)), dim3(ZKV_BLOCK), 0, s, n, ws, status);
+    hipLaunchKernelGGL(k_finalexp2, dim3(hot_grid(n)), dim3(PAIR_BLOCK), 0, s, n, ws, status);
 }
 
 }  // namespace zkv

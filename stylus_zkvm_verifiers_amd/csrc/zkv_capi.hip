@@ -1406,6 +1406,7 @@ static int run_precompile(zkv_ctx* c, int kind, size_t n, size_t k, const uint8_
         if (in_sz) HIP_TRY(hipMemcpyAsync(c->d_blob, in + base * in_sz, m * in_sz, hipMemcpyHostToDevice, c->stream));
         if (kind == 0) launch_ecadd(m, c->d_blob, c->d_pv, c->d_status, c->stream);
         else if (kind == 1) launch_ecmul(m, c->d_blob, c->d_pv, c->d_status, c->stream);
+        else if (m <= dual_below()) launch_pairing_w(m, (uint32_t)k, c->d_blob, c->ws, c->d_pv, c->d_status, c->stream);      // few calls: latency
         else launch_pairing(m, (uint32_t)k, c->d_blob, c->ws, c->d_pv, c->d_status, c->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(out + base * out_sz, c->d_pv, m * out_sz, hipMemcpyDeviceToHost, c->stream));

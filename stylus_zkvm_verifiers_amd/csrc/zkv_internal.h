@@ -125,5 +125,7 @@ void launch_diag_issue(int kind, unsigned blocks, uint32_t iters, uint32_t* out,
 void launch_ecadd(size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok, hipStream_t s);
 void launch_ecmul(size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok, hipStream_t s);
 void launch_pairing(size_t n, uint32_t k, const uint8_t* in, const Workspace& ws, uint8_t* result, uint8_t* ok, hipStream_t s);
+// the same for small batches of calls: one call per workgroup of two wavefronts (k_wide.hip)
+void launch_pairing_w(size_t n, uint32_t k, const uint8_t* in, const Workspace& ws, uint8_t* result, uint8_t* ok, hipStream_t s);
 
 }  // namespace zkv

@@ -417,11 +417,12 @@ ZKV_HD bool miller_lines_wait(volatile uint32_t* ready, uint32_t need) {
     }
     return false;
 }
-template <int S> ZKV_HD bool miller_loop_consumer(const VkTables& vk, uint32_t flags, const G1Norm& n, MRef fm, MRef sc, MRef lines, volatile uint32_t* ready, WL w, MRef red) {
+// vkp: the context's tables, or nullptr for a single variable pair without fixed pairs (the ecPairing seam)
+template <int S> ZKV_HD bool miller_loop_consumer(const VkTables* vkp, uint32_t flags, const G1Norm& n, MRef fm, MRef sc, MRef lines, volatile uint32_t* ready, WL w, MRef red) {
     const uint8_t KIND[ZKV_MILLER_STEPS] = ZKV_MILLER_STEP_KIND;
     const int q = w.q;
     const bool do_ab = !(flags & (FL_A_INF | FL_B_INF));
-    const bool do_l = !(flags & FL_L_INF) && !vk.skip_fixed[0], do_c = !(flags & FL_C_INF) && !vk.skip_fixed[1];
+    const bool do_l = vkp && !(flags & FL_L_INF) && !vkp->skip_fixed[0], do_c = vkp && !(flags & FL_C_INF) && !vkp->skip_fixed[1];
     w12_set_one(fm, q);
     bool ok = true;
 #pragma unroll 1
@@ -434,7 +435,7 @@ template <int S> ZKV_HD bool miller_loop_consumer(const VkTables& vk, uint32_t f
             const Fp2 l0 = m_ld_f2(row, 0), l1 = m_ld_f2(row, 1), l3 = m_ld_f2(row, 2);
             var_line_mul_w<S>(fm, sc, l0, l1, l3, n.axs, n.ays, w, red);
         }
-        fixed_lines_mul_w<S>(fm, sc, vk.lines[0][li], vk.lines[1][li], n, do_l, do_c, w, red);
+        if (do_l || do_c) fixed_lines_mul_w<S>(fm, sc, vkp->lines[0][li], vkp->lines[1][li], n, do_l, do_c, w, red);
     }
     return ok;
 }

@@ -116,13 +116,16 @@ def test_precompile_seam_matches_kats_and_oracle(zkv, precompile_kats):
     muls = [c for c in precompile_kats['ecmul']]
     got = pc.ecmul([H(c['input']) for c in muls])
     assert [g.hex() if g is not None else None for g in got] == [c['output'] for c in muls]
-    for k in (1, 2):
-        cases = [c for c in precompile_kats['pairing'] if len(c['input']) == 384 * k]
-        got = pc.pairing([H(c['input']) for c in cases], k)
-        for c, g in zip(cases, got):
-            exp = None if c['output'] is None else (int(c['output'], 16) != 0)
-            assert g == exp, c['name']
-    assert pc.pairing([b''], 0) == [True]                       # empty input: product of no pairings is 1
+    for dual in ('768', '0'):             # few calls: one call per workgroup of two wavefronts (k_pairing_pair_w64d); '0': the lane-pair kernels
+        os.environ['ZKV_DUAL_BELOW'] = dual
+        for k in (1, 2):
+            cases = [c for c in precompile_kats['pairing'] if len(c['input']) == 384 * k]
+            got = pc.pairing([H(c['input']) for c in cases], k)
+            for c, g in zip(cases, got):
+                exp = None if c['output'] is None else (int(c['output'], 16) != 0)
+                assert g == exp, (dual, c['name'])
+        assert pc.pairing([b''], 0) == [True]                       # empty input: product of no pairings is 1
+    del os.environ['ZKV_DUAL_BELOW']
     # random ecMul / ecAdd against the C oracle
     rng = random.Random(99)
     G = (1).to_bytes(32, 'big') + (2).to_bytes(32, 'big')
@@ -147,9 +150,17 @@ def test_groth16_pairing_through_the_precompile_seam(zkv, real_proofs):
     data = (m.be32(ax) + m.be32(ay) + b''.join(w[2:6]) + m.be32(vk['alpha1'][0]) + m.be32(vk['alpha1'][1]) + g2(vk['beta2'])
             + H(r['vk_x'][0]) + H(r['vk_x'][1]) + g2(vk['gamma2']) + w[6] + w[7] + g2(vk['delta2']))
     pc = zkv.Bn254Precompiles()
-    assert pc.pairing([data], 4) == [True]
     bad = bytearray(data); bad[100] ^= 1
-    assert pc.pairing([bytes(bad)], 4) == [ol.ecpairing(bytes(bad)) if ol.ecpairing(bytes(bad)) is None else bool(ol.ecpairing(bytes(bad))[-1])]
+    inf_g1 = bytes(64) + data[64:]                           # first pair with A = infinity: still a valid input, the product changes
+    inf_g2 = data[:64] + bytes(128) + data[192:]
+    off_g2 = data[:64] + data[64:100] + bytes([data[100] ^ 1]) + data[101:]
+    want = lambda x: (lambda r: None if r is None else bool(r[-1]))(ol.ecpairing(x))
+    for dual in ('768', '0'):             # the two-wavefront kernels of small batches, then the lane-pair kernels
+        os.environ['ZKV_DUAL_BELOW'] = dual
+        assert pc.pairing([data], 4) == [True], dual
+        batch = [bytes(bad), inf_g1, inf_g2, off_g2, data, data[:192] + data[:192] + data[384:]]
+        assert pc.pairing(batch, 4) == [want(x) for x in batch], dual
+    del os.environ['ZKV_DUAL_BELOW']
     pc.close()
 
 
@@ -831,15 +842,18 @@ def test_small_order_g2_points_through_the_pairing_kernels(zkv, r0, sp1, precomp
     G1 = (1).to_bytes(32, 'big') + (2).to_bytes(32, 'big')
     calls = [G1 + H(''.join(c['point'])) for c in pts]
     pc = zkv.Bn254Precompiles()
-    got = pc.pairing(calls, 1)
-    for c, call, g in zip(pts, calls, got):
-        want = ol.ecpairing(call)
-        assert (g is not None) == (c['on_twist'] and c['in_subgroup']) == (want is not None), c['point'][0][:16]
-        if g is not None:
-            assert g == bool(want[-1])
-    # the same points paired with infinity on the G1 side: validation happens regardless of the skip (EIP-197)
-    got = pc.pairing([bytes(64) + H(''.join(c['point'])) for c in pts], 1)
-    assert [g is not None for g in got] == [c['on_twist'] and c['in_subgroup'] for c in pts]
+    for dual in ('768', '0'):             # the two-wavefront kernels of small batches (verdict from the producer's final point), then the lane pairs
+        os.environ['ZKV_DUAL_BELOW'] = dual
+        got = pc.pairing(calls, 1)
+        for c, call, g in zip(pts, calls, got):
+            want = ol.ecpairing(call)
+            assert (g is not None) == (c['on_twist'] and c['in_subgroup']) == (want is not None), (dual, c['point'][0][:16])
+            if g is not None:
+                assert g == bool(want[-1])
+        # the same points paired with infinity on the G1 side: validation happens regardless of the skip (EIP-197)
+        got = pc.pairing([bytes(64) + H(''.join(c['point'])) for c in pts], 1)
+        assert [g is not None for g in got] == [c['on_twist'] and c['in_subgroup'] for c in pts], dual
+    del os.environ['ZKV_DUAL_BELOW']
     pc.close()
     r, s = real_proofs['risc0'], real_proofs['sp1']
     orc = ol.Risc0Oracle(); orc.initialize(H(r['control_root']), H(r['bn254_control_id']))
