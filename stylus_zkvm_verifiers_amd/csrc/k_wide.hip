@@ -131,7 +131,7 @@ void launch_miller_w64d(size_t n, const VkTables* d_tab, const Workspace& ws, ui
 // the two-wavefront Miller kernel: one launch per pair index j as in k_pairing_pair (k_pair.hip), but one CALL per workgroup of two
 // wavefronts instead of one call per lane pair -- a single 4-pair call takes 4 x 0.8 + 0.8 ms instead of 4 x 5 + 3 ms.  The producer
 // wavefront's final running point gives the subgroup verdict for Q (miller_point_closes), as in the lane-pair kernels.
-__device__ __forceinline__ bool pair_all_w(bool mine) {
+ZKV_HD bool pair_all_w(bool mine) {
     uint32_t v = mine ? 0u : 1u;
     v |= zkv_partner_u32(v);
     return v == 0;
