@@ -11,7 +11,8 @@
 namespace zkv {
 
 // Wavefronts per workgroup of the two hot kernels.  The wavefronts of a group share nothing (each has its own LDS rows, no barrier);
-// larger groups only mean fewer workgroups for the dispatcher to place (round-3 experiment for the 2^16-proof launch).
+// larger groups only mean fewer workgroups for the dispatcher to place.  Round-3 experiment for the 2^16-proof launch: 13.0 / 12.9 / 12.9 ms
+// per step with 1 / 2 / 4 (184.0 / 187.4 / 183.9 at 2^20; profiles/round3_n_waves_per_workgroup_ab.txt) -- no effect, the default stays 1.
 #ifndef ZKV_PAIR_WAVES
 #define ZKV_PAIR_WAVES 1
 #endif
