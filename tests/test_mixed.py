@@ -412,3 +412,56 @@ def test_config4_full_2p22_batch_on_one_gpu(zkv, mixed, real_proofs):
     from stylus_zkvm_verifiers_amd import _lib
     assert _lib.lib().zkv_chunk_capacity() <= 1 << 20             # so that the sub-batches really cross chunk boundaries
     _config4_through_properties(zkv, mixed, real_proofs, 1 << 21)
+
+
+def _nccl_world1_worker(port, q):
+    """RCCL on this box at all: process group over backend "nccl" with one rank, the collectives bench.py's N > 1 path uses that are
+    defined for a single rank (broadcast, all_reduce, barrier), then one config-4 step under the initialised group."""
+    import json
+    import torch
+    import torch.distributed as dist
+    import stylus_zkvm_verifiers_amd as z
+    from stylus_zkvm_verifiers_amd import parallel, synth
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    rank, local_rank, world = parallel.init_distributed('nccl')           # what bench.py does (backend None picks nccl on a GPU box)
+    assert (rank, world) == (0, 1)
+    if not dist.is_initialized():                                        # init_distributed skips a one-rank world: initialise it here
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend='nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    dev = torch.device('cuda', 0)
+    t = torch.arange(8, dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=0); dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier()
+    blob = parallel.broadcast_context(parallel.pack_context(parallel.CTX_SP1), dev)
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'real_proofs.json')))
+    r, s = g['risc0'], g['sp1']
+    n1 = 600
+    s1, m1, _, f1 = synth.make_batch('sp1', H(s['proof']), n1, 0x5A4B56D1, pool=4, mutate_every=6)
+    vk = np.tile(np.frombuffer(H(s['vkey']), dtype=np.uint8), (n1, 1))
+    pv = np.tile(np.frombuffer(H(s['public_values']), dtype=np.uint8), (n1, 1)); pv[f1, -1] ^= 1
+    root = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (np.ones((n1, 1), dtype=np.uint8), s1, vk, pv)]
+    mv = z.MixedVerifier(H(r['control_root']), H(r['bn254_control_id']), 0)
+    st = torch.full((n1,), 255, dtype=torch.uint8, device=dev)
+
+    def verify_fn(p, vm_t, seals_t, a_t, b_t):
+        mv.verify_batch_dev(int(vm_t.numel()), vm_t.data_ptr(), seals_t.data_ptr(), a_t.data_ptr(), b_t.data_ptr(), 96, 96, st.data_ptr(), 0,
+                            torch.cuda.current_stream().cuda_stream)
+        return st
+    out, _ = parallel.mixed_step(H(r['control_root']) + H(r['bn254_control_id']), root, n1, verify_fn, dev, dev, sync=torch.cuda.synchronize)
+    ok = bool(((out.cpu().numpy() == 0) == ~m1).all()) and parallel.unpack_context(blob)['kind'] == parallel.CTX_SP1 and t.tolist() == list(range(8))
+    q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_backend_initialises_and_a_step_runs_under_it(zkv):
+    """The N > 1 path of bench.py has never met more than one real rank (one-GPU boxes); this at least proves that backend "nccl"
+    (= RCCL) initialises on the box with the device_id binding bench.py uses, that its collectives run, and that a config-4 step runs
+    inside an initialised process group."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_worker, args=(_free_port(), q))
+    p.start()
+    ok = q.get(timeout=600)
+    p.join(timeout=120)
+    assert ok is True and p.exitcode == 0
