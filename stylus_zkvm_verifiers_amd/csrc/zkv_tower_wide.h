@@ -407,12 +407,17 @@ template <class RT> ZKV_HD void miller_lines_producer(const Fp2& bx, const Fp2& 
     }
 }
 // false: the producer never published step `need - 1` (cannot happen unless it died); bounded so that nothing can hang the GPU
+#if !defined(__HIP_DEVICE_COMPILE__)
+void zkv_wide_host_yield();             // host emulation: the producer's threads need the CPU the consumer is spinning on
+#endif
 ZKV_HD bool miller_lines_wait(volatile uint32_t* ready, uint32_t need) {
 #pragma unroll 1
     for (uint32_t spin = 0; spin < (1u << 22); spin++) {
         if (*ready >= need) return true;
 #if defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_s_sleep(4);
+#else
+        zkv_wide_host_yield();
 #endif
     }
     return false;

@@ -173,6 +173,7 @@ def hs_wide(hs):
     L = C.CDLL(lib)
     L.hs3_pairing.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.hs3_pairing_w64.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.hs3_pairing_w64d.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     hs.hs_prepare.restype = C.c_void_p
     return L
 
@@ -208,8 +209,10 @@ def test_sixteen_lane_kernels_on_corpus(hs, hs_pair, hs_wide, verify_corpus, rea
 
 def test_one_proof_per_wavefront_kernels_on_corpus(hs, hs_pair, hs_wide, verify_corpus, real_proofs):
     """The same code with four slices of 16 lanes -- ONE PROOF PER WAVEFRONT (k_miller_w64 / k_finalexp_w64: every slice forms every
-    fourth term, partial results meet in four scratch rows) -- emulated with 48 host threads: same accept/reject as the lane-pair
-    emulation on both real proofs, on rejects that reach the pairing, and with A or C at infinity."""
+    fourth term, partial results meet in four scratch rows) -- emulated with 48 host threads, and the two-wavefront Miller kernel
+    (k_miller_w64d: a producer group steps the running point and fills the line table, a consumer group accumulates f behind the step
+    counter) with 96: same accept/reject as the lane-pair emulation on both real proofs, on rejects that reach the pairing, and with A
+    or C at infinity."""
     r0 = real_proofs['risc0']
     cr, cid = H(r0['control_root']), H(r0['bn254_control_id'])
     v = m.Risc0Verifier(); v.initialize(cr, cid)
@@ -232,10 +235,14 @@ def test_one_proof_per_wavefront_kernels_on_corpus(hs, hs_pair, hs_wide, verify_
         if n >= 12 and c['status'] != 0:          # 48 threads in lock step are slow: all accepts, a dozen rejects
             continue
         assert hs_wide.hs3_pairing_w64(t, fl.value, norm, b) == acc2 == (1 if c['status'] == 0 else 0), c['name']
+        if n < 6 or c['status'] == 0:             # the two-wavefront Miller kernel (producer / consumer around the line table): 96 threads
+            assert hs_wide.hs3_pairing_w64d(t, fl.value, norm, b) == acc2, c['name']
         n += 1; accepts += acc2
         if accepts == 1:                          # the same proof with A at infinity / with C at infinity: both mappings must still agree
             for extra in (2, 8):
-                assert hs_wide.hs3_pairing_w64(t, fl.value | extra, norm, b) == hs_pair.hs2_pairing(t, fl.value | extra, norm, b, C.byref(sub))
+                want = hs_pair.hs2_pairing(t, fl.value | extra, norm, b, C.byref(sub))
+                assert hs_wide.hs3_pairing_w64(t, fl.value | extra, norm, b) == want
+                assert hs_wide.hs3_pairing_w64d(t, fl.value | extra, norm, b) == want
     assert n >= 8 and accepts >= 2
 
 
