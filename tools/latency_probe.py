@@ -21,3 +21,12 @@ st, _ = sp.verify_batch([H(c['vkey']) for c in sc], [H(c['public_values']) for c
 bad = [(c['name'], int(s), c['status']) for c, s in zip(sc, st) if int(s) != c['status']]
 print('sp1 corpus mismatches:', bad[:10], 'of', len(sc), 'stage ms', sp.last_stage_ms())
 t0 = time.time(); ok = v.verify(H(r['seal']), H(r['image_id']), H(r['journal_digest'])); print('single verify', ok, (time.time() - t0) * 1e3, 'ms', v.last_stage_ms())
+# host-call latency of the reference-shaped single-proof entry points (host buffers in, status out, everything inside the call)
+for name, fn in (('zkv_risc0_verify', lambda: v.verify(H(r['seal']), H(r['image_id']), H(r['journal_digest']))),
+                 ('zkv_sp1_verify_proof', lambda: sp.verify_proof(H(g['sp1']['vkey']), H(g['sp1']['public_values']), H(g['sp1']['proof'])))):
+    fn()
+    ts = []
+    for _ in range(50):
+        t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    print('%s host call: median %.3f ms, min %.3f ms, p90 %.3f ms over 50 calls' % (name, ts[25], ts[0], ts[45]))
