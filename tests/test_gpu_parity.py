@@ -557,16 +557,22 @@ def test_differential_fuzz_against_the_oracle(zkv, r0, sp1, real_proofs):
     seals = [damage(H(r['seal'])) for _ in range(n)]
     ids = [H(r['image_id'])] * n
     jds = [H(r['journal_digest']) if rng.random() < 0.9 else rng.randbytes(32) for _ in range(n)]
-    st, rv = r0.verify_batch(seals, ids, jds)
     ost, orv = orc.verify_batch(seals, ids, jds, threads=8)
-    assert (st == ost).all() and (rv.reshape(-1) == orv).all()
+    for lanes in (0, 128, 64, 16, 2):        # every kernel mapping under the same damaged inputs (0 = automatic: one proof per wavefront at this size)
+        r0.set_lanes_per_proof(lanes)
+        st, rv = r0.verify_batch(seals, ids, jds)
+        assert (st == ost).all() and (rv.reshape(-1) == orv).all(), lanes
+    r0.set_lanes_per_proof(0)
     assert {0, 1, 4, 5} <= set(int(x) for x in st)
     proofs = [damage(H(s['proof'])) for _ in range(n)]
     vks = [H(s['vkey']) if rng.random() < 0.9 else rng.randbytes(32) for _ in range(n)]
     pvs = [H(s['public_values']) if rng.random() < 0.8 else rng.randbytes(rng.randrange(0, 200)) for _ in range(n)]
-    st, rv = sp1.verify_batch(vks, pvs, proofs)
     ost, orv = ol.sp1_verify_batch(vks, pvs, proofs, threads=8)
-    assert (st == ost).all() and (rv.reshape(-1) == orv).all()
+    for lanes in (0, 128, 64, 16, 2):
+        sp1.set_lanes_per_proof(lanes)
+        st, rv = sp1.verify_batch(vks, pvs, proofs)
+        assert (st == ost).all() and (rv.reshape(-1) == orv).all(), lanes
+    sp1.set_lanes_per_proof(0)
 
     # calldata: damage anywhere in the canonical encoding
     def damage_cd(cd):
