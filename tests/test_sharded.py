@@ -160,3 +160,63 @@ def test_sharded_device_batches_equal_single_device(zkv, real_proofs, staging):
     finally:
         for k in env:
             del os.environ[k]
+
+
+@pytest.mark.gpu
+def test_caller_supplied_keys_travel_as_context_blobs_and_shard(zkv):
+    """The caller-keyed verifiers over several devices (missing #4): a generic Groth16 trapdoor key
+    (`Groth16Verifier::verify_proof_with_key`, common/groth16.rs:23-49) and the PLONK key of the golden corpus (a) as context blobs
+    through `parallel.sharded_step` + `make_verifier` (one rank: the blob path without a second GPU) and (b) as sharded contexts with
+    three logical shards on device 0.  Results equal the directly constructed single-device verifier / the golden statuses."""
+    import json
+    import random
+    import torch
+    import spec_model as m
+    from stylus_zkvm_verifiers_amd import parallel
+    os.environ['ZKV_SHARD_MIN'] = '4'
+    try:
+        rng = random.Random(91)
+        vk, td = m.trapdoor_vk(rng, 4)
+        proofs, sigs, exp = [], [], []
+        for i in range(40):
+            sig = [rng.randrange(m.R) for _ in range(3)]
+            prf = m.trapdoor_prove(rng, td, sig, 'sp1')
+            if i % 4 == 3:
+                sig[i % 3] ^= 2
+            proofs.append(m.proof_to_words(*prf)); sigs.append([m.be32(s) for s in sig]); exp.append(i % 4 != 3)
+        vkb = m.vk_to_words(vk)
+        # (a) context blob -> verifier on "every rank"
+        blob = parallel.pack_context(parallel.CTX_GROTH16, vk=vkb, n_ic=4, vm_type=zkv.errors.VM_SP1)
+        dev = torch.device('cuda', 0)
+        rows = [torch.from_numpy(np.frombuffer(b''.join(proofs), dtype=np.uint8).reshape(40, 256).copy()),
+                torch.from_numpy(np.frombuffer(b''.join(b''.join(s) for s in sigs), dtype=np.uint8).reshape(40, 96).copy())]
+        state = {}
+
+        def verify_fn(b, p_t, s_t):
+            v = state.setdefault('v', parallel.make_verifier(b, 0))
+            pr = p_t.cpu().numpy(); sg = s_t.cpu().numpy()
+            ok = v.verify_batch([pr[i].tobytes() for i in range(len(pr))], [[sg[i, 32 * k:32 * k + 32].tobytes() for k in range(3)] for i in range(len(sg))])
+            return torch.from_numpy((~ok).astype(np.uint8)).to(p_t.device)          # 0 = verified, as a status byte
+        out, _ = parallel.sharded_step(blob, rows, 40, verify_fn, torch.device('cpu'), torch.device('cpu'))
+        assert [int(x) == 0 for x in out] == exp
+        state['v'].close()
+        # (b) three logical shards behind zkv_groth16_verify_batch
+        sv = zkv.shard([zkv.Groth16Verifier(vkb, 4, zkv.errors.VM_SP1, 0) for _ in range(3)])
+        assert zkv.shard_count(sv) == 3 and list(sv.verify_batch(proofs, sigs)) == exp
+        sv.close()
+        with pytest.raises(ValueError):                                 # shards of one verifier: a different key is refused
+            vk2, _ = m.trapdoor_vk(rng, 4)
+            zkv.shard([zkv.Groth16Verifier(vkb, 4, zkv.errors.VM_SP1, 0), zkv.Groth16Verifier(m.vk_to_words(vk2), 4, zkv.errors.VM_SP1, 0)])
+        # PLONK (parity unpinned): the golden corpus through a blob-built verifier and through three shards
+        cases = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'plonk_cases.json')))
+        pk, vh = H(cases['vk']), H(cases['verifier_hash'])
+        cs = cases['cases']
+        pv = parallel.make_verifier(parallel.pack_context(parallel.CTX_PLONK, vk=pk, verifier_hash=vh), 0)
+        sh = zkv.shard([zkv.Sp1PlonkVerifier(pk, vh, 0) for _ in range(3)])
+        for v in (pv, sh):
+            st, rv = v.verify_batch([H(c['vkey']) for c in cs], [H(c['public_values']) for c in cs], [H(c['proof']) for c in cs])
+            assert [int(x) for x in st] == [c['status'] for c in cs]
+            assert [bytes(x).hex() for x in rv] == [(c['received'] or '00000000') for c in cs]
+        pv.close(); sh.close()
+    finally:
+        del os.environ['ZKV_SHARD_MIN']
