@@ -1544,6 +1544,9 @@ ZKV_EXPORT int zkv_ctx_vm(const zkv_ctx* c) { return c ? c->vm : ZKV_ERR_INVALID
 ZKV_EXPORT int zkv_ctx_set_lanes_per_proof(zkv_ctx* c, int lanes) {
     if (!c || (lanes != 0 && lanes != 2 && lanes != 16 && lanes != 64 && lanes != 128)) return ZKV_ERR_INVALID_ARG;
     if (is_sharded(c)) { for (auto* k : c->shards) { const int rc = zkv_ctx_set_lanes_per_proof(k, lanes); if (rc != ZKV_OK) return rc; } return ZKV_OK; }
+    if (c->vm == ZKV_VM_MIXED) {                         // the two verifiers behind the tag run the stages
+        for (auto* k : c->kid) { const int rc = zkv_ctx_set_lanes_per_proof(k, lanes); if (rc != ZKV_OK) return rc; }
+    }
     std::lock_guard<std::mutex> lk(c->mu);
     c->lanes = lanes;
     return ZKV_OK;

@@ -48,6 +48,10 @@ class MixedVerifier:
         _lib.check(self._L.zkv_mixed_verify_batch_dev(self._h, n, d_vm, d_seals, d_in_a, d_in_b, b_stride, pv_len, d_status,
                                                       d_recv or None, stream or None), 'zkv_mixed_verify_batch_dev')
 
+    def set_lanes_per_proof(self, lanes):
+        """Kernel mapping of both verifiers behind the tag (0 automatic, 2, 16, 64, 128: see RiscZeroVerifier.set_lanes_per_proof)."""
+        _lib.check(self._L.zkv_ctx_set_lanes_per_proof(self._h, lanes), 'zkv_ctx_set_lanes_per_proof')
+
     def reserve(self, n):
         _lib.check(self._L.zkv_ctx_reserve(self._h, n), 'zkv_ctx_reserve')
 

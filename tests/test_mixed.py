@@ -222,6 +222,14 @@ def test_mixed_device_path_equals_separate_verifiers_and_oracle(zkv, mixed, real
         want = orc.verify(seals[i].tobytes(), a[i].tobytes(), b[i, :32].tobytes())[0] if vm[i] == 0 else \
             ol.sp1_verify_proof(a[i].tobytes(), b[i].tobytes(), seals[i].tobytes())[0]
         assert int(st[i]) == want, i
+    # every kernel mapping behind the tag gives the same bytes (the knob reaches both verifiers of the mixed context)
+    for lanes in (2, 16, 64, 128):
+        mixed.set_lanes_per_proof(lanes)
+        d_st.fill_(255)
+        mixed.verify_batch_dev(n, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 96, 96, d_st.data_ptr(), d_rv.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert (d_st.cpu().numpy() == st).all(), lanes
+    mixed.set_lanes_per_proof(0)
     # one-VM batches and the empty batch go through the same entry point
     only = torch.zeros(n, dtype=torch.uint8, device=dev)
     keep = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (s0, ids, jds)]
