@@ -49,6 +49,15 @@ inline Bytes revert_bytes(int vm, uint8_t status, const uint8_t received[4], con
 class RiscZeroVerifier {
 public:
     explicit RiscZeroVerifier(int device = 0) : ctx_(zkv_risc0_ctx_new(device)) { if (!ctx_) throw std::bad_alloc(); }
+    // An `initialize`d verifier over the GPUs named by device_mask (bit d = HIP device d): every method below works unchanged, batches
+    // are split over the GPUs (include/zkv.h, "sharded contexts"; SURVEY 8b `device_mask`).
+    static RiscZeroVerifier multi(const B256& control_root, const B256& bn254_control_id, uint64_t device_mask) {
+        zkv_ctx* c = zkv_risc0_ctx_create_multi(control_root.data(), bn254_control_id.data(), device_mask);
+        if (!c) throw std::invalid_argument("zkv_risc0_ctx_create_multi: empty or invalid device mask");
+        return RiscZeroVerifier(c);
+    }
+    RiscZeroVerifier(RiscZeroVerifier&& o) noexcept : ctx_(o.ctx_) { o.ctx_ = nullptr; }
+    size_t shard_count() const { return zkv_ctx_shard_count(ctx_); }
     ~RiscZeroVerifier() { zkv_ctx_destroy(ctx_); }
     RiscZeroVerifier(const RiscZeroVerifier&) = delete;
     RiscZeroVerifier& operator=(const RiscZeroVerifier&) = delete;
@@ -97,12 +106,20 @@ private:
         }
         return r;
     }
+    explicit RiscZeroVerifier(zkv_ctx* adopted) : ctx_(adopted) {}
     zkv_ctx* ctx_;
 };
 
 class Sp1Verifier {
 public:
     explicit Sp1Verifier(int device = 0) : ctx_(zkv_sp1_ctx_create(device)) { if (!ctx_) throw std::bad_alloc(); }
+    static Sp1Verifier multi(uint64_t device_mask) {       // one verifier over several GPUs (sharded context)
+        zkv_ctx* c = zkv_sp1_ctx_create_multi(device_mask);
+        if (!c) throw std::invalid_argument("zkv_sp1_ctx_create_multi: empty or invalid device mask");
+        return Sp1Verifier(c);
+    }
+    Sp1Verifier(Sp1Verifier&& o) noexcept : ctx_(o.ctx_) { o.ctx_ = nullptr; }
+    size_t shard_count() const { return zkv_ctx_shard_count(ctx_); }
     ~Sp1Verifier() { zkv_ctx_destroy(ctx_); }
     Sp1Verifier(const Sp1Verifier&) = delete;
     Sp1Verifier& operator=(const Sp1Verifier&) = delete;
@@ -125,6 +142,7 @@ public:
     zkv_ctx* raw() const { return ctx_; }
 
 private:
+    explicit Sp1Verifier(zkv_ctx* adopted) : ctx_(adopted) {}
     zkv_ctx* ctx_;
 };
 

@@ -23,11 +23,19 @@ int main(int argc, char** argv) {
     auto vkd = v.get_verifier_key_digest(); printf(" vk_digest="); hex(vkd.data(), 32);
     zkv::Sp1Verifier s(0);
     printf(" sp1_version=%s", s.version().c_str());
+    // the same traits over a device mask (sharded contexts): getters answer without a device
+    auto vm = zkv::RiscZeroVerifier::multi(arr<32>(argv[1]), arr<32>(argv[2]), 1);
+    auto sm = zkv::Sp1Verifier::multi(1);
+    auto sel_m = vm.get_selector(); printf(" multi_shards=%zu multi_selector=", vm.shard_count()); hex(sel_m.data(), 4);
+    printf(" multi_initialized=%d sp1_multi_shards=%zu", (int)vm.is_initialized(), sm.shard_count());
+    try { zkv::Sp1Verifier::multi(0); printf(" empty_mask=accepted"); } catch (const std::invalid_argument&) { printf(" empty_mask=refused"); }
     auto cd = zkv::encode_verify_call(unhex(argv[3]), arr<32>(argv[4]), arr<32>(argv[5]));
     printf(" calldata_len=%zu calldata_head=", cd.size()); hex(cd.data(), 36);
     if (zkv_device_count() > 0) {
         auto ok = v.verify(unhex(argv[3]), arr<32>(argv[4]), arr<32>(argv[5]));
         printf(" verify_ok=%d", (int)ok.ok);
+        auto okm = vm.verify(unhex(argv[3]), arr<32>(argv[4]), arr<32>(argv[5]));
+        printf(" multi_verify_ok=%d", (int)okm.ok);
         zkv::Bytes bad = unhex(argv[3]); bad[0] ^= 1;
         auto mm = v.verify(bad, arr<32>(argv[4]), arr<32>(argv[5]));
         printf(" mismatch_status=%d mismatch_err=", (int)mm.status); hex(mm.err.data(), mm.err.size());

@@ -29,6 +29,7 @@ def test_cpp_mirror_host_logic(real_proofs):
     assert kv['selector'] == r['selector'] and kv['vk_digest'] == r['vk_digest']
     assert kv['sp1_version'] == 'v5.0.0'
     assert kv['calldata_len'] == '8452' and kv['calldata_head'] == 'f8b3b60b' + '00' * 31 + '60'
+    assert (kv['multi_shards'], kv['multi_selector'], kv['multi_initialized'], kv['sp1_multi_shards'], kv['empty_mask']) == ('1', r['selector'], '1', '1', 'refused')
     if 'verify_runtime_error' in kv:
         assert kv['verify_runtime_error'] == '-2'       # ZKV_ERR_NO_DEVICE: no CPU fallback
 
@@ -36,7 +37,7 @@ def test_cpp_mirror_host_logic(real_proofs):
 @pytest.mark.gpu
 def test_cpp_mirror_verifies_on_gpu(real_proofs):
     kv = _build_and_run(real_proofs)
-    assert kv['verify_ok'] == '1'
+    assert kv['verify_ok'] == '1' and kv['multi_verify_ok'] == '1'
     assert kv['mismatch_status'] == '5'
     assert kv['mismatch_err'].startswith('b8b38d4c9e39696c')
     # wire layer through the C++ mirror: verify() call -> true word, getSelector() -> bytes4 word, garbage -> empty revert
