@@ -85,20 +85,20 @@ ZKV_HD bool pair_all(bool mine) {          // AND over the two lanes of a pair
     v |= zkv_partner_u32(v);
     return v == 0;
 }
-// One launch per pair index j (k launches: pair j of every call is validated, run through the Miller loop and multiplied into the
-// call's F slot; ok[] collects the verdict on the inputs), then the final exponentiation of the valid calls.  (As one kernel with
-// the pair loop inside, the inlined stages pushed the register allocator to 217 spilled VGPRs and an 880-byte scratch frame.)
-__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_pair(size_t n, uint32_t k, uint32_t j, const uint8_t* __restrict__ in, Workspace ws,
-                                                               uint8_t* __restrict__ ok) {
-    __shared__ uint32_t lds[(48 + 24) * ZKV_BLOCK];
+// Two launches per pair index j: k_pairing_check validates pair j of every call (coordinates < p, P on the curve, Q on the twist),
+// writes the normalised rows and a per-call word in ws.flags (0 = identity pair, nothing to do; 1 = run; 2 = run with P = infinity:
+// only the point is stepped), k_pairing_miller runs the Miller loop - the subgroup test of Q as well - and multiplies into the call's
+// F slot; ok[] collects the verdict on the inputs.  Then the final exponentiation of the valid calls.  (As one kernel per pair the
+// check's inversion and the Miller loop shared a frame of 70 spilled VGPRs; with the pair loop inside as well, 217.)
+__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_check(size_t n, uint32_t k, uint32_t j, const uint8_t* __restrict__ in, Workspace ws,
+                                                                uint8_t* __restrict__ ok) {
     size_t i = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
     if (i >= n) return;
     const uint32_t par = threadIdx.x & 1u;
-    LRef fm = l_ref(lds + threadIdx.x);
-    LRef tm = l_ref(lds + 48 * ZKV_BLOCK + threadIdx.x);
-    MRef P = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, (uint32_t)ws.cap, 16);
-    if (j == 0) { f12m_set_one(P); if (!par) ok[i] = 1; }
-    else if (!ok[i]) return;                                    // an earlier pair of this call was invalid (both lanes read the same byte)
+    if (j == 0) {
+        f12m_set_one(m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, (uint32_t)ws.cap, 16));
+        if (!par) ok[i] = 1;
+    } else if (!ok[i]) { if (!par) ws.flags[i] = 0; return; }   // an earlier pair of this call was invalid (both lanes read the same byte)
     const uint8_t* p = in + (size_t)192 * ((size_t)k * i + j);
     uint32_t gx[8], gy[8], qxw[8], qyw[8];
     load_be256(gx, p); load_be256(gy, p + 32);
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_pair(size_t n, uint32_
     const bool qinf = pair_all(raw_is_zero(qxw) && raw_is_zero(qyw));
     Fp px = fp_zero(), py = fp_zero();
     if (okj && !pinf) { px = fp_from_raw(gx); py = fp_from_raw(gy); okj = g1_on_curve(px, py); }
-    bool run = false;
+    uint32_t run = 0;
     if (okj && !qinf) {
         Fp2 qx, qy; qx.h = fp_from_raw(qxw); qy.h = fp_from_raw(qyw);
         okj = g2_on_twist(qx, qy);
@@ -118,17 +118,26 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_pair(size_t n, uint32_
             const Fp iy = pinf ? fp_zero() : fp_inv(py);
             ws_st(ws.norm, ws.cap, 0, i, fp_mul(px, iy)); ws_st(ws.norm, ws.cap, 8, i, iy);            // both lanes store the same words
             ws_st(ws.prep, ws.cap, 32 + 8 * (int)par, i, qx.h); ws_st(ws.prep, ws.cap, 48 + 8 * (int)par, i, qy.h);
-            run = true;
+            run = pinf ? 2u : 1u;
         }
     }
-    if (run) {
-        // the Miller loop is the subgroup test of Q as well; for P = infinity only the point is stepped (no line products)
-        SoaRef norm = {ws.norm, ws.cap, (uint32_t)i * 4u};
-        SoaRef bsrc = {ws.prep + 32 * ws.cap, ws.cap, (uint32_t)(8 * par * ws.cap + i) * 4u};
-        okj = miller_loop_p((const VkTables*)nullptr, pinf ? (uint32_t)FL_A_INF : 0u, norm, bsrc, fm, tm, true);
-        if (okj && !pinf) f12m_mul_body(P, P, fm, false);
-    }
-    if (!okj && !par) ok[i] = 0;
+    if (!par) { ws.flags[i] = run; if (!okj) ok[i] = 0; }
+}
+__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_miller(size_t n, Workspace ws, uint8_t* __restrict__ ok) {
+    __shared__ uint32_t lds[(48 + 24) * ZKV_BLOCK];
+    size_t i = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
+    if (i >= n) return;
+    const uint32_t run = ws.flags[i];                           // both lanes of the pair read the same word
+    if (!run) return;
+    const uint32_t par = threadIdx.x & 1u;
+    LRef fm = l_ref(lds + threadIdx.x);
+    LRef tm = l_ref(lds + 48 * ZKV_BLOCK + threadIdx.x);
+    MRef P = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, (uint32_t)ws.cap, 16);
+    SoaRef norm = {ws.norm, ws.cap, (uint32_t)i * 4u};
+    SoaRef bsrc = {ws.prep + 32 * ws.cap, ws.cap, (uint32_t)(8 * par * ws.cap + i) * 4u};
+    const bool fine = miller_loop_p((const VkTables*)nullptr, run == 2 ? (uint32_t)FL_A_INF : 0u, norm, bsrc, fm, tm, true);
+    if (fine && run == 1) f12m_mul(P, fm, P);                 // not inlined: inside this kernel the product kept 70 VGPRs in scratch
+    if (!fine && !par) ok[i] = 0;
 }
 __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_finalexp(size_t n, Workspace ws, const uint8_t* __restrict__ ok, uint8_t* __restrict__ result,
                                                                    uint32_t empty) {
@@ -151,7 +160,10 @@ void launch_pairing(size_t n, uint32_t k, const uint8_t* in, const Workspace& ws
     if (!n) return;
     const unsigned grid = (unsigned)((2 * n + ZKV_BLOCK - 1) / ZKV_BLOCK);
     if (k == 0) (void)hipMemsetAsync(ok, 1, n, s);              // the empty product: valid input, result 1 (its F slot is set below)
-    for (uint32_t j = 0; j < k; j++) hipLaunchKernelGGL(k_pairing_pair, dim3(grid), dim3(ZKV_BLOCK), 0, s, n, k, j, in, ws, ok);
+    for (uint32_t j = 0; j < k; j++) {
+        hipLaunchKernelGGL(k_pairing_check, dim3(grid), dim3(ZKV_BLOCK), 0, s, n, k, j, in, ws, ok);
+        hipLaunchKernelGGL(k_pairing_miller, dim3(grid), dim3(ZKV_BLOCK), 0, s, n, ws, ok);
+    }
     hipLaunchKernelGGL(k_pairing_finalexp, dim3(grid), dim3(ZKV_BLOCK), 0, s, n, ws, ok, result, k == 0 ? 1u : 0u);
 }
 

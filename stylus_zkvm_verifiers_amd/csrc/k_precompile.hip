@@ -58,7 +58,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_ecmul(size_t n, const uint8_t* __
     ok[i] = good ? 1 : 0;
 }
 
-// ecPairing: k_pairing_pair + k_pairing_finalexp in k_pair.hip (lane-pair kernels, shared with the verify path).
+// ecPairing: k_pairing_check + k_pairing_miller + k_pairing_finalexp in k_pair.hip (lane-pair kernels, shared with the verify path).
 
 void launch_ecadd(size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok, hipStream_t s) {
     if (!n) return;

@@ -128,7 +128,7 @@ void launch_miller_w64d(size_t n, const VkTables* d_tab, const Workspace& ws, ui
 }
 
 // The ecPairing precompile for SMALL batches of calls (the reference makes exactly one such call per proof: common/groth16.rs:109-128), on
-// the two-wavefront Miller kernel: one launch per pair index j as in k_pairing_pair (k_pair.hip), but one CALL per workgroup of two
+// the two-wavefront Miller kernel: one launch per pair index j as in k_pairing_check + k_pairing_miller (k_pair.hip), but one CALL per workgroup of two
 // wavefronts instead of one call per lane pair -- a single 4-pair call takes 4 x 0.8 + 0.8 ms instead of 4 x 5 + 3 ms.  The producer
 // wavefront's final running point gives the subgroup verdict for Q (miller_point_closes), as in the lane-pair kernels.
 ZKV_HD bool pair_all_w(bool mine) {
