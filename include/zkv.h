@@ -299,6 +299,23 @@ int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_* */
  * wavefront per proof, which steps the running G2 point ahead of the accumulator.  2 = always lane pairs; 16 = always 16 lanes per
  * proof; 64 = always one proof per wavefront; 128 = always two wavefronts per proof in the Miller loop.  Results are identical.  (The round-1 one-proof-per-lane kernels were retired: 2.53 against 3.11 M proofs/s.) */
 int zkv_ctx_set_lanes_per_proof(zkv_ctx* ctx, int lanes);
+/* Aggregate check (no reference counterpart; off by default).  The reference answers one proof per call with one pairing check
+ * (common/groth16.rs:60-72, 109-128).  A batch may share that check: with enable != 0, chunks of at least ZKV_AGG_MIN proofs
+ * (environment, default 16384) are checked in sub-batches of 64 proofs through ONE product of pairings per sub-batch,
+ *     prod_i e(r_i (-A_i), B_i) * e(sum_i r_i vk_x_i, gamma) * e(sum_i r_i C_i, delta) * e((sum_i r_i) alpha, beta) == 1,
+ * with 128-bit coefficients r_i derived (SHA-256) from 32 secret bytes and a per-chunk counter.  Every check before the pairing
+ * equation stays per proof and deterministic (seal format, selector, signal ranges, curve membership of A and C, curve and subgroup
+ * membership of B).  A sub-batch whose aggregate check fails is verified again proof by proof by the ordinary kernels, so the
+ * statuses are the deterministic ones unless invalid proofs pass an aggregate check, which happens with probability 2^-128 per
+ * sub-batch over the coefficients -- provided the proofs were fixed before the secret was drawn.  seed32 = NULL draws the secret from
+ * the operating system (getrandom) -- the setting for production; a caller-supplied seed makes runs reproducible (tests) and must
+ * not be known to whoever supplies proofs.  Applies to RISC Zero, SP1 (Groth16), verifier-set, generic-key, mixed and sharded
+ * contexts; ZKV_ERR_INVALID_ARG on a PLONK or precompile context.  Keys with alpha or beta at infinity fall back to the ordinary path.
+ * Throughput: see DESIGN.md (about 1.6x on all-valid batches; a rejected proof costs its sub-batch a second, ordinary pass). */
+int zkv_ctx_set_aggregate_check(zkv_ctx* ctx, int enable, const uint8_t* seed32);
+/* out[0] = sub-batches checked in aggregate, out[1] = those that failed and were verified proof by proof, since device set-up.
+ * Synchronise (zkv_ctx_synchronize or the stream) with the batches to be counted first. */
+int zkv_ctx_aggregate_counters(zkv_ctx* ctx, uint64_t out[2]);
 /* Device set-up (stream, verification-key tables) and per-chunk buffers for batches of up to n proofs, ahead of the first
  * batch call.  Optional: every batch entry point does this on demand; the buffers (about 3.7 KB per proof in flight) grow to the
  * largest batch seen, at most ZKV_CHUNK proofs (environment, default 2^20; larger batches run chunk by chunk). */

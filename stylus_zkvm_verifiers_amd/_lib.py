@@ -68,6 +68,8 @@ SYMBOLS = {
     'zkv_mixed_ctx_create_multi': (_vp, [_cp, _cp, C.c_uint64]),
     'zkv_ctx_vm': (_i, [_vp]),
     'zkv_ctx_set_lanes_per_proof': (_i, [_vp, _i]),
+    'zkv_ctx_set_aggregate_check': (_i, [_vp, _i, _cp]),
+    'zkv_ctx_aggregate_counters': (_i, [_vp, C.POINTER(C.c_uint64)]),
     'zkv_ctx_reserve': (_i, [_vp, _sz]),
     'zkv_chunk_capacity': (_sz, []),
     'zkv_ctx_synchronize': (_i, [_vp]),

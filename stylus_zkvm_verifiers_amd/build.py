@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 BUILD = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libzkv_mi355x.so')
-UNITS = ['k_setup', 'k_prep', 'k_msm', 'k_pair', 'k_wide', 'k_precompile', 'k_wire', 'k_mixed', 'k_diag', 'k_plonk', 'zkv_capi']
+UNITS = ['k_setup', 'k_prep', 'k_msm', 'k_pair', 'k_wide', 'k_precompile', 'k_wire', 'k_mixed', 'k_diag', 'k_plonk', 'k_agg', 'zkv_capi']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-DZKV_FP_MUL_NOINLINE',
          '-Rpass-analysis=kernel-resource-usage']
 UNIT_FLAGS = {}          # per-unit extra flags (none at present)

@@ -1,0 +1,160 @@
+// Aggregate check (zkv_agg.h), the one-proof-per-lane kernels: the per-proof G1 stage (vk_x, the coefficient, r A, r vk_x, r C), the
+// per-sub-batch reduction (one wavefront = one sub-batch of 64 proofs: butterfly sums of the points and of the coefficients, the
+// pseudo-proof's rows), and the kernel that turns the sub-batches' verdicts into statuses and re-arms the proofs of a failed
+// sub-batch for the ordinary kernels.  The product of the proofs' Miller values is a lane-pair kernel (k_agg_fprod, k_pair.hip).
+#include "zkv_internal.h"
+#include "zkv_agg.h"
+
+namespace zkv {
+
+__global__ __launch_bounds__(64) void k_setup_agg(const VkRaw* __restrict__ raw, const VkTables* __restrict__ tab, AggTables* __restrict__ t) {
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j < AGG_ALPHA_POW) setup_agg_alpha(*raw, *t, j);
+    if (j == AGG_ALPHA_POW) {
+        for (int k = 0; k < 4; k++) t->beta[k] = fp_from_raw(raw->beta[k]);
+        t->ok = (tab->vk_valid && !raw_g1_is_inf(raw->alpha) && !raw_g2_is_inf(raw->beta)) ? 1u : 0u;
+    }
+}
+void launch_setup_agg(const VkRaw* d_raw, const VkTables* d_tab, AggTables* d_agg, hipStream_t s) {
+    hipLaunchKernelGGL(k_setup_agg, dim3(2), dim3(64), 0, s, d_raw, d_tab, d_agg);
+}
+
+__device__ __forceinline__ void agg_st_g1j(uint32_t* agg, size_t cap, int word0, size_t i, const G1J& p) {
+    ws_st(agg, cap, word0, i, p.x); ws_st(agg, cap, word0 + 8, i, p.y); ws_st(agg, cap, word0 + 16, i, p.z);
+}
+__device__ __forceinline__ G1J agg_ld_g1j(const uint32_t* agg, size_t cap, int word0, size_t i) {
+    G1J p; p.x = ws_ld(agg, cap, word0, i); p.y = ws_ld(agg, cap, word0 + 8, i); p.z = ws_ld(agg, cap, word0 + 16, i);
+    return p;
+}
+
+// Per proof: vk_x as in k_msm, the coefficient r, then A' <- r A' (normalised into the rows the Miller loop reads), U = r vk_x and
+// W = r C (Jacobian, summed per sub-batch later).  The proof's flags word is saved and replaced by one that tells k_miller2 to skip
+// both fixed pairs: its Miller value is then f_i = ML(r A', B) * ML(alpha, beta).
+__global__ __launch_bounds__(ZKV_BLOCK) void k_agg_g1(size_t n, const VkTables* __restrict__ vk, const InstTab* __restrict__ inst_tab, Workspace ws,
+                                                      uint32_t* __restrict__ agg, AggSeed seed) {
+    size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t flags0 = ws.flags[i];
+    agg[(size_t)AGG_W_FLAGS * ws.cap + i] = flags0;
+    if (!(flags0 & FL_ALIVE)) return;
+    PrepOut in;
+    in.ax = ws_ld(ws.prep, ws.cap, 0, i); in.ay = ws_ld(ws.prep, ws.cap, 8, i);
+    in.cx = ws_ld(ws.prep, ws.cap, 16, i); in.cy = ws_ld(ws.prep, ws.cap, 24, i);
+#pragma unroll 1
+    for (uint32_t b = 0; b < vk->n_var; b++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) in.s[b][k] = ws.prep[(size_t)(64 + 8 * b + k) * ws.cap + i];
+    }
+    G1J L;
+    uint32_t flags = flags0;
+    if (inst_tab) { const InstTab& t = inst_tab[flags >> 8]; flags &= 0xFFu; L = msm_accumulate(*vk, in, t.base, t.base_inf); }
+    else L = msm_accumulate(*vk, in);
+    uint64_t r1, r2;
+    agg_coeff(seed, (uint32_t)i, r1, r2);
+    agg[(size_t)(AGG_W_R + 0) * ws.cap + i] = (uint32_t)r1; agg[(size_t)(AGG_W_R + 1) * ws.cap + i] = (uint32_t)(r1 >> 32);
+    agg[(size_t)(AGG_W_R + 2) * ws.cap + i] = (uint32_t)r2; agg[(size_t)(AGG_W_R + 3) * ws.cap + i] = (uint32_t)(r2 >> 32);
+    G1A la; uint32_t linf;
+    g1j_to_affine(L, la, linf);
+    agg_st_g1j(agg, ws.cap, AGG_W_U, i, linf ? g1j_infinity() : agg_mul(la.x, la.y, r1, r2));
+    agg_st_g1j(agg, ws.cap, AGG_W_W, i, (flags & FL_C_INF) ? g1j_infinity() : agg_mul(in.cx, in.cy, r1, r2));
+    flags |= FL_L_INF | FL_C_INF;                               // for the Miller kernel only: the fixed pairs are taken per sub-batch
+    if (!(flags & FL_A_INF)) {
+        const G1J a = agg_mul(in.ax, in.ay, r1, r2);
+        if (fp_is_zero(a.z)) flags |= FL_A_INF;                 // r = 0 (probability 2^-128): the pair contributes 1
+        else {
+            const Fp iy = fp_inv(a.y);                          // no point of G1 has y = 0
+            ws_st(ws.norm, ws.cap, 0, i, fp_mul(fp_mul(a.x, a.z), iy));                 // (X / Z^2) / (Y / Z^3)
+            ws_st(ws.norm, ws.cap, 8, i, fp_mul(fp_mul(fp_sqr(a.z), a.z), iy));         // Z^3 / Y
+        }
+    }
+    ws.flags[i] = flags;
+}
+
+__device__ __forceinline__ G1J g1j_xor(const G1J& p, int mask) {
+    G1J r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        r.x.v[k] = (uint32_t)__shfl_xor((int)p.x.v[k], mask, 64);
+        r.y.v[k] = (uint32_t)__shfl_xor((int)p.y.v[k], mask, 64);
+        r.z.v[k] = (uint32_t)__shfl_xor((int)p.z.v[k], mask, 64);
+    }
+    return r;
+}
+// One wavefront per sub-batch.  Lane l holds proof 64 sb + l: its U, W and coefficient words if the proof is still in the check
+// (alive after PREP, B in the subgroup), nothing otherwise.  Butterflies give every lane the sums; E = (S1 - cnt - 1) alpha + S2 phi(alpha)
+// comes from the lanes' table look-ups (one bit of S1, S2 per lane) and a third butterfly -- every proof's Miller value and the pseudo-proof's
+// carry one factor ML(alpha, beta), hence the cnt + 1.  Lane 0 writes the pseudo-proof (A := E, B := beta, vk_x := sum U, C := sum W) into
+// the second workspace.
+__global__ __launch_bounds__(ZKV_BLOCK) void k_agg_reduce(size_t n, Workspace ws, const uint32_t* __restrict__ agg, const AggTables* __restrict__ tab,
+                                                          Workspace ws2, uint8_t* __restrict__ status2) {
+    const size_t sb = blockIdx.x, i = sb * ZKV_BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x;
+    bool in = false;
+    if (i < n) in = (agg[(size_t)AGG_W_FLAGS * ws.cap + i] & FL_ALIVE) && !ws.g2bad[i];
+    G1J U = g1j_infinity(), W = g1j_infinity();
+    uint32_t s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0}, cnt = in ? 1u : 0u;
+    if (in) {
+        U = agg_ld_g1j(agg, ws.cap, AGG_W_U, i); W = agg_ld_g1j(agg, ws.cap, AGG_W_W, i);
+        s1[0] = agg[(size_t)(AGG_W_R + 0) * ws.cap + i]; s1[1] = agg[(size_t)(AGG_W_R + 1) * ws.cap + i];
+        s2[0] = agg[(size_t)(AGG_W_R + 2) * ws.cap + i]; s2[1] = agg[(size_t)(AGG_W_R + 3) * ws.cap + i];
+    }
+#pragma unroll 1
+    for (int m = 32; m >= 1; m >>= 1) {
+        U = g1j_add(U, g1j_xor(U, m));
+        W = g1j_add(W, g1j_xor(W, m));
+        uint32_t c = 0;
+        s1[0] = addc(s1[0], (uint32_t)__shfl_xor((int)s1[0], m, 64), c); s1[1] = addc(s1[1], (uint32_t)__shfl_xor((int)s1[1], m, 64), c);
+        s1[2] = addc(s1[2], (uint32_t)__shfl_xor((int)s1[2], m, 64), c);
+        c = 0;
+        s2[0] = addc(s2[0], (uint32_t)__shfl_xor((int)s2[0], m, 64), c); s2[1] = addc(s2[1], (uint32_t)__shfl_xor((int)s2[1], m, 64), c);
+        s2[2] = addc(s2[2], (uint32_t)__shfl_xor((int)s2[2], m, 64), c);
+        cnt += (uint32_t)__shfl_xor((int)cnt, m, 64);
+    }
+    G1J E = agg_e_share(*tab, lane, ((uint64_t)s1[1] << 32) | s1[0], s1[2], ((uint64_t)s2[1] << 32) | s2[0], s2[2], cnt + 1u);
+#pragma unroll 1
+    for (int m = 32; m >= 1; m >>= 1) E = g1j_add(E, g1j_xor(E, m));
+    if (lane != 0) return;
+    ws2.g2bad[sb] = 0;
+    if (cnt == 0) { ws2.flags[sb] = 0; status2[sb] = ST_OK; return; }       // nothing left to check in this sub-batch
+    uint32_t flags = FL_ALIVE;
+    G1Norm o;
+    agg_normalize3(E, U, W, flags, o);
+    ws_st(ws2.norm, ws2.cap, 0, sb, o.axs); ws_st(ws2.norm, ws2.cap, 8, sb, o.ays);
+    ws_st(ws2.norm, ws2.cap, 16, sb, o.lxs); ws_st(ws2.norm, ws2.cap, 24, sb, o.lys);
+    ws_st(ws2.norm, ws2.cap, 32, sb, o.cxs); ws_st(ws2.norm, ws2.cap, 40, sb, o.cys);
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) ws_st(ws2.prep, ws2.cap, 32 + 8 * k, sb, tab->beta[k]);
+    ws2.flags[sb] = flags;
+    status2[sb] = ST_VERIFICATION_FAILED;
+}
+
+// Verdicts: a proof that was in a sub-batch whose check passed is accepted and taken out of the chunk (flags 0); one in a failed
+// sub-batch gets its PREP flags back, and the ordinary MSM / Miller / final-exponentiation kernels that follow verify it alone.
+// Proofs PREP rejected or whose B failed the subgroup test already have their final status.  counters: [0] sub-batches checked,
+// [1] sub-batches that failed.
+__global__ __launch_bounds__(ZKV_BLOCK) void k_agg_mark(size_t n, Workspace ws, const uint32_t* __restrict__ agg, const uint8_t* __restrict__ status2,
+                                                        uint8_t* __restrict__ status, unsigned long long* __restrict__ counters) {
+    const size_t sb = blockIdx.x, i = sb * ZKV_BLOCK + threadIdx.x;
+    const bool passed = status2[sb] == ST_OK;
+    if (threadIdx.x == 0) { atomicAdd(&counters[0], 1ull); if (!passed) atomicAdd(&counters[1], 1ull); }
+    if (i >= n) return;
+    const uint32_t flags0 = agg[(size_t)AGG_W_FLAGS * ws.cap + i];
+    if (!(flags0 & FL_ALIVE) || ws.g2bad[i]) { ws.flags[i] = 0; return; }
+    if (passed) { status[i] = ST_OK; ws.flags[i] = 0; }
+    else ws.flags[i] = flags0;
+}
+
+void launch_agg_g1(size_t n, const VkTables* d_tab, const InstTab* inst_tab, const Workspace& ws, uint32_t* agg, const AggSeed& seed, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_agg_g1, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, d_tab, inst_tab, ws, agg, seed);
+}
+void launch_agg_reduce(size_t n, const Workspace& ws, const uint32_t* agg, const AggTables* tab, const Workspace& ws2, uint8_t* status2, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_agg_reduce, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, ws, agg, tab, ws2, status2);
+}
+void launch_agg_mark(size_t n, const Workspace& ws, const uint32_t* agg, const uint8_t* status2, uint8_t* status, unsigned long long* counters, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_agg_mark, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, ws, agg, status2, status, counters);
+}
+
+}  // namespace zkv

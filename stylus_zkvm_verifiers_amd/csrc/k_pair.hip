@@ -7,6 +7,7 @@
 // supplies them (2^17 lanes = 2048 waves on 1024 SIMDs).
 #define ZKV_PAIRED 1
 #include "zkv_internal.h"
+#include "zkv_agg.h"
 
 namespace zkv {
 
@@ -165,6 +166,31 @@ void launch_pairing(size_t n, uint32_t k, const uint8_t* in, const Workspace& ws
         hipLaunchKernelGGL(k_pairing_miller, dim3(grid), dim3(ZKV_BLOCK), 0, s, n, ws, ok);
     }
     hipLaunchKernelGGL(k_pairing_finalexp, dim3(grid), dim3(ZKV_BLOCK), 0, s, n, ws, ok, result, k == 0 ? 1u : 0u);
+}
+
+// Aggregate check (zkv_agg.h): the product of the Miller values of a sub-batch's proofs, multiplied into the pseudo-proof's slot
+// between its Miller loop and its final exponentiation.  One sub-batch per lane pair, the running product in LDS.
+__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_agg_fprod(size_t n, size_t n2, Workspace ws, const uint32_t* __restrict__ agg, Workspace ws2) {
+    __shared__ uint32_t lds[48 * ZKV_BLOCK];
+    const size_t sb = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
+    if (sb >= n2) return;
+    if (!(ws2.flags[sb] & FL_ALIVE)) return;
+    const uint32_t par = threadIdx.x & 1u;
+    LRef acc = l_ref(lds + threadIdx.x);
+    MRef P2 = m_ref(ws2.f + (size_t)(8 * par) * ws2.cap + sb, (uint32_t)ws2.cap, 16);
+    f12m_copy(acc, P2);
+    const size_t i0 = sb * AGG_SUB, i1 = i0 + AGG_SUB < n ? i0 + AGG_SUB : n;
+#pragma unroll 1
+    for (size_t i = i0; i < i1; i++) {
+        if (!(agg[(size_t)AGG_W_FLAGS * ws.cap + i] & FL_ALIVE) || ws.g2bad[i]) continue;      // both lanes of the pair read the same words
+        MRef Pi = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, (uint32_t)ws.cap, 16);
+        f12m_mul(acc, acc, Pi);
+    }
+    f12m_copy(P2, acc);
+}
+void launch_agg_fprod(size_t n, size_t n2, const Workspace& ws, const uint32_t* agg, const Workspace& ws2, hipStream_t s) {
+    if (!n2) return;
+    hipLaunchKernelGGL(k_agg_fprod, dim3((unsigned)((2 * n2 + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, n2, ws, agg, ws2);
 }
 
 static inline unsigned pair_grid(size_t n) { return (unsigned)((2 * n + ZKV_BLOCK - 1) / ZKV_BLOCK); }

@@ -16,6 +16,8 @@
 #include "zkv_host_vk.h"
 #include "zkv_internal.h"
 #include "zkv_plonk.h"
+#include "zkv_agg.h"
+#include <sys/random.h>
 
 using namespace zkv;
 
@@ -65,6 +67,16 @@ struct zkv_ctx {
     PlonkKeyRaw pk_raw; uint8_t pk_g2[256] = {0}, plonk_hash[32] = {0};
     PlonkKey* d_pkey = nullptr;
     uint32_t* d_plonk_tab = nullptr;                           // per-proof window tables of the PLONK stage (PLONK_TAB_WORDS words per proof in flight)
+    // Aggregate check (zkv_agg.h, zkv_ctx_set_aggregate_check): key tables, per-proof rows, the pseudo-proofs' workspace (one per
+    // sub-batch of AGG_SUB proofs), their statuses and the counters {sub-batches checked, sub-batches failed}
+    bool agg_on = false, agg_key_ok = false;
+    AggTables* d_agg_tab = nullptr;
+    uint32_t* d_agg = nullptr;
+    Workspace ws2 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    uint8_t* d_status2 = nullptr;
+    unsigned long long* d_agg_cnt = nullptr;
+    size_t agg_cap = 0;
+    AggSeed agg_seed = {{0, 0, 0, 0, 0, 0, 0, 0}, 0};
     // ZKV_VM_MIXED: one RISC Zero and one SP1 verifier behind a per-proof VM tag; mx[] are the demultiplexing buffers
     // Sharded (multi-device) context: `shards` single-device contexts of one verifier behind the ordinary batch entry points
     // (zkv_ctx_create_sharded).  sh[] is the per-shard state of device-resident batches: staging rows on the shard's device, a copy
@@ -155,8 +167,11 @@ static void ctx_free_device(zkv_ctx* c) {
                      (void**)&c->ws.g2bad, (void**)&c->d_blob, (void**)&c->d_a, (void**)&c->d_b, (void**)&c->d_pv, (void**)&c->d_status,
                      (void**)&c->d_recv, (void**)&c->d_off, (void**)&c->d_pvoff, (void**)&c->d_cd[0], (void**)&c->d_cd[1], (void**)&c->d_kind,
                      (void**)&c->d_cdoff[0], (void**)&c->d_cdoff[1], (void**)&c->d_len, (void**)&c->d_pvlen, (void**)&c->d_st_all,
-                     (void**)&c->d_rv_all, (void**)&c->d_inst, (void**)&c->d_inst_idx, (void**)&c->d_pkey, (void**)&c->d_plonk_tab};
+                     (void**)&c->d_rv_all, (void**)&c->d_inst, (void**)&c->d_inst_idx, (void**)&c->d_pkey, (void**)&c->d_plonk_tab,
+                     (void**)&c->d_agg_tab, (void**)&c->d_agg, (void**)&c->ws2.prep, (void**)&c->ws2.norm, (void**)&c->ws2.f, (void**)&c->ws2.fe,
+                     (void**)&c->ws2.flags, (void**)&c->ws2.g2bad, (void**)&c->d_status2, (void**)&c->d_agg_cnt};
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    c->ws2.cap = 0; c->agg_cap = 0; c->agg_key_ok = false;
     for (int k = 0; k < 6; k++) { if (c->hb[k]) (void)hipFree(c->hb[k]); c->hb[k] = nullptr; c->hb_cap[k] = 0; }
     for (int k = 0; k < 20; k++) { if (c->mx[k]) (void)hipFree(c->mx[k]); c->mx[k] = nullptr; c->mx_cap[k] = 0; }
     c->ws.cap = 0; c->blob_cap = c->pv_cap = 0; c->cd_cap[0] = c->cd_cap[1] = c->st_all_cap = c->rv_all_cap = 0;
@@ -205,6 +220,14 @@ static int ctx_device_setup(zkv_ctx* c) {
         HIP_TRY(hipMemcpyAsync(d_raw, &raw, sizeof raw, hipMemcpyHostToDevice, c->stream));
         launch_setup(d_raw, c->d_tab, c->stream);
         HIP_TRY(hipGetLastError());
+        const bool agg_vm = c->vm == ZKV_VM_RISC0 || c->vm == ZKV_VM_RISC0_SET || c->vm == ZKV_VM_SP1 || c->vm == ZKV_VM_GROTH16;
+        if (agg_vm) {
+            HIP_TRY(hipMalloc(&c->d_agg_tab, sizeof(AggTables)));
+            HIP_TRY(hipMalloc(&c->d_agg_cnt, 2 * sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(c->d_agg_cnt, 0, 2 * sizeof(unsigned long long), c->stream));
+            launch_setup_agg(d_raw, c->d_tab, c->d_agg_tab, c->stream);
+            HIP_TRY(hipGetLastError());
+        }
         if (c->vm == ZKV_VM_RISC0_SET) {
             const size_t k = c->inst_raw.size();
             InstConsts ic;
@@ -231,6 +254,11 @@ static int ctx_device_setup(zkv_ctx* c) {
         uint32_t valid = 0;
         HIP_TRY(hipMemcpy(&valid, &c->d_tab->vk_valid, sizeof valid, hipMemcpyDeviceToHost));
         c->vk_invalid = valid == 0;
+        if (c->d_agg_tab) {
+            uint32_t ok = 0;
+            HIP_TRY(hipMemcpy(&ok, &c->d_agg_tab->ok, sizeof ok, hipMemcpyDeviceToHost));
+            c->agg_key_ok = ok != 0;
+        }
     }
     return ZKV_OK;
 }
@@ -251,10 +279,31 @@ static int ctx_device_init(zkv_ctx* c) {
 // of two, at most ZKV_CHUNK (default 2^20) proofs: a context that only ever verifies single proofs stays small, a 2^20-proof
 // batch runs as one chunk (larger launches amortise kernel tails: 4.12 M proofs/s at 2^18 per chunk against 4.00 at 2^17).
 // Growing frees the old buffers, which synchronises the device, so work in flight on them has finished.
+// Buffers of the aggregate check, sized with the workspace: 224 B of rows per proof and one pseudo-proof workspace per AGG_SUB proofs.
+static int agg_reserve(zkv_ctx* c) {
+    if (!c->agg_on || !c->agg_key_ok || c->agg_cap >= c->ws.cap) return ZKV_OK;
+    void** bufs[] = {(void**)&c->d_agg, (void**)&c->ws2.prep, (void**)&c->ws2.norm, (void**)&c->ws2.f, (void**)&c->ws2.fe, (void**)&c->ws2.flags,
+                     (void**)&c->ws2.g2bad, (void**)&c->d_status2};
+    for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+    c->agg_cap = 0; c->ws2.cap = 0;
+    const size_t cap = c->ws.cap, cap2 = (cap + AGG_SUB - 1) / AGG_SUB;
+    if (hipMalloc(&c->d_agg, sizeof(uint32_t) * WS_AGG_WORDS * cap) != hipSuccess ||
+        hipMalloc(&c->ws2.prep, sizeof(uint32_t) * WS_PREP_WORDS * cap2) != hipSuccess ||
+        hipMalloc(&c->ws2.norm, sizeof(uint32_t) * WS_NORM_WORDS * cap2) != hipSuccess ||
+        hipMalloc(&c->ws2.f, sizeof(uint32_t) * WS_F_WORDS * cap2) != hipSuccess ||
+        hipMalloc(&c->ws2.fe, sizeof(uint32_t) * WS_FE_WORDS * cap2) != hipSuccess ||
+        hipMalloc(&c->ws2.flags, sizeof(uint32_t) * cap2) != hipSuccess || hipMalloc(&c->ws2.g2bad, sizeof(uint32_t) * cap2) != hipSuccess ||
+        hipMalloc(&c->d_status2, cap2) != hipSuccess) {
+        (void)hipGetLastError();
+        return ZKV_ERR_OOM;
+    }
+    c->ws2.cap = cap2; c->agg_cap = cap;
+    return ZKV_OK;
+}
 static int ctx_reserve(zkv_ctx* c, size_t want) {
     const size_t limit = chunk_capacity();
     if (want > limit) want = limit;
-    if (want <= c->ws.cap) return ZKV_OK;
+    if (want <= c->ws.cap) return agg_reserve(c);
     size_t cap = 4096;
     while (cap < want) cap <<= 1;
     if (cap > limit) cap = limit;
@@ -282,7 +331,7 @@ static int ctx_reserve(zkv_ctx* c, size_t want) {
         return ZKV_ERR_OOM;
     }
     c->ws.cap = cap;
-    return ZKV_OK;
+    return agg_reserve(c);
 }
 // device set-up + buffers for a batch of n
 static int ctx_ready(zkv_ctx* c, size_t n) {
@@ -310,6 +359,47 @@ static int mark_done(zkv_ctx* c, hipStream_t s) {
     return ZKV_OK;
 }
 
+// Chunks of at least this many proofs take the aggregate check when it is switched on (below, the per-sub-batch pseudo-proofs are too few
+// to hide their latency: the ordinary kernels are as fast).  ZKV_AGG_MIN overrides.
+static size_t agg_min() {
+    const char* e = getenv("ZKV_AGG_MIN");
+    size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)16384;
+    return v < (size_t)AGG_SUB ? (size_t)AGG_SUB : v;
+}
+// Miller loop / final exponentiation of n proofs in workspace ws with the kernel family the chunk size selects (as enqueue_chunk does)
+static void launch_miller_by_size(zkv_ctx* c, size_t n, const Workspace& ws, uint8_t* status, hipStream_t s) {
+    if (n <= dual_below()) launch_miller_w64d(n, c->d_tab, ws, status, s);
+    else if (n <= wave_below()) launch_miller_w64(n, c->d_tab, ws, s);
+    else if (n <= wide_below()) launch_miller_w(n, c->d_tab, ws, s);
+    else launch_miller2(n, c->d_tab, ws, status, s);
+}
+static void launch_finalexp_by_size(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s) {
+    if (n <= wave_below()) launch_finalexp_w64(n, ws, status, s);
+    else if (n <= wide_below()) launch_finalexp_w(n, ws, status, s);
+    else launch_finalexp2(n, ws, status, s);
+}
+// The aggregate check of one chunk (zkv_agg.h), after PREP: per-proof G1 stage and Miller loop of the variable pair only, one
+// pseudo-proof per sub-batch through the ordinary Miller loop and final exponentiation, then the ordinary stages once more for the
+// proofs of sub-batches that failed (a launch over the whole chunk: wavefronts without such a proof leave at once).
+static void enqueue_agg(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed) {
+    const size_t n2 = (a.n + AGG_SUB - 1) / AGG_SUB;
+    const InstTab* inst = a.inst ? c->d_inst : nullptr;
+    c->agg_seed.call++;                                       // fresh coefficients for every chunk
+    launch_agg_g1(a.n, c->d_tab, inst, c->ws, c->d_agg, c->agg_seed, s);
+    if (timed) { (void)hipEventRecord(c->ev[2], s); (void)hipEventRecord(c->ev[3], s); }
+    launch_miller2(a.n, c->d_tab, c->ws, a.status, s);
+    launch_agg_reduce(a.n, c->ws, c->d_agg, c->d_agg_tab, c->ws2, c->d_status2, s);
+    launch_miller_by_size(c, n2, c->ws2, c->d_status2, s);
+    if (timed) (void)hipEventRecord(c->ev[4], s);
+    launch_agg_fprod(a.n, n2, c->ws, c->d_agg, c->ws2, s);
+    launch_finalexp_by_size(n2, c->ws2, c->d_status2, s);
+    launch_agg_mark(a.n, c->ws, c->d_agg, c->d_status2, a.status, c->d_agg_cnt, s);
+    launch_msm(a.n, c->d_tab, inst, c->ws, s);
+    launch_miller2(a.n, c->d_tab, c->ws, a.status, s);
+    launch_finalexp2(a.n, c->ws, a.status, s);
+    if (timed) (void)hipEventRecord(c->ev[5], s);
+}
+
 // Enqueues the five stages for one chunk (all pointers device-resident).
 static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed) {
     if (timed) (void)hipEventRecord(c->ev[0], s);
@@ -333,6 +423,7 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     else if (c->vm == ZKV_VM_GROTH16) launch_prep_groth16(a, c->ws, s);
     else launch_prep_sp1(a, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[1], s);
+    if (c->agg_on && c->agg_key_ok && c->agg_cap >= c->ws.cap && c->lanes == 0 && a.n >= agg_min()) { enqueue_agg(c, a, s, timed); return; }
     const int lanes = c->lanes ? c->lanes : 2;       // 2 = one proof per lane pair; 16 = one proof per 16 lanes (small chunks); 64 = per wavefront (smallest)
     const bool dual = lanes == 128 || (c->lanes == 0 && a.n <= dual_below());       // 128 = two wavefronts per proof in the Miller loop
     const bool wave = dual || lanes == 64 || (c->lanes == 0 && a.n <= wave_below());
@@ -1549,6 +1640,61 @@ ZKV_EXPORT int zkv_ctx_set_lanes_per_proof(zkv_ctx* c, int lanes) {
     }
     std::lock_guard<std::mutex> lk(c->mu);
     c->lanes = lanes;
+    return ZKV_OK;
+}
+// Aggregate check on / off (zkv_agg.h).  seed32 = nullptr draws the 32 secret bytes from the operating system.
+ZKV_EXPORT int zkv_ctx_set_aggregate_check(zkv_ctx* c, int enable, const uint8_t* seed32) {
+    if (!c) return ZKV_ERR_INVALID_ARG;
+    uint8_t seed[32];
+    if (enable) {
+        if (seed32) memcpy(seed, seed32, 32);
+        else if (getrandom(seed, 32, 0) != 32) return ZKV_ERR_INVALID_ARG;
+    }
+    if (is_sharded(c)) {                                 // every shard its own seed, derived from this one (or drawn afresh)
+        for (size_t k = 0; k < c->shards.size(); k++) {
+            uint8_t sk[32];
+            if (enable && seed32) { uint8_t buf[36]; memcpy(buf, seed, 32); buf[32] = (uint8_t)(k >> 24); buf[33] = (uint8_t)(k >> 16); buf[34] = (uint8_t)(k >> 8); buf[35] = (uint8_t)k; host::sha256_host(buf, 36, sk); }
+            const int rc = zkv_ctx_set_aggregate_check(c->shards[k], enable, enable && seed32 ? sk : nullptr);
+            if (rc != ZKV_OK) return rc;
+        }
+        return ZKV_OK;
+    }
+    if (c->vm == ZKV_VM_MIXED) {
+        for (int k = 0; k < 2; k++) {
+            uint8_t sk[32];
+            if (enable && seed32) { uint8_t buf[33]; memcpy(buf, seed, 32); buf[32] = (uint8_t)k; host::sha256_host(buf, 33, sk); }
+            const int rc = zkv_ctx_set_aggregate_check(c->kid[k], enable, enable && seed32 ? sk : nullptr);
+            if (rc != ZKV_OK) return rc;
+        }
+        return ZKV_OK;
+    }
+    if (c->vm != ZKV_VM_RISC0 && c->vm != ZKV_VM_RISC0_SET && c->vm != ZKV_VM_SP1 && c->vm != ZKV_VM_GROTH16) return enable ? ZKV_ERR_INVALID_ARG : ZKV_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->agg_on = enable != 0;
+    if (enable) for (int i = 0; i < 8; i++) c->agg_seed.w[i] = be32_of(seed + 4 * i);
+    return ZKV_OK;
+}
+// {sub-batches checked, sub-batches that failed and were verified proof by proof} since the context was set up; the calling thread
+// must have synchronised with the batches it wants counted.
+ZKV_EXPORT int zkv_ctx_aggregate_counters(zkv_ctx* c, uint64_t out[2]) {
+    if (!c || !out) return ZKV_ERR_INVALID_ARG;
+    out[0] = out[1] = 0;
+    if (is_sharded(c) || c->vm == ZKV_VM_MIXED) {
+        const size_t nk = is_sharded(c) ? c->shards.size() : 2;
+        for (size_t k = 0; k < nk; k++) {
+            uint64_t o[2];
+            const int rc = zkv_ctx_aggregate_counters(is_sharded(c) ? c->shards[k] : c->kid[k], o);
+            if (rc != ZKV_OK) return rc;
+            out[0] += o[0]; out[1] += o[1];
+        }
+        return ZKV_OK;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->dev_ready || !c->d_agg_cnt) return ZKV_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long v[2];
+    HIP_TRY(hipMemcpy(v, c->d_agg_cnt, sizeof v, hipMemcpyDeviceToHost));
+    out[0] = v[0]; out[1] = v[1];
     return ZKV_OK;
 }
 ZKV_EXPORT int zkv_ctx_reserve(zkv_ctx* c, size_t n) {

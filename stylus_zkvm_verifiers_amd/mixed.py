@@ -9,7 +9,7 @@ import numpy as np
 
 from . import _lib
 from .errors import VM_RISC0, VM_SP1
-from .risc0 import _blob, _cat32, _same_len
+from .risc0 import _aggregate_counters, _blob, _cat32, _same_len, _set_aggregate_check
 
 STATUS_UNKNOWN_VM = 7
 
@@ -54,6 +54,15 @@ class MixedVerifier:
 
     def reserve(self, n):
         _lib.check(self._L.zkv_ctx_reserve(self._h, n), 'zkv_ctx_reserve')
+
+    def set_aggregate_check(self, enable=True, seed=None):
+        """Opt-in: share the pairing check among sub-batches of 64 proofs of a large chunk (include/zkv.h, csrc/zkv_agg.h); statuses
+        stay the deterministic ones (a failed sub-batch is verified again proof by proof)."""
+        _set_aggregate_check(self._L, self._h, enable, seed)
+
+    def aggregate_counters(self):
+        """(sub-batches checked in aggregate, sub-batches that failed and were verified proof by proof)."""
+        return _aggregate_counters(self._L, self._h)
 
     def synchronize(self):
         """Waits for everything this verifier enqueued -- on the MIXED context itself: an all-SP1 batch never sets up the RISC Zero

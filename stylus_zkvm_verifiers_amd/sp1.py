@@ -6,7 +6,7 @@ import numpy as np
 
 from . import _lib
 from .errors import STATUS_OK, STATUS_SELECTOR_MISMATCH, VM_SP1, VerifierError
-from .risc0 import _blob, _cat32, _same_len
+from .risc0 import _aggregate_counters, _blob, _cat32, _same_len, _set_aggregate_check
 
 
 class Sp1Verifier:
@@ -73,6 +73,15 @@ class Sp1Verifier:
     def reserve(self, n):
         """Device set-up and per-chunk buffers for batches of up to n proofs, ahead of the first batch (optional)."""
         _lib.check(self._L.zkv_ctx_reserve(self._h, n), 'zkv_ctx_reserve')
+
+    def set_aggregate_check(self, enable=True, seed=None):
+        """Opt-in: share the pairing check among sub-batches of 64 proofs of a large chunk (include/zkv.h, csrc/zkv_agg.h); statuses
+        stay the deterministic ones (a failed sub-batch is verified again proof by proof)."""
+        _set_aggregate_check(self._L, self._h, enable, seed)
+
+    def aggregate_counters(self):
+        """(sub-batches checked in aggregate, sub-batches that failed and were verified proof by proof)."""
+        return _aggregate_counters(self._L, self._h)
 
     def synchronize(self):
         _lib.check(self._L.zkv_ctx_synchronize(self._h), 'zkv_ctx_synchronize')

@@ -1,0 +1,59 @@
+// Host build of the aggregate-check arithmetic the GPU runs (stylus_zkvm_verifiers_amd/csrc/zkv_agg.h): coefficient derivation,
+// the GLV scalar multiplication, the lanes' shares of E and the three-point normalisation.  TEST ONLY.
+#include <stdint.h>
+#include <string.h>
+#include "../../stylus_zkvm_verifiers_amd/csrc/zkv_agg.h"
+using namespace zkv;
+
+static void be_to_limbs(uint32_t l[8], const uint8_t* p) { load_be256(l, p); }
+static void fp_to_be(uint8_t* o, const Fp& a) {
+    uint32_t r[8];
+    fp_to_raw(r, a);
+    for (int k = 0; k < 8; k++) { uint32_t v = r[7 - k]; o[4 * k] = v >> 24; o[4 * k + 1] = v >> 16; o[4 * k + 2] = v >> 8; o[4 * k + 3] = v; }
+}
+static int affine_out(const G1J& p, uint8_t* out64) {
+    G1A a; uint32_t inf;
+    g1j_to_affine(p, a, inf);
+    fp_to_be(out64, a.x); fp_to_be(out64 + 32, a.y);
+    return inf ? 1 : 0;
+}
+
+extern "C" void hsa_coeff(const uint8_t* seed32, uint32_t call, uint32_t index, uint64_t* r) {
+    AggSeed s;
+    for (int i = 0; i < 8; i++) s.w[i] = load_be32(seed32 + 4 * i);
+    s.call = call;
+    agg_coeff(s, index, r[0], r[1]);
+}
+// r1 P + r2 phi(P); returns 1 for infinity
+extern "C" int hsa_mul(const uint8_t* xy64, uint64_t r1, uint64_t r2, uint8_t* out64) {
+    uint32_t x[8], y[8];
+    be_to_limbs(x, xy64); be_to_limbs(y, xy64 + 32);
+    return affine_out(agg_mul(fp_from_raw(x), fp_from_raw(y), r1, r2), out64);
+}
+// the 64 lanes' shares summed: E = (S1 - c) alpha + S2 phi(alpha)
+extern "C" int hsa_e(const uint8_t* alpha64, uint64_t s1lo, uint32_t s1hi, uint64_t s2lo, uint32_t s2hi, uint32_t c, uint8_t* out64) {
+    static VkRaw vk; static AggTables t;
+    memset(&vk, 0, sizeof vk);
+    be_to_limbs(vk.alpha[0], alpha64); be_to_limbs(vk.alpha[1], alpha64 + 32);
+    for (int j = 0; j < AGG_ALPHA_POW; j++) setup_agg_alpha(vk, t, j);
+    G1J acc = g1j_infinity();
+    for (uint32_t lane = 0; lane < 64; lane++) acc = g1j_add(acc, agg_e_share(t, lane, s1lo, s1hi, s2lo, s2hi, c));
+    return affine_out(acc, out64);
+}
+// (x/y, 1/y) of three points given as affine (or all-zero = infinity) after a random Jacobian rescaling; out: 6 x 32 bytes + flags
+extern "C" uint32_t hsa_norm3(const uint8_t* pts192, const uint8_t* z96, uint8_t* out192) {
+    G1J p[3];
+    for (int k = 0; k < 3; k++) {
+        uint32_t x[8], y[8], z[8];
+        be_to_limbs(x, pts192 + 64 * k); be_to_limbs(y, pts192 + 64 * k + 32); be_to_limbs(z, z96 + 32 * k);
+        if (raw_is_zero(x) && raw_is_zero(y)) { p[k] = g1j_infinity(); continue; }
+        const Fp Z = fp_from_raw(z), Z2 = fp_sqr(Z);
+        p[k].x = fp_mul(fp_from_raw(x), Z2); p[k].y = fp_mul(fp_from_raw(y), fp_mul(Z2, Z)); p[k].z = Z;
+    }
+    uint32_t flags = FL_ALIVE;
+    G1Norm o;
+    agg_normalize3(p[0], p[1], p[2], flags, o);
+    const Fp* f[6] = {&o.axs, &o.ays, &o.lxs, &o.lys, &o.cxs, &o.cys};
+    for (int k = 0; k < 6; k++) fp_to_be(out192 + 32 * k, *f[k]);
+    return flags;
+}

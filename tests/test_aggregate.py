@@ -1,0 +1,221 @@
+"""The opt-in aggregate check (csrc/zkv_agg.h, k_agg.hip): the arithmetic compiled for the host against the spec model's integers, and
+on the GPU the statuses of aggregate-mode batches against the deterministic ones (= the oracle's).  The reference has no such mode
+(it verifies one proof per call); what is pinned here is that switching it on never changes a status."""
+import ctypes as C
+import hashlib
+import os
+import random
+import subprocess
+
+import pytest
+
+import spec_model as m
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LAMBDA = int.from_bytes(b''.join(w.to_bytes(4, 'little') for w in
+                                 (0x36636f23, 0xb8ca0b2d, 0xec2bc5e9, 0xcc37a73f, 0x3fd84104, 0x048b6e19, 0xe131a029, 0x30644e72)), 'little')
+
+
+@pytest.fixture(scope='module')
+def hsa():
+    src = os.path.join(HERE, 'host_sim', 'host_sim_agg.cpp')
+    lib = os.path.join(HERE, 'host_sim', 'libhost_sim_agg.so')
+    csrc = os.path.join(HERE, '..', 'stylus_zkvm_verifiers_amd', 'csrc')
+    deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith('.h')]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-Wno-unknown-pragmas', '-o', lib, src])
+    L = C.CDLL(lib)
+    L.hsa_mul.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_char_p]
+    L.hsa_e.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_char_p]
+    L.hsa_coeff.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.hsa_norm3.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    L.hsa_norm3.restype = C.c_uint32
+    return L
+
+
+def _xy(pt): return b'\0' * 64 if pt is None else m.be32(pt[0]) + m.be32(pt[1])
+def _pt(b): return (int.from_bytes(b[:32], 'big'), int.from_bytes(b[32:64], 'big'))
+
+
+def test_lambda_is_a_cube_root_of_unity_and_the_short_pairs_are_injective():
+    assert (LAMBDA * LAMBDA + LAMBDA + 1) % m.R == 0 and LAMBDA != 1
+    # (r1, r2) -> r1 + r2 lambda is injective on [0, 2^64)^2 iff the lattice {(a, b): a + b lambda = 0 mod R} has no non-zero vector with
+    # |a|, |b| < 2^64: Gauss-reduce its basis (R, 0), (-lambda, 1) and look at the shortest vector
+    u, v = (m.R, 0), (-LAMBDA % m.R, 1)
+    n2 = lambda w: w[0] * w[0] + w[1] * w[1]
+    while True:
+        if n2(u) < n2(v): u, v = v, u
+        q = (u[0] * v[0] + u[1] * v[1] + n2(v) // 2) // n2(v)
+        if q == 0: break
+        u = (u[0] - q * v[0], u[1] - q * v[1])
+    # a vector with both entries below 2^64 is shorter than 2^64.5; every non-zero lattice vector is at least as long as v (~2^127)
+    assert n2(v) > 2 * (1 << 128)
+
+
+def test_coefficients_are_sha256_of_seed_call_index(hsa):
+    seed = bytes(range(32))
+    for call, idx in ((0, 0), (1, 5), (0xFFFFFFFF, 0x03FFFFFF), (7, 1 << 20)):
+        r = (C.c_uint64 * 2)()
+        hsa.hsa_coeff(seed, call, idx, r)
+        h = hashlib.sha256(seed + call.to_bytes(4, 'big') + idx.to_bytes(4, 'big')).digest()
+        assert (r[0], r[1]) == (int.from_bytes(h[:8], 'big'), int.from_bytes(h[8:16], 'big'))
+
+
+def test_glv_scalar_multiplication_matches_the_spec_model(hsa):
+    rng = random.Random(0xA66)
+    g = (1, 2)
+    pts = [g, m.g1_mul(g, 5), m.g1_mul(g, rng.randrange(m.R)), m.g1_mul(g, m.R - 1)]
+    pairs = [(0, 0), (1, 0), (0, 1), (1, 1), (2, 3), ((1 << 64) - 1, (1 << 64) - 1), (1 << 63, 1), (0x8000000000000001, 0xFFFFFFFF00000000)]
+    pairs += [(rng.randrange(1 << 64), rng.randrange(1 << 64)) for _ in range(12)]
+    for p in pts:
+        for r1, r2 in pairs:
+            o = C.create_string_buffer(64)
+            inf = hsa.hsa_mul(_xy(p), r1, r2, o)
+            want = m.g1_mul(p, (r1 + r2 * LAMBDA) % m.R)
+            assert (inf == 1) == (want is None)
+            if want is not None: assert _pt(o.raw) == want
+
+
+def test_lane_shares_sum_to_e(hsa):
+    rng = random.Random(0xE5)
+    alpha = m.g1_mul((1, 2), rng.randrange(1, m.R))
+    cases = [(0, 0, 1), (1, 0, 1), (5, 7, 3), ((1 << 70) - 1, (1 << 70) - 1, 65), (64 * ((1 << 64) - 1), 0, 65), (0, 64 * ((1 << 64) - 1), 1)]
+    cases += [(rng.randrange(1 << 70), rng.randrange(1 << 70), rng.randrange(1, 66)) for _ in range(10)]
+    for s1, s2, c in cases:
+        o = C.create_string_buffer(64)
+        inf = hsa.hsa_e(_xy(alpha), s1 & ((1 << 64) - 1), s1 >> 64, s2 & ((1 << 64) - 1), s2 >> 64, c, o)
+        want = m.g1_mul(alpha, (s1 - c + s2 * LAMBDA) % m.R)
+        assert (inf == 1) == (want is None)
+        if want is not None: assert _pt(o.raw) == want
+
+
+def test_three_point_normalisation(hsa):
+    rng = random.Random(0x303)
+    g = (1, 2)
+    for mask in range(8):
+        pts = [None if mask >> k & 1 else m.g1_mul(g, rng.randrange(1, m.R)) for k in range(3)]
+        z = [rng.randrange(1, m.P) for _ in range(3)]
+        o = C.create_string_buffer(192)
+        fl = hsa.hsa_norm3(b''.join(_xy(p) for p in pts), b''.join(m.be32(v) for v in z), o)
+        assert fl == 1 | (2 if pts[0] is None else 0) | (16 if pts[1] is None else 0) | (8 if pts[2] is None else 0)
+        for k, p in enumerate(pts):
+            xs, ys = int.from_bytes(o.raw[64 * k:64 * k + 32], 'big'), int.from_bytes(o.raw[64 * k + 32:64 * k + 64], 'big')
+            if p is None: assert (xs, ys) == (0, 0)
+            else: assert (xs, ys) == (p[0] * pow(p[1], -1, m.P) % m.P, pow(p[1], -1, m.P))
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+H = bytes.fromhex
+
+
+def _risc0_inputs(real_proofs, n, seed, mutate_every, classes=None):
+    import numpy as np
+    from stylus_zkvm_verifiers_amd import synth
+    r = real_proofs['risc0']
+    kw = {} if classes is None else {'classes': classes}
+    seals, mut, mclass, flip = synth.make_batch('risc0', H(r['seal']), n, seed, pool=8, mutate_every=mutate_every, **kw)
+    ids = np.tile(np.frombuffer(H(r['image_id']), dtype=np.uint8), (n, 1))
+    jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (n, 1)); jds[flip, 0] ^= 1
+    return seals, ids, jds, mut, mclass
+
+
+def _run_risc0_dev(v, seals, ids, jds):
+    import numpy as np
+    import torch
+    dev = torch.device('cuda', 0)
+    n = len(seals)
+    d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (seals, ids, jds)]
+    d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+    v.verify_batch_dev(n, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d_st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return d_st.cpu().numpy()
+
+
+@pytest.mark.gpu
+def test_aggregate_check_gives_the_deterministic_statuses(real_proofs, monkeypatch):
+    """RISC Zero, 4,160 proofs (65 sub-batches, the last one partial...), every mutation class, one proof in 7 mutated: statuses with
+    the aggregate check on == statuses with it off == the oracle's on a sample; the counters show sub-batches that passed and
+    sub-batches that were verified again."""
+    import numpy as np
+    import oracle_lib as ol
+    import stylus_zkvm_verifiers_amd as zkv
+    monkeypatch.setenv('ZKV_AGG_MIN', '64')
+    r = real_proofs['risc0']
+    n = 4160 + 17
+    seals, ids, jds, mut, mclass = _risc0_inputs(real_proofs, n, 0x5A4B56A1, 7)
+    v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    plain = _run_risc0_dev(v, seals, ids, jds)
+    v.set_aggregate_check(True, seed=bytes(range(32)))
+    agg = _run_risc0_dev(v, seals, ids, jds)
+    checked, failed = v.aggregate_counters()
+    assert (agg == plain).all()
+    assert ((agg == 0) == ~mut).all()
+    assert checked == (n + 63) // 64 and 0 < failed <= checked
+    # a second run draws other coefficients (the per-chunk counter): same statuses
+    assert (_run_risc0_dev(v, seals, ids, jds) == plain).all()
+    k = 512
+    orc = ol.Risc0Oracle(); orc.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    ost, _ = orc.verify_batch([x.tobytes() for x in seals[:k]], [x.tobytes() for x in ids[:k]], [x.tobytes() for x in jds[:k]], threads=8)
+    assert (agg[:k] == ost).all()
+    v.set_aggregate_check(False)
+    assert (_run_risc0_dev(v, seals, ids, jds) == plain).all()
+    v.close()
+
+
+@pytest.mark.gpu
+def test_aggregate_check_all_valid_and_only_early_rejects(real_proofs, monkeypatch):
+    """All-valid batch: no sub-batch fails.  Rejects that never reach the pairing (bad selector, length, coordinate, a point off the
+    curve) or whose B fails the subgroup test leave their sub-batch's aggregate check untouched: still no failure."""
+    import stylus_zkvm_verifiers_amd as zkv
+    from stylus_zkvm_verifiers_amd import synth
+    monkeypatch.setenv('ZKV_AGG_MIN', '64')
+    r = real_proofs['risc0']
+    v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    v.set_aggregate_check(True, seed=b'\x07' * 32)
+    n = 2048
+    seals, ids, jds, mut, _ = _risc0_inputs(real_proofs, n, 0x5A4B56A2, 0)
+    st = _run_risc0_dev(v, seals, ids, jds)
+    assert (st == 0).all() and v.aggregate_counters() == (32, 0)
+    early = tuple(c for c in synth.MUTATION_CLASSES if c != 'flip_input')
+    seals, ids, jds, mut, _ = _risc0_inputs(real_proofs, n, 0x5A4B56A3, 5, classes=early)
+    st = _run_risc0_dev(v, seals, ids, jds)
+    assert ((st == 0) == ~mut).all() and mut.sum() > 300
+    assert v.aggregate_counters() == (64, 0)
+    # one wrong public input in the whole batch: exactly one sub-batch is verified again, and only that proof is rejected
+    seals, ids, jds, mut, _ = _risc0_inputs(real_proofs, n, 0x5A4B56A4, 0)
+    jds[777, 3] ^= 0x10
+    st = _run_risc0_dev(v, seals, ids, jds)
+    assert st[777] == 1 and (st == 0).sum() == n - 1
+    assert v.aggregate_counters() == (96, 1)
+    v.close()
+
+
+@pytest.mark.gpu
+def test_aggregate_check_sp1_and_mixed(real_proofs, monkeypatch):
+    import numpy as np
+    import torch
+    import stylus_zkvm_verifiers_amd as zkv
+    from stylus_zkvm_verifiers_amd import synth
+    monkeypatch.setenv('ZKV_AGG_MIN', '64')
+    dev = torch.device('cuda', 0)
+    s = real_proofs['sp1']
+    n = 1500
+    proofs, mut, mclass, flip = synth.make_batch('sp1', H(s['proof']), n, 0x5A4B56A5, pool=4, mutate_every=9)
+    vk = np.tile(np.frombuffer(H(s['vkey']), dtype=np.uint8), (n, 1))
+    pv = np.tile(np.frombuffer(H(s['public_values']), dtype=np.uint8), (n, 1)); pv[flip, -1] ^= 1
+    d_p, d_vk, d_pv = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (proofs, vk, pv))
+    out = []
+    v = zkv.Sp1Verifier()
+    for on in (False, True):
+        if on: v.set_aggregate_check(True, seed=b'\x31' * 32)
+        d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+        v.verify_batch_dev(n, d_vk.data_ptr(), d_pv.data_ptr(), 96, d_p.data_ptr(), d_st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out.append(d_st.cpu().numpy())
+    assert (out[0] == out[1]).all() and ((out[1] == 0) == ~mut).all()
+    checked, failed = v.aggregate_counters()
+    assert checked == (n + 63) // 64 and failed > 0
+    # host-pointer entry point (ragged blobs, several segments)
+    hst, _ = v.verify_batch([x.tobytes() for x in vk], [x.tobytes() for x in pv], [x.tobytes() for x in proofs])
+    assert (np.asarray(hst) == out[0]).all()
+    v.close()
