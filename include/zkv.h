@@ -301,7 +301,8 @@ int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_* */
 int zkv_ctx_set_lanes_per_proof(zkv_ctx* ctx, int lanes);
 /* Aggregate check (no reference counterpart; off by default).  The reference answers one proof per call with one pairing check
  * (common/groth16.rs:60-72, 109-128).  A batch may share that check: with enable != 0, chunks of at least ZKV_AGG_MIN proofs
- * (environment, default 16384) are checked in sub-batches of 64 proofs through ONE product of pairings per sub-batch,
+ * (environment, default 16384) are checked in sub-batches of 64 proofs (enable = 1 or 64; enable = 16 or 32 selects smaller
+ * sub-batches: more shared checks, fewer proofs verified again when one fails) through ONE product of pairings per sub-batch,
  *     prod_i e(r_i (-A_i), B_i) * e(sum_i r_i vk_x_i, gamma) * e(sum_i r_i C_i, delta) * e((sum_i r_i) alpha, beta) == 1,
  * with 128-bit coefficients r_i derived (SHA-256) from 32 secret bytes and a per-chunk counter.  Every check before the pairing
  * equation stays per proof and deterministic (seal format, selector, signal ranges, curve membership of A and C, curve and subgroup

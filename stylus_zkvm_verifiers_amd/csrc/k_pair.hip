@@ -170,7 +170,7 @@ void launch_pairing(size_t n, uint32_t k, const uint8_t* in, const Workspace& ws
 
 // Aggregate check (zkv_agg.h): the product of the Miller values of a sub-batch's proofs, multiplied into the pseudo-proof's slot
 // between its Miller loop and its final exponentiation.  One sub-batch per lane pair, the running product in LDS.
-__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_agg_fprod(size_t n, size_t n2, Workspace ws, const uint32_t* __restrict__ agg, Workspace ws2) {
+__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_agg_fprod(size_t n, size_t n2, uint32_t sub, Workspace ws, const uint32_t* __restrict__ agg, Workspace ws2) {
     __shared__ uint32_t lds[48 * ZKV_BLOCK];
     const size_t sb = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
     if (sb >= n2) return;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_agg_fprod(size_t n, size_t n2,
     LRef acc = l_ref(lds + threadIdx.x);
     MRef P2 = m_ref(ws2.f + (size_t)(8 * par) * ws2.cap + sb, (uint32_t)ws2.cap, 16);
     f12m_copy(acc, P2);
-    const size_t i0 = sb * AGG_SUB, i1 = i0 + AGG_SUB < n ? i0 + AGG_SUB : n;
+    const size_t i0 = sb * sub, i1 = i0 + sub < n ? i0 + sub : n;
 #pragma unroll 1
     for (size_t i = i0; i < i1; i++) {
         if (!(agg[(size_t)AGG_W_FLAGS * ws.cap + i] & FL_ALIVE) || ws.g2bad[i]) continue;      // both lanes of the pair read the same words
@@ -188,9 +188,9 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_agg_fprod(size_t n, size_t n2,
     }
     f12m_copy(P2, acc);
 }
-void launch_agg_fprod(size_t n, size_t n2, const Workspace& ws, const uint32_t* agg, const Workspace& ws2, hipStream_t s) {
+void launch_agg_fprod(size_t n, size_t n2, uint32_t sub, const Workspace& ws, const uint32_t* agg, const Workspace& ws2, hipStream_t s) {
     if (!n2) return;
-    hipLaunchKernelGGL(k_agg_fprod, dim3((unsigned)((2 * n2 + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, n2, ws, agg, ws2);
+    hipLaunchKernelGGL(k_agg_fprod, dim3((unsigned)((2 * n2 + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, n2, sub, ws, agg, ws2);
 }
 
 static inline unsigned pair_grid(size_t n) { return (unsigned)((2 * n + ZKV_BLOCK - 1) / ZKV_BLOCK); }

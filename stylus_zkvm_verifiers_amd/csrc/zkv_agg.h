@@ -1,7 +1,7 @@
 // Aggregate check of a sub-batch of Groth16 proofs (opt-in: zkv_ctx_set_aggregate_check).
 //
 // The reference verifies one proof per call: e(-A, B) e(alpha, beta) e(vk_x, gamma) e(C, delta) == 1 (common/groth16.rs:60-72,
-// 109-128).  A batch service may instead check AGG_SUB proofs with ONE final exponentiation: for coefficients r_i unknown to
+// 109-128).  A batch service may instead check a sub-batch of 16, 32 or 64 proofs with ONE final exponentiation: for coefficients r_i unknown to
 // whoever produced the proofs,
 //     prod_i e(r_i (-A_i), B_i)  *  e(sum_i r_i vk_x_i, gamma)  *  e(sum_i r_i C_i, delta)  *  e((sum_i r_i) alpha, beta)  ==  1
 // holds when every proof of the sub-batch verifies, and with probability 2^-128 over the coefficients otherwise.  Everything before
@@ -17,8 +17,7 @@
 
 namespace zkv {
 
-constexpr int AGG_SUB = 64;              // proofs per aggregate check = one wavefront of the per-lane kernels
-constexpr int AGG_ALPHA_POW = 72;        // 2^j alpha for the bits of sum r1, sum r2 (64 summands of 64 bits: 70 bits)
+constexpr int AGG_ALPHA_POW = 72;        // 2^j alpha for the bits of sum r1, sum r2 (at most 64 summands of 64 bits: 70 bits)
 constexpr int WS_AGG_WORDS = 56;         // per proof: U = r vk_x (24) | W = r C (24) | r1, r2 (4) | the flags word PREP left (1) | pad (3)
 constexpr int AGG_W_U = 0, AGG_W_W = 24, AGG_W_R = 48, AGG_W_FLAGS = 52;
 
@@ -58,17 +57,15 @@ ZKV_HD_NI G1J agg_mul(const Fp& x, const Fp& y, uint64_t r1, uint64_t r2) {
     }
     return acc;
 }
-// One lane's share of E = (S1 - c) alpha + S2 phi(alpha): bit `lane` of S1 and S2 (lanes 0..7 also bit 64 + lane), and bit `lane` of
-// c (c <= AGG_SUB + 1: seven bits) with the negated table entry.  The sum of the 64 shares is E.
-ZKV_HD G1J agg_e_share(const AggTables& t, uint32_t lane, uint64_t s1lo, uint32_t s1hi, uint64_t s2lo, uint32_t s2hi, uint32_t c) {
+// One lane's share of E = (S1 - c) alpha + S2 phi(alpha), `sub` lanes (16, 32 or 64) per sub-batch: bits lane, lane + sub, ... of S1
+// and S2 (below AGG_ALPHA_POW), and bit `lane` of c (c <= sub + 1: seven bits) with the negated table entry.  The sum of the shares is E.
+ZKV_HD G1J agg_e_share(const AggTables& t, uint32_t lane, uint32_t sub, uint64_t s1lo, uint32_t s1hi, uint64_t s2lo, uint32_t s2hi, uint32_t c) {
     const Fp beta = ZKV_GLV_BETA;
     G1J acc = g1j_infinity();
 #pragma unroll 1
-    for (uint32_t h = 0; h < 2; h++) {
-        const uint32_t j = lane + 64u * h;
-        if (j >= (uint32_t)AGG_ALPHA_POW) break;
-        const uint32_t b1 = h ? (s1hi >> lane) & 1u : (uint32_t)(s1lo >> lane) & 1u;
-        const uint32_t b2 = h ? (s2hi >> lane) & 1u : (uint32_t)(s2lo >> lane) & 1u;
+    for (uint32_t j = lane; j < (uint32_t)AGG_ALPHA_POW; j += sub) {
+        const uint32_t b1 = j < 64u ? (uint32_t)(s1lo >> j) & 1u : (s1hi >> (j - 64u)) & 1u;
+        const uint32_t b2 = j < 64u ? (uint32_t)(s2lo >> j) & 1u : (s2hi >> (j - 64u)) & 1u;
         const G1A e = t.alpha_pow[j];
         if (b1) acc = g1j_add_affine(acc, e.x, e.y);
         if (b2) acc = g1j_add_affine(acc, fp_mul(e.x, beta), e.y);
@@ -93,7 +90,7 @@ ZKV_HD void agg_normalize3(const G1J& e, const G1J& u, const G1J& w, uint32_t& f
     o.lxs = fp_mul(fp_mul(u.x, u.z), iyu); o.lys = fp_mul(fp_mul(fp_sqr(u.z), u.z), iyu);
     o.cxs = fp_mul(fp_mul(w.x, w.z), iyw); o.cys = fp_mul(fp_mul(fp_sqr(w.z), w.z), iyw);
 }
-// 2^j alpha (affine) for one j, and beta in Montgomery form
+// 2^j alpha (affine) for one j
 ZKV_HD void setup_agg_alpha(const VkRaw& vk, AggTables& t, int j) {
     if (raw_g1_is_inf(vk.alpha)) { t.alpha_pow[j].x = fp_zero(); t.alpha_pow[j].y = fp_zero(); return; }
     G1J p; p.x = fp_from_raw(vk.alpha[0]); p.y = fp_from_raw(vk.alpha[1]); p.z = fp_one();
@@ -101,12 +98,6 @@ ZKV_HD void setup_agg_alpha(const VkRaw& vk, AggTables& t, int j) {
     for (int i = 0; i < j; i++) p = g1j_dbl(p);
     uint32_t inf;
     g1j_to_affine(p, t.alpha_pow[j], inf);
-}
-ZKV_HD void setup_agg_beta(const VkRaw& vk, AggTables& t) {
-    for (int k = 0; k < 4; k++) t.beta[k] = fp_from_raw(vk.beta[k]);
-    bool ok = raw_g1_valid(vk.alpha) && raw_g2_valid(vk.beta) && raw_g2_valid(vk.gamma) && raw_g2_valid(vk.delta);
-    for (uint32_t i = 0; i < vk.n_ic; i++) ok = ok && raw_g1_valid(vk.ic[i]);
-    t.ok = (ok && !raw_g1_is_inf(vk.alpha) && !raw_g2_is_inf(vk.beta)) ? 1u : 0u;
 }
 #endif  // !ZKV_PAIRED
 

@@ -68,12 +68,18 @@ struct zkv_ctx {
     PlonkKey* d_pkey = nullptr;
     uint32_t* d_plonk_tab = nullptr;                           // per-proof window tables of the PLONK stage (PLONK_TAB_WORDS words per proof in flight)
     // Aggregate check (zkv_agg.h, zkv_ctx_set_aggregate_check): key tables, per-proof rows, the pseudo-proofs' workspace (one per
-    // sub-batch of AGG_SUB proofs), their statuses and the counters {sub-batches checked, sub-batches failed}
+    // sub-batch), their statuses and the counters {sub-batches checked, sub-batches failed}
     bool agg_on = false, agg_key_ok = false;
+    uint32_t agg_sub = 64;                                     // proofs per sub-batch: 16, 32 or 64
     AggTables* d_agg_tab = nullptr;
     uint32_t* d_agg = nullptr;
     Workspace ws2 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     uint8_t* d_status2 = nullptr;
+    // proofs of failed sub-batches, gathered into a dense workspace for the ordinary kernels: own PREP rows, flags and statuses; the
+    // scratch rows (norm, f, fe) are the chunk workspace's
+    Workspace ws3 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    uint8_t* d_status3 = nullptr;
+    uint32_t* d_agg_idx = nullptr;
     unsigned long long* d_agg_cnt = nullptr;
     size_t agg_cap = 0;
     AggSeed agg_seed = {{0, 0, 0, 0, 0, 0, 0, 0}, 0};
@@ -169,9 +175,10 @@ static void ctx_free_device(zkv_ctx* c) {
                      (void**)&c->d_cdoff[0], (void**)&c->d_cdoff[1], (void**)&c->d_len, (void**)&c->d_pvlen, (void**)&c->d_st_all,
                      (void**)&c->d_rv_all, (void**)&c->d_inst, (void**)&c->d_inst_idx, (void**)&c->d_pkey, (void**)&c->d_plonk_tab,
                      (void**)&c->d_agg_tab, (void**)&c->d_agg, (void**)&c->ws2.prep, (void**)&c->ws2.norm, (void**)&c->ws2.f, (void**)&c->ws2.fe,
-                     (void**)&c->ws2.flags, (void**)&c->ws2.g2bad, (void**)&c->d_status2, (void**)&c->d_agg_cnt};
+                     (void**)&c->ws2.flags, (void**)&c->ws2.g2bad, (void**)&c->d_status2, (void**)&c->d_agg_cnt, (void**)&c->ws3.prep, (void**)&c->ws3.flags,
+                     (void**)&c->ws3.g2bad, (void**)&c->d_status3, (void**)&c->d_agg_idx};
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
-    c->ws2.cap = 0; c->agg_cap = 0; c->agg_key_ok = false;
+    c->ws2.cap = 0; c->ws3 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}; c->agg_cap = 0; c->agg_key_ok = false;
     for (int k = 0; k < 6; k++) { if (c->hb[k]) (void)hipFree(c->hb[k]); c->hb[k] = nullptr; c->hb_cap[k] = 0; }
     for (int k = 0; k < 20; k++) { if (c->mx[k]) (void)hipFree(c->mx[k]); c->mx[k] = nullptr; c->mx_cap[k] = 0; }
     c->ws.cap = 0; c->blob_cap = c->pv_cap = 0; c->cd_cap[0] = c->cd_cap[1] = c->st_all_cap = c->rv_all_cap = 0;
@@ -223,8 +230,8 @@ static int ctx_device_setup(zkv_ctx* c) {
         const bool agg_vm = c->vm == ZKV_VM_RISC0 || c->vm == ZKV_VM_RISC0_SET || c->vm == ZKV_VM_SP1 || c->vm == ZKV_VM_GROTH16;
         if (agg_vm) {
             HIP_TRY(hipMalloc(&c->d_agg_tab, sizeof(AggTables)));
-            HIP_TRY(hipMalloc(&c->d_agg_cnt, 2 * sizeof(unsigned long long)));
-            HIP_TRY(hipMemsetAsync(c->d_agg_cnt, 0, 2 * sizeof(unsigned long long), c->stream));
+            HIP_TRY(hipMalloc(&c->d_agg_cnt, 3 * sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(c->d_agg_cnt, 0, 3 * sizeof(unsigned long long), c->stream));
             launch_setup_agg(d_raw, c->d_tab, c->d_agg_tab, c->stream);
             HIP_TRY(hipGetLastError());
         }
@@ -279,24 +286,29 @@ static int ctx_device_init(zkv_ctx* c) {
 // of two, at most ZKV_CHUNK (default 2^20) proofs: a context that only ever verifies single proofs stays small, a 2^20-proof
 // batch runs as one chunk (larger launches amortise kernel tails: 4.12 M proofs/s at 2^18 per chunk against 4.00 at 2^17).
 // Growing frees the old buffers, which synchronises the device, so work in flight on them has finished.
-// Buffers of the aggregate check, sized with the workspace: 224 B of rows per proof and one pseudo-proof workspace per AGG_SUB proofs.
+// Buffers of the aggregate check, sized with the workspace: 224 B of rows per proof and one pseudo-proof workspace per 16 proofs (the smallest sub-batch).
 static int agg_reserve(zkv_ctx* c) {
     if (!c->agg_on || !c->agg_key_ok || c->agg_cap >= c->ws.cap) return ZKV_OK;
     void** bufs[] = {(void**)&c->d_agg, (void**)&c->ws2.prep, (void**)&c->ws2.norm, (void**)&c->ws2.f, (void**)&c->ws2.fe, (void**)&c->ws2.flags,
-                     (void**)&c->ws2.g2bad, (void**)&c->d_status2};
+                     (void**)&c->ws2.g2bad, (void**)&c->d_status2, (void**)&c->ws3.prep, (void**)&c->ws3.flags, (void**)&c->ws3.g2bad, (void**)&c->d_status3,
+                     (void**)&c->d_agg_idx};
     for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
-    c->agg_cap = 0; c->ws2.cap = 0;
-    const size_t cap = c->ws.cap, cap2 = (cap + AGG_SUB - 1) / AGG_SUB;
+    c->agg_cap = 0; c->ws2.cap = 0; c->ws3.cap = 0;
+    const size_t cap = c->ws.cap, cap2 = (cap + 15) / 16;      // room for the smallest sub-batch size
     if (hipMalloc(&c->d_agg, sizeof(uint32_t) * WS_AGG_WORDS * cap) != hipSuccess ||
         hipMalloc(&c->ws2.prep, sizeof(uint32_t) * WS_PREP_WORDS * cap2) != hipSuccess ||
         hipMalloc(&c->ws2.norm, sizeof(uint32_t) * WS_NORM_WORDS * cap2) != hipSuccess ||
         hipMalloc(&c->ws2.f, sizeof(uint32_t) * WS_F_WORDS * cap2) != hipSuccess ||
         hipMalloc(&c->ws2.fe, sizeof(uint32_t) * WS_FE_WORDS * cap2) != hipSuccess ||
         hipMalloc(&c->ws2.flags, sizeof(uint32_t) * cap2) != hipSuccess || hipMalloc(&c->ws2.g2bad, sizeof(uint32_t) * cap2) != hipSuccess ||
-        hipMalloc(&c->d_status2, cap2) != hipSuccess) {
+        hipMalloc(&c->d_status2, cap2) != hipSuccess ||
+        hipMalloc(&c->ws3.prep, sizeof(uint32_t) * WS_PREP_WORDS * cap) != hipSuccess || hipMalloc(&c->ws3.flags, sizeof(uint32_t) * cap) != hipSuccess ||
+        hipMalloc(&c->ws3.g2bad, sizeof(uint32_t) * cap) != hipSuccess || hipMalloc(&c->d_status3, cap) != hipSuccess ||
+        hipMalloc(&c->d_agg_idx, sizeof(uint32_t) * cap) != hipSuccess) {
         (void)hipGetLastError();
         return ZKV_ERR_OOM;
     }
+    c->ws3.norm = c->ws.norm; c->ws3.f = c->ws.f; c->ws3.fe = c->ws.fe; c->ws3.cap = cap;
     c->ws2.cap = cap2; c->agg_cap = cap;
     return ZKV_OK;
 }
@@ -364,7 +376,7 @@ static int mark_done(zkv_ctx* c, hipStream_t s) {
 static size_t agg_min() {
     const char* e = getenv("ZKV_AGG_MIN");
     size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)16384;
-    return v < (size_t)AGG_SUB ? (size_t)AGG_SUB : v;
+    return v < 64 ? 64 : v;
 }
 // Miller loop / final exponentiation of n proofs in workspace ws with the kernel family the chunk size selects (as enqueue_chunk does)
 static void launch_miller_by_size(zkv_ctx* c, size_t n, const Workspace& ws, uint8_t* status, hipStream_t s) {
@@ -380,23 +392,27 @@ static void launch_finalexp_by_size(size_t n, const Workspace& ws, uint8_t* stat
 }
 // The aggregate check of one chunk (zkv_agg.h), after PREP: per-proof G1 stage and Miller loop of the variable pair only, one
 // pseudo-proof per sub-batch through the ordinary Miller loop and final exponentiation, then the ordinary stages once more for the
-// proofs of sub-batches that failed (a launch over the whole chunk: wavefronts without such a proof leave at once).
+// proofs of sub-batches that failed, gathered into a dense workspace (the launches cover the whole chunk -- the host does not know how
+// many there are -- and wavefronts past the end of the list leave at once).
 static void enqueue_agg(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed) {
-    const size_t n2 = (a.n + AGG_SUB - 1) / AGG_SUB;
+    const uint32_t sub = c->agg_sub;
+    const size_t n2 = (a.n + sub - 1) / sub;
     const InstTab* inst = a.inst ? c->d_inst : nullptr;
     c->agg_seed.call++;                                       // fresh coefficients for every chunk
     launch_agg_g1(a.n, c->d_tab, inst, c->ws, c->d_agg, c->agg_seed, s);
     if (timed) { (void)hipEventRecord(c->ev[2], s); (void)hipEventRecord(c->ev[3], s); }
     launch_miller2(a.n, c->d_tab, c->ws, a.status, s);
-    launch_agg_reduce(a.n, c->ws, c->d_agg, c->d_agg_tab, c->ws2, c->d_status2, s);
+    launch_agg_reduce(a.n, sub, c->ws, c->d_agg, c->d_agg_tab, c->ws2, c->d_status2, s);
     launch_miller_by_size(c, n2, c->ws2, c->d_status2, s);
     if (timed) (void)hipEventRecord(c->ev[4], s);
-    launch_agg_fprod(a.n, n2, c->ws, c->d_agg, c->ws2, s);
+    launch_agg_fprod(a.n, n2, sub, c->ws, c->d_agg, c->ws2, s);
     launch_finalexp_by_size(n2, c->ws2, c->d_status2, s);
-    launch_agg_mark(a.n, c->ws, c->d_agg, c->d_status2, a.status, c->d_agg_cnt, s);
-    launch_msm(a.n, c->d_tab, inst, c->ws, s);
-    launch_miller2(a.n, c->d_tab, c->ws, a.status, s);
-    launch_finalexp2(a.n, c->ws, a.status, s);
+    launch_agg_mark(a.n, sub, c->ws, c->d_agg, c->d_status2, a.status, c->d_agg_cnt, c->d_agg_idx, s);
+    launch_agg_gather(a.n, c->ws, c->d_agg, c->d_agg_cnt, c->d_agg_idx, c->ws3, c->d_status3, s);
+    launch_msm(a.n, c->d_tab, inst, c->ws3, s);
+    launch_miller2(a.n, c->d_tab, c->ws3, c->d_status3, s);
+    launch_finalexp2(a.n, c->ws3, c->d_status3, s);
+    launch_agg_scatter(a.n, c->d_agg_cnt, c->d_agg_idx, c->d_status3, a.status, s);
     if (timed) (void)hipEventRecord(c->ev[5], s);
 }
 
@@ -1644,7 +1660,7 @@ ZKV_EXPORT int zkv_ctx_set_lanes_per_proof(zkv_ctx* c, int lanes) {
 }
 // Aggregate check on / off (zkv_agg.h).  seed32 = nullptr draws the 32 secret bytes from the operating system.
 ZKV_EXPORT int zkv_ctx_set_aggregate_check(zkv_ctx* c, int enable, const uint8_t* seed32) {
-    if (!c) return ZKV_ERR_INVALID_ARG;
+    if (!c || (enable != 0 && enable != 1 && enable != 16 && enable != 32 && enable != 64)) return ZKV_ERR_INVALID_ARG;
     uint8_t seed[32];
     if (enable) {
         if (seed32) memcpy(seed, seed32, 32);
@@ -1671,6 +1687,7 @@ ZKV_EXPORT int zkv_ctx_set_aggregate_check(zkv_ctx* c, int enable, const uint8_t
     if (c->vm != ZKV_VM_RISC0 && c->vm != ZKV_VM_RISC0_SET && c->vm != ZKV_VM_SP1 && c->vm != ZKV_VM_GROTH16) return enable ? ZKV_ERR_INVALID_ARG : ZKV_OK;
     std::lock_guard<std::mutex> lk(c->mu);
     c->agg_on = enable != 0;
+    if (enable) c->agg_sub = enable == 1 ? 64u : (uint32_t)enable;
     if (enable) for (int i = 0; i < 8; i++) c->agg_seed.w[i] = be32_of(seed + 4 * i);
     return ZKV_OK;
 }

@@ -30,14 +30,14 @@ extern "C" int hsa_mul(const uint8_t* xy64, uint64_t r1, uint64_t r2, uint8_t* o
     be_to_limbs(x, xy64); be_to_limbs(y, xy64 + 32);
     return affine_out(agg_mul(fp_from_raw(x), fp_from_raw(y), r1, r2), out64);
 }
-// the 64 lanes' shares summed: E = (S1 - c) alpha + S2 phi(alpha)
-extern "C" int hsa_e(const uint8_t* alpha64, uint64_t s1lo, uint32_t s1hi, uint64_t s2lo, uint32_t s2hi, uint32_t c, uint8_t* out64) {
+// the lanes' shares summed (sub = 16, 32 or 64 lanes per sub-batch): E = (S1 - c) alpha + S2 phi(alpha)
+extern "C" int hsa_e(const uint8_t* alpha64, uint32_t sub, uint64_t s1lo, uint32_t s1hi, uint64_t s2lo, uint32_t s2hi, uint32_t c, uint8_t* out64) {
     static VkRaw vk; static AggTables t;
     memset(&vk, 0, sizeof vk);
     be_to_limbs(vk.alpha[0], alpha64); be_to_limbs(vk.alpha[1], alpha64 + 32);
     for (int j = 0; j < AGG_ALPHA_POW; j++) setup_agg_alpha(vk, t, j);
     G1J acc = g1j_infinity();
-    for (uint32_t lane = 0; lane < 64; lane++) acc = g1j_add(acc, agg_e_share(t, lane, s1lo, s1hi, s2lo, s2hi, c));
+    for (uint32_t lane = 0; lane < sub; lane++) acc = g1j_add(acc, agg_e_share(t, lane, sub, s1lo, s1hi, s2lo, s2hi, c));
     return affine_out(acc, out64);
 }
 // (x/y, 1/y) of three points given as affine (or all-zero = infinity) after a random Jacobian rescaling; out: 6 x 32 bytes + flags

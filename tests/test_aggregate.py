@@ -26,7 +26,7 @@ def hsa():
         subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-Wno-unknown-pragmas', '-o', lib, src])
     L = C.CDLL(lib)
     L.hsa_mul.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_char_p]
-    L.hsa_e.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_char_p]
+    L.hsa_e.argtypes = [C.c_char_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_char_p]
     L.hsa_coeff.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.hsa_norm3.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
     L.hsa_norm3.restype = C.c_uint32
@@ -81,12 +81,13 @@ def test_lane_shares_sum_to_e(hsa):
     alpha = m.g1_mul((1, 2), rng.randrange(1, m.R))
     cases = [(0, 0, 1), (1, 0, 1), (5, 7, 3), ((1 << 70) - 1, (1 << 70) - 1, 65), (64 * ((1 << 64) - 1), 0, 65), (0, 64 * ((1 << 64) - 1), 1)]
     cases += [(rng.randrange(1 << 70), rng.randrange(1 << 70), rng.randrange(1, 66)) for _ in range(10)]
-    for s1, s2, c in cases:
-        o = C.create_string_buffer(64)
-        inf = hsa.hsa_e(_xy(alpha), s1 & ((1 << 64) - 1), s1 >> 64, s2 & ((1 << 64) - 1), s2 >> 64, c, o)
-        want = m.g1_mul(alpha, (s1 - c + s2 * LAMBDA) % m.R)
-        assert (inf == 1) == (want is None)
-        if want is not None: assert _pt(o.raw) == want
+    for k, (s1, s2, c) in enumerate(cases):
+        for sub in ((16, 32, 64) if k < 8 else (64,)):
+            o = C.create_string_buffer(64)
+            inf = hsa.hsa_e(_xy(alpha), sub, s1 & ((1 << 64) - 1), s1 >> 64, s2 & ((1 << 64) - 1), s2 >> 64, c, o)
+            want = m.g1_mul(alpha, (s1 - c + s2 * LAMBDA) % m.R)
+            assert (inf == 1) == (want is None)
+            if want is not None: assert _pt(o.raw) == want
 
 
 def test_three_point_normalisation(hsa):
@@ -145,12 +146,15 @@ def test_aggregate_check_gives_the_deterministic_statuses(real_proofs, monkeypat
     seals, ids, jds, mut, mclass = _risc0_inputs(real_proofs, n, 0x5A4B56A1, 7)
     v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
     plain = _run_risc0_dev(v, seals, ids, jds)
-    v.set_aggregate_check(True, seed=bytes(range(32)))
-    agg = _run_risc0_dev(v, seals, ids, jds)
-    checked, failed = v.aggregate_counters()
-    assert (agg == plain).all()
-    assert ((agg == 0) == ~mut).all()
-    assert checked == (n + 63) // 64 and 0 < failed <= checked
+    total = 0
+    for sub in (16, 32, 64):
+        v.set_aggregate_check(True, seed=bytes(range(32)), sub_batch=sub)
+        agg = _run_risc0_dev(v, seals, ids, jds)
+        checked, failed = v.aggregate_counters()
+        assert (agg == plain).all(), sub
+        assert ((agg == 0) == ~mut).all()
+        total += (n + sub - 1) // sub
+        assert checked == total and 0 < failed <= checked
     # a second run draws other coefficients (the per-chunk counter): same statuses
     assert (_run_risc0_dev(v, seals, ids, jds) == plain).all()
     k = 512
@@ -159,6 +163,7 @@ def test_aggregate_check_gives_the_deterministic_statuses(real_proofs, monkeypat
     assert (agg[:k] == ost).all()
     v.set_aggregate_check(False)
     assert (_run_risc0_dev(v, seals, ids, jds) == plain).all()
+    with pytest.raises(Exception): v.set_aggregate_check(True, sub_batch=48)
     v.close()
 
 
