@@ -14,9 +14,11 @@ __global__ __launch_bounds__(64) void k_setup_agg(const VkRaw* __restrict__ raw,
         for (int k = 0; k < 4; k++) t->beta[k] = fp_from_raw(raw->beta[k]);
         t->ok = (tab->vk_valid && !raw_g1_is_inf(raw->alpha) && !raw_g2_is_inf(raw->beta)) ? 1u : 0u;
     }
+    const int w = j - AGG_ALPHA_POW - 1;                        // the window rows of the vk_x constant term (k_setup_base ran before)
+    if (w >= 0 && w < MSM_MAX_WINDOWS) setup_agg_base_row(*tab, *t, w);
 }
 void launch_setup_agg(const VkRaw* d_raw, const VkTables* d_tab, AggTables* d_agg, hipStream_t s) {
-    hipLaunchKernelGGL(k_setup_agg, dim3(2), dim3(64), 0, s, d_raw, d_tab, d_agg);
+    hipLaunchKernelGGL(k_setup_agg, dim3(2), dim3(64), 0, s, d_raw, d_tab, d_agg);     // 72 + 1 + 32 lanes at work
 }
 
 __device__ __forceinline__ void agg_st_g1j(uint32_t* agg, size_t cap, int word0, size_t i, const G1J& p) {
@@ -27,11 +29,16 @@ __device__ __forceinline__ G1J agg_ld_g1j(const uint32_t* agg, size_t cap, int w
     return p;
 }
 
-// Per proof: vk_x as in k_msm, the coefficient r, then A' <- r A' (normalised into the rows the Miller loop reads), U = r vk_x and
-// W = r C (Jacobian, summed per sub-batch later).  The proof's flags word is saved and replaced by one that tells k_miller2 to skip
-// both fixed pairs: its Miller value is then f_i = ML(r A', B) * ML(alpha, beta).
+// Per proof: the coefficient r, A' <- r A' (normalised into the rows the Miller loop reads) and W = r C (Jacobian, summed per sub-batch
+// later); for vk_x either the scalars r, r s_0, r s_1 mod r (sums != 0: one key, at most two per-proof signals) or U = r vk_x with vk_x as
+// in k_msm.  The proof's flags word is saved and replaced by one that tells k_miller2 to skip both fixed pairs: its Miller value is then
+// f_i = ML(r A', B) * ML(alpha, beta).
+__device__ __forceinline__ void agg_st_fr(uint32_t* agg, size_t cap, int word0, size_t i, const Fr& a) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) agg[(size_t)(word0 + k) * cap + i] = a.v[k];
+}
 __global__ __launch_bounds__(ZKV_BLOCK) void k_agg_g1(size_t n, const VkTables* __restrict__ vk, const InstTab* __restrict__ inst_tab, Workspace ws,
-                                                      uint32_t* __restrict__ agg, AggSeed seed) {
+                                                      uint32_t* __restrict__ agg, AggSeed seed, uint32_t sums) {
     size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint32_t flags0 = ws.flags[i];
@@ -45,17 +52,26 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_agg_g1(size_t n, const VkTables* 
 #pragma unroll
         for (int k = 0; k < 8; k++) in.s[b][k] = ws.prep[(size_t)(64 + 8 * b + k) * ws.cap + i];
     }
-    G1J L;
-    uint32_t flags = flags0;
-    if (inst_tab) { const InstTab& t = inst_tab[flags >> 8]; flags &= 0xFFu; L = msm_accumulate(*vk, in, t.base, t.base_inf); }
-    else L = msm_accumulate(*vk, in);
     uint64_t r1, r2;
     agg_coeff(seed, (uint32_t)i, r1, r2);
     agg[(size_t)(AGG_W_R + 0) * ws.cap + i] = (uint32_t)r1; agg[(size_t)(AGG_W_R + 1) * ws.cap + i] = (uint32_t)(r1 >> 32);
     agg[(size_t)(AGG_W_R + 2) * ws.cap + i] = (uint32_t)r2; agg[(size_t)(AGG_W_R + 3) * ws.cap + i] = (uint32_t)(r2 >> 32);
-    G1A la; uint32_t linf;
-    g1j_to_affine(L, la, linf);
-    agg_st_g1j(agg, ws.cap, AGG_W_U, i, linf ? g1j_infinity() : agg_mul(la.x, la.y, r1, r2));
+    uint32_t flags = flags0;
+    if (sums) {
+        const Fr rm = agg_coeff_fr(r1, r2);
+        agg_st_fr(agg, ws.cap, AGG_W_U, i, rm);
+#pragma unroll 1
+        for (uint32_t b = 0; b < (uint32_t)AGG_SUM_VARS; b++)
+            agg_st_fr(agg, ws.cap, AGG_W_U + 8 + 8 * (int)b, i, b < vk->n_var ? fr_mul(fr_from_raw(in.s[b]), rm) : fr_zero());     // signals are < r (PREP)
+    } else {
+        G1J L;
+        if (inst_tab) { const InstTab& t = inst_tab[flags >> 8]; L = msm_accumulate(*vk, in, t.base, t.base_inf); }
+        else L = msm_accumulate(*vk, in);
+        G1A la; uint32_t linf;
+        g1j_to_affine(L, la, linf);
+        agg_st_g1j(agg, ws.cap, AGG_W_U, i, linf ? g1j_infinity() : agg_mul(la.x, la.y, r1, r2));
+    }
+    if (inst_tab) flags &= 0xFFu;
     agg_st_g1j(agg, ws.cap, AGG_W_W, i, (flags & FL_C_INF) ? g1j_infinity() : agg_mul(in.cx, in.cy, r1, r2));
     flags |= FL_L_INF | FL_C_INF;                               // for the Miller kernel only: the fixed pairs are taken per sub-batch
     if (!(flags & FL_A_INF)) {
@@ -86,23 +102,40 @@ __device__ __forceinline__ G1J g1j_xor(const G1J& p, int mask) {
 // lane + sub, ... of S1 and S2) and a third butterfly -- every proof's Miller value and the pseudo-proof's carry one factor
 // ML(alpha, beta), hence the cnt + 1.  The group's first lane writes the pseudo-proof (A := E, B := beta, vk_x := sum U, C := sum W) into
 // the second workspace.
-__global__ __launch_bounds__(ZKV_BLOCK) void k_agg_reduce(size_t n, uint32_t sub, Workspace ws, const uint32_t* __restrict__ agg,
-                                                          const AggTables* __restrict__ tab, Workspace ws2, uint8_t* __restrict__ status2) {
+__device__ __forceinline__ Fr fr_xor(const Fr& a, int mask) {
+    Fr r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.v[k] = (uint32_t)__shfl_xor((int)a.v[k], mask, 64);
+    return r;
+}
+__device__ __forceinline__ Fr agg_ld_fr(const uint32_t* agg, size_t cap, int word0, size_t i) {
+    Fr r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.v[k] = agg[(size_t)(word0 + k) * cap + i];
+    return r;
+}
+__global__ __launch_bounds__(ZKV_BLOCK) void k_agg_reduce(size_t n, uint32_t sub, uint32_t sums, const VkTables* __restrict__ vk, Workspace ws,
+                                                          const uint32_t* __restrict__ agg, const AggTables* __restrict__ tab, Workspace ws2,
+                                                          uint8_t* __restrict__ status2) {
     const size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     const uint32_t lane = threadIdx.x & (sub - 1u);
     const size_t sb = i / sub;
     bool in = false;
     if (i < n) in = (agg[(size_t)AGG_W_FLAGS * ws.cap + i] & FL_ALIVE) && !ws.g2bad[i];
     G1J U = g1j_infinity(), W = g1j_infinity();
+    Fr Rm = fr_zero(), T0 = fr_zero(), T1 = fr_zero();         // sums of r, r s_0, r s_1 mod r (the scalar form of vk_x)
     uint32_t s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0}, cnt = in ? 1u : 0u;
     if (in) {
-        U = agg_ld_g1j(agg, ws.cap, AGG_W_U, i); W = agg_ld_g1j(agg, ws.cap, AGG_W_W, i);
+        if (sums) { Rm = agg_ld_fr(agg, ws.cap, AGG_W_U, i); T0 = agg_ld_fr(agg, ws.cap, AGG_W_U + 8, i); T1 = agg_ld_fr(agg, ws.cap, AGG_W_U + 16, i); }
+        else U = agg_ld_g1j(agg, ws.cap, AGG_W_U, i);
+        W = agg_ld_g1j(agg, ws.cap, AGG_W_W, i);
         s1[0] = agg[(size_t)(AGG_W_R + 0) * ws.cap + i]; s1[1] = agg[(size_t)(AGG_W_R + 1) * ws.cap + i];
         s2[0] = agg[(size_t)(AGG_W_R + 2) * ws.cap + i]; s2[1] = agg[(size_t)(AGG_W_R + 3) * ws.cap + i];
     }
 #pragma unroll 1
     for (int m = (int)sub >> 1; m >= 1; m >>= 1) {
-        U = g1j_add(U, g1j_xor(U, m));
+        if (sums) { Rm = fr_add(Rm, fr_xor(Rm, m)); T0 = fr_add(T0, fr_xor(T0, m)); T1 = fr_add(T1, fr_xor(T1, m)); }
+        else U = g1j_add(U, g1j_xor(U, m));
         W = g1j_add(W, g1j_xor(W, m));
         uint32_t c = 0;
         s1[0] = addc(s1[0], (uint32_t)__shfl_xor((int)s1[0], m, 64), c); s1[1] = addc(s1[1], (uint32_t)__shfl_xor((int)s1[1], m, 64), c);
@@ -111,6 +144,13 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_agg_reduce(size_t n, uint32_t sub
         s2[0] = addc(s2[0], (uint32_t)__shfl_xor((int)s2[0], m, 64), c); s2[1] = addc(s2[1], (uint32_t)__shfl_xor((int)s2[1], m, 64), c);
         s2[2] = addc(s2[2], (uint32_t)__shfl_xor((int)s2[2], m, 64), c);
         cnt += (uint32_t)__shfl_xor((int)cnt, m, 64);
+    }
+    if (sums) {                                                 // every lane holds the sums: its windows of them, then a butterfly as for U itself
+        uint32_t R[8], T[AGG_SUM_VARS][8];
+        fr_to_raw(R, Rm); fr_to_raw(T[0], T0); fr_to_raw(T[1], T1);
+        U = agg_u_share(*vk, *tab, lane, sub, R, T);
+#pragma unroll 1
+        for (int m = (int)sub >> 1; m >= 1; m >>= 1) U = g1j_add(U, g1j_xor(U, m));
     }
     G1J E = agg_e_share(*tab, lane, sub, ((uint64_t)s1[1] << 32) | s1[0], s1[2], ((uint64_t)s2[1] << 32) | s2[0], s2[2], cnt + 1u);
 #pragma unroll 1
@@ -176,13 +216,14 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_agg_scatter(size_t n, const unsig
     if (j < n && j < counters[2]) status[idx[j]] = status3[j];
 }
 
-void launch_agg_g1(size_t n, const VkTables* d_tab, const InstTab* inst_tab, const Workspace& ws, uint32_t* agg, const AggSeed& seed, hipStream_t s) {
+void launch_agg_g1(size_t n, const VkTables* d_tab, const InstTab* inst_tab, const Workspace& ws, uint32_t* agg, const AggSeed& seed, bool sums, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_agg_g1, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, d_tab, inst_tab, ws, agg, seed);
+    hipLaunchKernelGGL(k_agg_g1, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, d_tab, inst_tab, ws, agg, seed, sums ? 1u : 0u);
 }
-void launch_agg_reduce(size_t n, uint32_t sub, const Workspace& ws, const uint32_t* agg, const AggTables* tab, const Workspace& ws2, uint8_t* status2, hipStream_t s) {
+void launch_agg_reduce(size_t n, uint32_t sub, bool sums, const VkTables* d_tab, const Workspace& ws, const uint32_t* agg, const AggTables* tab, const Workspace& ws2,
+                       uint8_t* status2, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_agg_reduce, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, sub, ws, agg, tab, ws2, status2);
+    hipLaunchKernelGGL(k_agg_reduce, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, sub, sums ? 1u : 0u, d_tab, ws, agg, tab, ws2, status2);
 }
 void launch_agg_mark(size_t n, uint32_t sub, const Workspace& ws, const uint32_t* agg, const uint8_t* status2, uint8_t* status, unsigned long long* counters,
                      uint32_t* idx, hipStream_t s) {

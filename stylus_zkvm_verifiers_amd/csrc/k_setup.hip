@@ -16,10 +16,11 @@ __global__ __launch_bounds__(64) void k_setup_lines(const VkRaw* __restrict__ ra
     if (threadIdx.x == 0) setup_lines(raw->gamma, t->lines[0]);
     if (threadIdx.x == 1) setup_lines(raw->delta, t->lines[1]);
 }
-// one lane per (scalar, window) row of the fixed-base MSM table
+// one lane per (scalar, window) row of the fixed-base MSM table; all 32 windows of every per-proof scalar (the vk_x stage reads
+// var_windows[b] of them, the aggregate check all)
 __global__ __launch_bounds__(64) void k_setup_msm(const VkRaw* __restrict__ raw, VkTables* __restrict__ t) {
     int b = blockIdx.x, w = threadIdx.x;
-    if (b < (int)raw->n_var && w < (int)raw->var_windows[b]) setup_msm_row(*raw, *t, b, w);
+    if (b < (int)raw->n_var && w < MSM_MAX_WINDOWS) setup_msm_row(*raw, *t, b, w);
 }
 // Miller value of (alpha, beta); f and T of the single lane live in LDS like in k_miller
 __global__ __launch_bounds__(64) void k_setup_alpha_beta(const VkRaw* __restrict__ raw, VkTables* __restrict__ t) {

@@ -399,10 +399,12 @@ static void enqueue_agg(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed
     const size_t n2 = (a.n + sub - 1) / sub;
     const InstTab* inst = a.inst ? c->d_inst : nullptr;
     c->agg_seed.call++;                                       // fresh coefficients for every chunk
-    launch_agg_g1(a.n, c->d_tab, inst, c->ws, c->d_agg, c->agg_seed, s);
+    // vk_x through summed scalars: one key (no per-proof base) and at most two per-proof signals
+    const bool sums = !inst && (c->vm == ZKV_VM_RISC0 || c->vm == ZKV_VM_SP1 || (c->vm == ZKV_VM_GROTH16 && c->g_n_ic >= 1 && c->g_n_ic - 1 <= (uint32_t)AGG_SUM_VARS));
+    launch_agg_g1(a.n, c->d_tab, inst, c->ws, c->d_agg, c->agg_seed, sums, s);
     if (timed) { (void)hipEventRecord(c->ev[2], s); (void)hipEventRecord(c->ev[3], s); }
     launch_miller2(a.n, c->d_tab, c->ws, a.status, s);
-    launch_agg_reduce(a.n, sub, c->ws, c->d_agg, c->d_agg_tab, c->ws2, c->d_status2, s);
+    launch_agg_reduce(a.n, sub, sums, c->d_tab, c->ws, c->d_agg, c->d_agg_tab, c->ws2, c->d_status2, s);
     launch_miller_by_size(c, n2, c->ws2, c->d_status2, s);
     if (timed) (void)hipEventRecord(c->ev[4], s);
     launch_agg_fprod(a.n, n2, sub, c->ws, c->d_agg, c->ws2, s);

@@ -530,20 +530,14 @@ ZKV_HD void setup_base(const VkRaw& vk, VkTables& t) {
     t.n_var = vk.n_var;
     for (int b = 0; b < MAX_VAR; b++) t.var_windows[b] = vk.var_windows[b];
 }
-// one (b, w) row of the fixed-base table: d * 256^w * IC_var[b], d = 1..255, all affine.
+// one window row of a fixed-base table: d * 256^w * P, d = 1..255, all affine (P = (x, y), not infinity).
 // The row is built by doubling levels (1 | 2 3 | 4..7 | ... | 128..255): level m adds mP to the known multiples 1..m-1 and doubles
 // mP; the m slopes of a level share ONE field inversion (prefix products parked in the y slots that are about to be written).
-ZKV_HD void setup_msm_row(const VkRaw& vk, VkTables& t, int b, int w) {
-    uint32_t ici = vk.var_ic[b];
-    if (raw_g1_is_inf(vk.ic[ici])) {             // s * infinity = infinity: leave the row zero and never read it
-        if (w == 0) t.var_windows[b] = 0;
-        return;
-    }
-    G1J p; p.x = fp_from_raw(vk.ic[ici][0]); p.y = fp_from_raw(vk.ic[ici][1]); p.z = fp_one();
+ZKV_HD void setup_window_row(const Fp& x, const Fp& y, int w, G1A* row) {
+    G1J p; p.x = x; p.y = y; p.z = fp_one();
 #pragma unroll 1
     for (int i = 0; i < 8 * w; i++) p = g1j_dbl(p);
     Fp zi = fp_inv(p.z), zi2 = fp_sqr(zi);
-    G1A* row = t.msm[b][w];
     row[0].x = fp_zero(); row[0].y = fp_zero();
     row[1].x = fp_mul(p.x, zi2); row[1].y = fp_mul(p.y, fp_mul(zi2, zi));
 #pragma unroll 1
@@ -571,6 +565,16 @@ ZKV_HD void setup_msm_row(const VkRaw& vk, VkTables& t, int b, int w) {
             row[m + j].y = fp_sub(fp_mul(lam, fp_sub(xm, x3)), ym);
         }
     }
+}
+// one (b, w) row of the vk_x table: d * 256^w * IC_var[b].  Rows w >= var_windows[b] are never read by the vk_x stage (a 128-bit signal
+// has 16 windows); the aggregate check multiplies IC_var[b] by full-width sums and reads all 32.
+ZKV_HD void setup_msm_row(const VkRaw& vk, VkTables& t, int b, int w) {
+    uint32_t ici = vk.var_ic[b];
+    if (raw_g1_is_inf(vk.ic[ici])) {             // s * infinity = infinity: leave the row zero and never read it
+        if (w == 0) t.var_windows[b] = 0;
+        return;
+    }
+    setup_window_row(fp_from_raw(vk.ic[ici][0]), fp_from_raw(vk.ic[ici][1]), w, t.msm[b][w]);
 }
 // One instance of a RISC Zero verifier set: what `initialize` derives from (control_root, bn254_control_id)
 // (risc0/verifier.rs:58-76) -- the selector (verifier.rs:128-144: tagged SHA-256 over control root, byte-reversed control

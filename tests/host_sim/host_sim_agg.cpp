@@ -2,6 +2,8 @@
 // the GLV scalar multiplication, the lanes' shares of E and the three-point normalisation.  TEST ONLY.
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
+#include "../../stylus_zkvm_verifiers_amd/csrc/zkv_host_vk.h"
 #include "../../stylus_zkvm_verifiers_amd/csrc/zkv_agg.h"
 using namespace zkv;
 
@@ -56,4 +58,32 @@ extern "C" uint32_t hsa_norm3(const uint8_t* pts192, const uint8_t* z96, uint8_t
     const Fp* f[6] = {&o.axs, &o.ays, &o.lxs, &o.lys, &o.cxs, &o.cys};
     for (int k = 0; k < 6; k++) fp_to_be(out192 + 32 * k, *f[k]);
     return flags;
+}
+
+// r = r1 + r2 lambda mod r as a canonical big-endian integer
+extern "C" void hsa_coeff_fr(uint64_t r1, uint64_t r2, uint8_t* out32) {
+    uint32_t l[8];
+    fr_to_raw(l, agg_coeff_fr(r1, r2));
+    for (int k = 0; k < 8; k++) { uint32_t v = l[7 - k]; out32[4 * k] = v >> 24; out32[4 * k + 1] = v >> 16; out32[4 * k + 2] = v >> 8; out32[4 * k + 3] = v; }
+}
+// the lanes' shares of U = R base + T_0 IC_a + T_1 IC_b summed, on the RISC Zero key (vm 0: control root / id given) or the SP1 key (vm 1)
+extern "C" int hsa_u(int vm, const uint8_t* cr, const uint8_t* cid, uint32_t sub, const uint8_t* R32, const uint8_t* T64, uint8_t* out64) {
+    static VkTables* vt = (VkTables*)malloc(sizeof(VkTables));
+    static AggTables* at = (AggTables*)malloc(sizeof(AggTables));
+    static int built = -1;
+    if (built != vm) {
+        VkRaw raw;
+        if (vm == 0) { uint8_t lo[16], hi[16]; host::split_digest(cr, lo, hi); host::fill_vk_risc0(raw, lo, hi, cid); }
+        else host::fill_vk_sp1(raw);
+        memset(vt, 0, sizeof *vt); memset(at, 0, sizeof *at);
+        setup_base(raw, *vt);
+        for (uint32_t b = 0; b < raw.n_var; b++) for (int w = 0; w < MSM_MAX_WINDOWS; w++) setup_msm_row(raw, *vt, (int)b, w);
+        for (int w = 0; w < MSM_MAX_WINDOWS; w++) setup_agg_base_row(*vt, *at, w);
+        built = vm;
+    }
+    uint32_t R[8], T[2][8];
+    be_to_limbs(R, R32); be_to_limbs(T[0], T64); be_to_limbs(T[1], T64 + 32);
+    G1J acc = g1j_infinity();
+    for (uint32_t lane = 0; lane < sub; lane++) acc = g1j_add(acc, agg_u_share(*vt, *at, lane, sub, R, T));
+    return affine_out(acc, out64);
 }

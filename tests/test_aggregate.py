@@ -105,6 +105,37 @@ def test_three_point_normalisation(hsa):
             else: assert (xs, ys) == (p[0] * pow(p[1], -1, m.P) % m.P, pow(p[1], -1, m.P))
 
 
+def test_coefficient_as_field_element(hsa):
+    rng = random.Random(0xF7)
+    for r1, r2 in [(0, 0), (1, 0), (0, 1), ((1 << 64) - 1, (1 << 64) - 1)] + [(rng.randrange(1 << 64), rng.randrange(1 << 64)) for _ in range(20)]:
+        o = C.create_string_buffer(32)
+        hsa.hsa_coeff_fr(C.c_uint64(r1), C.c_uint64(r2), o)
+        assert int.from_bytes(o.raw, 'big') == (r1 + r2 * LAMBDA) % m.R
+
+
+def test_window_shares_sum_to_the_weighted_vk_x(hsa, real_proofs):
+    """U = R base + T_0 IC_a + T_1 IC_b from the keys' window tables (all 32 windows of each per-proof signal, although a RISC Zero
+    signal itself has 16), for 16, 32 and 64 lanes per sub-batch; R = 1 and T = the signals gives compute_vk_x itself."""
+    rng = random.Random(0x77)
+    r = real_proofs['risc0']
+    cr, cid = bytes.fromhex(r['control_root']), bytes.fromhex(r['bn254_control_id'])
+    v = m.Risc0Verifier(); v.initialize(cr, cid)
+    fixed = v.signals(bytes(32))                       # control root halves, zero claim halves, control id
+    keys = [(0, m.RISC0_VK, fixed, (2, 3)), (1, m.SP1_VK, [0, 0], (0, 1))]
+    hsa.hsa_u.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p]
+    for vm, vk, sig0, var in keys:
+        base = m.compute_vk_x(vk, sig0)
+        ics = [vk['ic'][1 + var[0]], vk['ic'][1 + var[1]]]
+        cases = [(1, 5, 7), (0, 0, 0), (m.R - 1, m.R - 1, m.R - 1), (1 << 253, 255, 256)] + [tuple(rng.randrange(m.R) for _ in range(3)) for _ in range(3)]
+        for k, (R_, t0, t1) in enumerate(cases):
+            for sub in ((16, 32, 64) if k < 2 else (64,)):
+                o = C.create_string_buffer(64)
+                inf = hsa.hsa_u(vm, cr, cid, sub, m.be32(R_), m.be32(t0) + m.be32(t1), o)
+                want = m.g1_add(m.g1_add(m.g1_mul(base, R_), m.g1_mul(ics[0], t0)), m.g1_mul(ics[1], t1))
+                assert (inf == 1) == (want is None), (vm, k)
+                if want is not None: assert _pt(o.raw) == want, (vm, k, sub)
+
+
 # ---------------------------------------------------------------------------------------------------------------- GPU
 H = bytes.fromhex
 
