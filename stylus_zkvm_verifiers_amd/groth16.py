@@ -4,6 +4,7 @@ import numpy as np
 
 from . import _lib
 from .errors import VM_RISC0, VM_SP1
+from .risc0 import _aggregate_counters, _set_aggregate_check
 
 
 def vk_words(alpha1, beta2, gamma2, delta2, ic):
@@ -51,6 +52,13 @@ class Groth16Verifier:
         out = np.zeros(max(n, 1), dtype=np.uint8)
         _lib.check(self._L.zkv_groth16_verify_batch(self._h, n, pb, sb, out.ctypes.data), 'zkv_groth16_verify_batch')
         return out[:n].astype(bool)
+
+    def set_aggregate_check(self, enable=True, seed=None, sub_batch=64):
+        """Opt-in: share the pairing check among sub-batches of a large chunk (include/zkv.h); the answers stay the deterministic ones."""
+        _set_aggregate_check(self._L, self._h, enable, seed, sub_batch)
+
+    def aggregate_counters(self):
+        return _aggregate_counters(self._L, self._h)
 
     def vk_x_batch(self, signals):
         """Groth16Verifier::compute_vk_x (common/groth16.rs:51-58): signals = list of n_ic - 1 32-byte big-endian values per proof

@@ -255,3 +255,81 @@ def test_aggregate_check_sp1_and_mixed(real_proofs, monkeypatch):
     hst, _ = v.verify_batch([x.tobytes() for x in vk], [x.tobytes() for x in pv], [x.tobytes() for x in proofs])
     assert (np.asarray(hst) == out[0]).all()
     v.close()
+
+
+@pytest.mark.gpu
+def test_aggregate_check_on_generic_keys_and_a_verifier_set(real_proofs, monkeypatch):
+    """Trapdoor keys with 1, 2, 3 and 6 IC points (0, 1, 2 per-proof signals: vk_x from summed scalars; 5: per-proof r vk_x), both VM
+    conventions, every fifth proof with a wrong signal; and a RISC Zero verifier set (a vk_x constant per instance: per-proof form),
+    the real instance among others: answers with the aggregate check on == off."""
+    import numpy as np
+    import stylus_zkvm_verifiers_amd as zkv
+    from stylus_zkvm_verifiers_amd import synth
+    monkeypatch.setenv('ZKV_AGG_MIN', '64')
+    rng = random.Random(0xA6A6)
+    for n_ic, vm in ((1, 'sp1'), (2, 'risc0'), (3, 'sp1'), (6, 'risc0')):
+        vk, td = m.trapdoor_vk(rng, n_ic)
+        proofs, sigs, exp = [], [], []
+        for i in range(96):
+            sig = [rng.randrange(m.R) for _ in range(n_ic - 1)]
+            prf = m.trapdoor_prove(rng, td, sig, vm)
+            bad = n_ic > 1 and i % 5 == 4
+            if bad: sig[i % (n_ic - 1)] ^= 2
+            if n_ic == 1 and i % 7 == 3:                                 # no signals to damage: damage C instead (another curve point)
+                prf = (prf[0], prf[1], m.g1_mul(prf[2], 3)); bad = True
+            proofs.append(m.proof_to_words(*prf)); sigs.append([m.be32(s) for s in sig]); exp.append(not bad)
+        v = zkv.Groth16Verifier(m.vk_to_words(vk), n_ic, zkv.errors.VM_RISC0 if vm == 'risc0' else zkv.errors.VM_SP1)
+        plain = list(v.verify_batch(proofs, sigs))
+        assert plain == exp, n_ic
+        v.set_aggregate_check(True, seed=b'\x55' * 32, sub_batch=32)
+        assert list(v.verify_batch(proofs, sigs)) == exp, n_ic
+        checked, failed = v.aggregate_counters()
+        assert checked == 3 and 0 < failed <= 3
+        v.close()
+    r = real_proofs['risc0']
+    roots = [H(r['control_root'])] + [rng.randbytes(32) for _ in range(2)]
+    ids = [H(r['bn254_control_id'])] + [rng.randrange(m.R).to_bytes(32, 'big') for _ in range(2)]
+    vs = zkv.RiscZeroVerifierSet(roots, ids)
+    n = 700
+    seals, mut, mclass, flip = synth.make_batch('risc0', H(r['seal']), n, 0x5A4B56A7, pool=4, mutate_every=9)
+    iid = np.tile(np.frombuffer(H(r['image_id']), dtype=np.uint8), (n, 1))
+    jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (n, 1)); jds[flip, 0] ^= 1
+    inst = np.array([0 if i % 4 else 1 + (i // 4) % 2 for i in range(n)], dtype=np.uint32)
+    for i in range(0, n, 8):                                             # another instance's own selector spliced in: reaches the pairing and fails
+        seals[i, :4] = np.frombuffer(vs.get_selector(int(inst[i])), dtype=np.uint8)
+    args = (inst, [x.tobytes() for x in seals], [x.tobytes() for x in iid], [x.tobytes() for x in jds])
+    st0, rv0 = vs.verify_batch(*args)
+    vs.set_aggregate_check(True, seed=b'\x66' * 32)
+    st1, rv1 = vs.verify_batch(*args)
+    assert (np.asarray(st0) == np.asarray(st1)).all() and (np.asarray(rv0) == np.asarray(rv1)).all()
+    assert {0, 1, 5} <= set(int(x) for x in st1)
+    assert vs.aggregate_counters()[0] == (n + 63) // 64
+    vs.close()
+
+
+@pytest.mark.gpu
+def test_aggregate_check_behind_the_mixed_entry_point(real_proofs, monkeypatch):
+    import numpy as np
+    import stylus_zkvm_verifiers_amd as zkv
+    from stylus_zkvm_verifiers_amd import synth
+    monkeypatch.setenv('ZKV_AGG_MIN', '64')
+    r, s = real_proofs['risc0'], real_proofs['sp1']
+    n = 900
+    s0, mut0, _, f0 = synth.make_batch('risc0', H(r['seal']), n, 0x5A4B56A8, pool=4, mutate_every=11)
+    s1, mut1, _, f1 = synth.make_batch('sp1', H(s['proof']), n, 0x5A4B56A9, pool=4, mutate_every=13)
+    vm, seals, ia, ib, want = [], [], [], [], []
+    for i in range(n):
+        for tag, ss, mm, ff in ((0, s0, mut0, f0), (1, s1, mut1, f1)):
+            vm.append(tag); seals.append(ss[i].tobytes()); want.append(not mm[i])
+            if tag == 0:
+                jd = bytearray(H(r['journal_digest'])); jd[0] ^= int(ff[i]); ia.append(H(r['image_id'])); ib.append(bytes(jd))
+            else:
+                pv = bytearray(H(s['public_values'])); pv[-1] ^= int(ff[i]); ia.append(H(s['vkey'])); ib.append(bytes(pv))
+    v = zkv.MixedVerifier(H(r['control_root']), H(r['bn254_control_id']))
+    st0, rv0 = v.verify_batch(vm, seals, ia, ib)
+    v.set_aggregate_check(True, seed=b'\x77' * 32, sub_batch=16)
+    st1, rv1 = v.verify_batch(vm, seals, ia, ib)
+    assert (st0 == st1).all() and (rv0 == rv1).all() and [x == 0 for x in st1] == want
+    checked, failed = v.aggregate_counters()
+    assert checked == 2 * ((n + 15) // 16) and failed > 0
+    v.close()
