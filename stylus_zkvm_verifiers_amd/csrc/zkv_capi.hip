@@ -70,7 +70,7 @@ struct zkv_ctx {
     // Aggregate check (zkv_agg.h, zkv_ctx_set_aggregate_check): key tables, per-proof rows, the pseudo-proofs' workspace (one per
     // sub-batch), their statuses and the counters {sub-batches checked, sub-batches failed}
     bool agg_on = false, agg_key_ok = false;
-    uint32_t agg_sub = 64;                                     // proofs per sub-batch: 16, 32 or 64
+    uint32_t agg_sub = 32;                                     // proofs per sub-batch: 16, 32 or 64
     AggTables* d_agg_tab = nullptr;
     uint32_t* d_agg = nullptr;
     Workspace ws2 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
@@ -371,11 +371,14 @@ static int mark_done(zkv_ctx* c, hipStream_t s) {
     return ZKV_OK;
 }
 
-// Chunks of at least this many proofs take the aggregate check when it is switched on (below, the per-sub-batch pseudo-proofs are too few
-// to hide their latency: the ordinary kernels are as fast).  ZKV_AGG_MIN overrides.
+// Chunks of at least this many proofs take the aggregate check when it is switched on.  Measured (SP1, tools/bench_aggregate.py,
+// profiles/round3_t_aggregate_sizes.txt), aggregate / ordinary, all proofs valid: 2^14 7.4 / 8.2 ms, 2^15 8.0 / 8.4, 2^16 10.7 / 13.4,
+// 2^17 16.6 / 24.6, 2^18 29.6 / 47.3, 2^20 104 / 183; one proof in 64 rejected (a fifth of those at the pairing): 2^16 19.1 / 13.4,
+// 2^17 25.3 / 24.6, 2^18 40.0 / 47.4, 2^20 121 / 182 -- the pseudo-proofs and the second pass over failed sub-batches each cost a
+// kernel latency, which small chunks cannot hide.  ZKV_AGG_MIN overrides.
 static size_t agg_min() {
     const char* e = getenv("ZKV_AGG_MIN");
-    size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)16384;
+    size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)131072;
     return v < 64 ? 64 : v;
 }
 // Miller loop / final exponentiation of n proofs in workspace ws with the kernel family the chunk size selects (as enqueue_chunk does)
@@ -1689,7 +1692,7 @@ ZKV_EXPORT int zkv_ctx_set_aggregate_check(zkv_ctx* c, int enable, const uint8_t
     if (c->vm != ZKV_VM_RISC0 && c->vm != ZKV_VM_RISC0_SET && c->vm != ZKV_VM_SP1 && c->vm != ZKV_VM_GROTH16) return enable ? ZKV_ERR_INVALID_ARG : ZKV_OK;
     std::lock_guard<std::mutex> lk(c->mu);
     c->agg_on = enable != 0;
-    if (enable) c->agg_sub = enable == 1 ? 64u : (uint32_t)enable;
+    if (enable) c->agg_sub = enable == 1 ? 32u : (uint32_t)enable;
     if (enable) for (int i = 0; i < 8; i++) c->agg_seed.w[i] = be32_of(seed + 4 * i);
     return ZKV_OK;
 }

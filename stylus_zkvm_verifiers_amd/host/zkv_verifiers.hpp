@@ -58,6 +58,10 @@ public:
     }
     RiscZeroVerifier(RiscZeroVerifier&& o) noexcept : ctx_(o.ctx_) { o.ctx_ = nullptr; }
     size_t shard_count() const { return zkv_ctx_shard_count(ctx_); }
+    // Opt-in aggregate check of large batches (include/zkv.h: zkv_ctx_set_aggregate_check): sub_batch 0 = off, 16 / 32 / 64 proofs per shared
+    // pairing check; seed32 = nullptr draws the secret from the operating system.  Statuses stay the deterministic ones.
+    void set_aggregate_check(int sub_batch, const uint8_t* seed32 = nullptr) { check(zkv_ctx_set_aggregate_check(ctx_, sub_batch, seed32), "zkv_ctx_set_aggregate_check"); }
+    std::pair<uint64_t, uint64_t> aggregate_counters() const { uint64_t o[2]; check(zkv_ctx_aggregate_counters(ctx_, o), "zkv_ctx_aggregate_counters"); return {o[0], o[1]}; }
     ~RiscZeroVerifier() { zkv_ctx_destroy(ctx_); }
     RiscZeroVerifier(const RiscZeroVerifier&) = delete;
     RiscZeroVerifier& operator=(const RiscZeroVerifier&) = delete;
@@ -120,6 +124,10 @@ public:
     }
     Sp1Verifier(Sp1Verifier&& o) noexcept : ctx_(o.ctx_) { o.ctx_ = nullptr; }
     size_t shard_count() const { return zkv_ctx_shard_count(ctx_); }
+    // Opt-in aggregate check of large batches (include/zkv.h: zkv_ctx_set_aggregate_check): sub_batch 0 = off, 16 / 32 / 64 proofs per shared
+    // pairing check; seed32 = nullptr draws the secret from the operating system.  Statuses stay the deterministic ones.
+    void set_aggregate_check(int sub_batch, const uint8_t* seed32 = nullptr) { check(zkv_ctx_set_aggregate_check(ctx_, sub_batch, seed32), "zkv_ctx_set_aggregate_check"); }
+    std::pair<uint64_t, uint64_t> aggregate_counters() const { uint64_t o[2]; check(zkv_ctx_aggregate_counters(ctx_, o), "zkv_ctx_aggregate_counters"); return {o[0], o[1]}; }
     ~Sp1Verifier() { zkv_ctx_destroy(ctx_); }
     Sp1Verifier(const Sp1Verifier&) = delete;
     Sp1Verifier& operator=(const Sp1Verifier&) = delete;

@@ -32,7 +32,7 @@ def _same_len(n, **lists):
             raise ValueError('%s has %d entries for a batch of %d proofs' % (name, len(v), n))
 
 
-def _set_aggregate_check(L, h, enable, seed, sub_batch=64):
+def _set_aggregate_check(L, h, enable, seed, sub_batch=32):
     """zkv_ctx_set_aggregate_check: seed = None draws the secret from the operating system; 32 bytes make a run reproducible."""
     if seed is not None and len(seed) != 32: raise ValueError('seed must be 32 bytes')
     _lib.check(L.zkv_ctx_set_aggregate_check(h, int(sub_batch) if enable else 0, bytes(seed) if seed is not None else None), 'zkv_ctx_set_aggregate_check')
@@ -149,8 +149,8 @@ class RiscZeroVerifier:
         """Device set-up and per-chunk buffers for batches of up to n proofs, ahead of the first batch (optional)."""
         _lib.check(self._L.zkv_ctx_reserve(self._h, n), 'zkv_ctx_reserve')
 
-    def set_aggregate_check(self, enable=True, seed=None, sub_batch=64):
-        """Opt-in: share the pairing check among sub-batches of 64 (or 32, 16) proofs of a large chunk (include/zkv.h, csrc/zkv_agg.h);
+    def set_aggregate_check(self, enable=True, seed=None, sub_batch=32):
+        """Opt-in: share the pairing check among sub-batches of 32 (or 16, 64) proofs of a large chunk (include/zkv.h, csrc/zkv_agg.h);
         statuses stay the deterministic ones (a failed sub-batch is verified again proof by proof)."""
         _set_aggregate_check(self._L, self._h, enable, seed, sub_batch)
 
@@ -218,8 +218,8 @@ class RiscZeroVerifierSet:
         _lib.check(self._L.zkv_risc0_set_vk_x_batch(self._h, n, idx.ctypes.data, blob, out.ctypes.data), 'zkv_risc0_set_vk_x_batch')
         return [out[64 * i:64 * i + 64].tobytes() for i in range(n)]
 
-    def set_aggregate_check(self, enable=True, seed=None, sub_batch=64):
-        """Opt-in: share the pairing check among sub-batches of 64 (or 32, 16) proofs of a large chunk (include/zkv.h, csrc/zkv_agg.h);
+    def set_aggregate_check(self, enable=True, seed=None, sub_batch=32):
+        """Opt-in: share the pairing check among sub-batches of 32 (or 16, 64) proofs of a large chunk (include/zkv.h, csrc/zkv_agg.h);
         statuses stay the deterministic ones (a failed sub-batch is verified again proof by proof)."""
         _set_aggregate_check(self._L, self._h, enable, seed, sub_batch)
 

@@ -74,8 +74,8 @@ class Sp1Verifier:
         """Device set-up and per-chunk buffers for batches of up to n proofs, ahead of the first batch (optional)."""
         _lib.check(self._L.zkv_ctx_reserve(self._h, n), 'zkv_ctx_reserve')
 
-    def set_aggregate_check(self, enable=True, seed=None, sub_batch=64):
-        """Opt-in: share the pairing check among sub-batches of 64 (or 32, 16) proofs of a large chunk (include/zkv.h, csrc/zkv_agg.h);
+    def set_aggregate_check(self, enable=True, seed=None, sub_batch=32):
+        """Opt-in: share the pairing check among sub-batches of 32 (or 16, 64) proofs of a large chunk (include/zkv.h, csrc/zkv_agg.h);
         statuses stay the deterministic ones (a failed sub-batch is verified again proof by proof)."""
         _set_aggregate_check(self._L, self._h, enable, seed, sub_batch)
 

@@ -207,7 +207,7 @@ def test_aggregate_check_all_valid_and_only_early_rejects(real_proofs, monkeypat
     monkeypatch.setenv('ZKV_AGG_MIN', '64')
     r = real_proofs['risc0']
     v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
-    v.set_aggregate_check(True, seed=b'\x07' * 32)
+    v.set_aggregate_check(True, seed=b'\x07' * 32, sub_batch=64)
     n = 2048
     seals, ids, jds, mut, _ = _risc0_inputs(real_proofs, n, 0x5A4B56A2, 0)
     st = _run_risc0_dev(v, seals, ids, jds)
@@ -243,7 +243,7 @@ def test_aggregate_check_sp1_and_mixed(real_proofs, monkeypatch):
     out = []
     v = zkv.Sp1Verifier()
     for on in (False, True):
-        if on: v.set_aggregate_check(True, seed=b'\x31' * 32)
+        if on: v.set_aggregate_check(True, seed=b'\x31' * 32, sub_batch=64)
         d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
         v.verify_batch_dev(n, d_vk.data_ptr(), d_pv.data_ptr(), 96, d_p.data_ptr(), d_st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
@@ -299,7 +299,7 @@ def test_aggregate_check_on_generic_keys_and_a_verifier_set(real_proofs, monkeyp
         seals[i, :4] = np.frombuffer(vs.get_selector(int(inst[i])), dtype=np.uint8)
     args = (inst, [x.tobytes() for x in seals], [x.tobytes() for x in iid], [x.tobytes() for x in jds])
     st0, rv0 = vs.verify_batch(*args)
-    vs.set_aggregate_check(True, seed=b'\x66' * 32)
+    vs.set_aggregate_check(True, seed=b'\x66' * 32, sub_batch=64)
     st1, rv1 = vs.verify_batch(*args)
     assert (np.asarray(st0) == np.asarray(st1)).all() and (np.asarray(rv0) == np.asarray(rv1)).all()
     assert {0, 1, 5} <= set(int(x) for x in st1)
@@ -332,4 +332,29 @@ def test_aggregate_check_behind_the_mixed_entry_point(real_proofs, monkeypatch):
     assert (st0 == st1).all() and (rv0 == rv1).all() and [x == 0 for x in st1] == want
     checked, failed = v.aggregate_counters()
     assert checked == 2 * ((n + 15) // 16) and failed > 0
+    v.close()
+
+
+@pytest.mark.gpu
+def test_aggregate_check_on_a_sharded_verifier(real_proofs, monkeypatch):
+    """Three SP1 verifiers on one GPU behind one sharded context: the switch reaches every shard (each with its own derived secret), and a
+    batch split over them gives the deterministic statuses."""
+    import numpy as np
+    import stylus_zkvm_verifiers_amd as zkv
+    from stylus_zkvm_verifiers_amd import sharded, synth
+    monkeypatch.setenv('ZKV_AGG_MIN', '64')
+    monkeypatch.setenv('ZKV_SHARD_MIN', '64')
+    s = real_proofs['sp1']
+    n = 3000
+    proofs, mut, _, flip = synth.make_batch('sp1', H(s['proof']), n, 0x5A4B56AA, pool=4, mutate_every=17)
+    vk = [H(s['vkey'])] * n
+    pv = np.tile(np.frombuffer(H(s['public_values']), dtype=np.uint8), (n, 1)); pv[flip, -1] ^= 1
+    v = sharded.shard([zkv.Sp1Verifier() for _ in range(3)])
+    args = (vk, [x.tobytes() for x in pv], [x.tobytes() for x in proofs])
+    st0, _ = v.verify_batch(*args)
+    v.set_aggregate_check(True, seed=b'\x42' * 32, sub_batch=16)
+    st1, _ = v.verify_batch(*args)
+    assert (np.asarray(st0) == np.asarray(st1)).all() and ((np.asarray(st1) == 0) == ~mut).all()
+    checked, failed = v.aggregate_counters()
+    assert checked == sum((k + 15) // 16 for k in (1000, 1000, 1000)) and failed > 0
     v.close()
