@@ -355,6 +355,73 @@ ZKV_HD bool miller_loop_p(const VkTables* vkp, uint32_t flags, SoaRef norm, SoaR
     Fp2 qx, qy; qx.h = bsrc.fp(0); qy.h = bsrc.fp(16);
     return miller_point_closes(tm, qx, qy);
 }
+// Writable rows addressed like SoaRef (wave-uniform base and stride, one 32-bit byte offset per lane); usable wherever an MRef is:
+// Fp2 value k of this lane at words 16 k .. 16 k + 7 (the lane offset already selects the lane's component).
+struct SoaRW {
+    uint32_t* p; size_t stride; uint32_t off;
+    ZKV_HD uint32_t ld(int k) const { return *(const uint32_t*)((const char*)(p + (size_t)k * stride) + off); }
+    ZKV_HD void st(int k, uint32_t v) const { *(uint32_t*)((char*)(p + (size_t)k * stride) + off) = v; }
+    ZKV_HD int fw() const { return 16; }
+};
+// The Miller loop of the aggregate check (zkv_agg.h) for TWO proofs of one lane pair that share the accumulator: f <- f^2 once per
+// doubling step, then each proof's line -- only the variable pairs (r A'_p, B_p); the fixed pairs are taken once per sub-batch.  The
+// running points live in HBM rows (tq; proof 1's rows `step` bytes after proof 0's, as in norm and bsrc) and pass through registers
+// only while their line is formed: LDS holds nothing but f, which keeps two wavefronts per SIMD.  mask bit p: proof p takes part
+// (alive, B finite); abmask bit p: its pair contributes (A finite as well).  Returns bit p set when proof p's B passed the
+// subgroup test the loop doubles as (miller_loop_p); a proof outside the mask reports set.
+template <class RF>
+ZKV_HD uint32_t miller_loop_p2(uint32_t mask, uint32_t abmask, SoaRef norm, SoaRef bsrc, SoaRW tq, uint32_t step, RF fm) {
+    const uint8_t KIND[ZKV_MILLER_STEPS] = ZKV_MILLER_STEP_KIND;
+    f12m_set_one(fm);
+#pragma unroll 1
+    for (uint32_t p = 0; p < 2; p++) {
+        if (!((mask >> p) & 1u)) continue;
+        SoaRef b = bsrc; b.off += p * step;
+        SoaRW t = tq; t.off += p * step;
+        Fp2 bx, by; bx.h = b.fp(0); by.h = b.fp(16);
+        m_st_f2(t, 0, bx); m_st_f2(t, 1, by); m_st_f2(t, 2, f2_one());
+    }
+#pragma unroll 1
+    for (int li = 0; li < ZKV_MILLER_STEPS; li++) {
+        const int kind = KIND[li];
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(norm.off), "+v"(bsrc.off), "+v"(tq.off));          // see miller_loop_p
+#endif
+        if (kind == 0 && li != 0) f12m_sqr_body(fm);
+#pragma unroll 1
+        for (uint32_t p = 0; p < 2; p++) {
+            if (!((mask >> p) & 1u)) continue;
+            SoaRef n = norm; n.off += p * step;
+            SoaRef b = bsrc; b.off += p * step;
+            SoaRW t = tq; t.off += p * step;
+            Fp2 l0, l1, l3;
+            G2H T; T.x = m_ld_f2(t, 0); T.y = m_ld_f2(t, 1); T.z = m_ld_f2(t, 2);
+            if (kind == 0) line_dbl(T, l0, l1, l3);
+            else {
+                Fp2 qx, qy; qx.h = b.fp(0); qy.h = b.fp(16);
+                if (kind == 2) qy = f2_neg(qy);
+                else if (kind == 3) { Fp2 x, y; g2_frob_affine(x, y, qx, qy); qx = x; qy = y; }
+                else if (kind == 4) { Fp2 x, y; g2_frob2_affine(x, y, qx, qy); qx = x; qy = f2_neg(y); }
+                line_add(T, qx, qy, l0, l1, l3);
+            }
+            m_st_f2(t, 0, T.x); m_st_f2(t, 1, T.y); m_st_f2(t, 2, T.z);
+            if ((abmask >> p) & 1u) {
+                const Fp2 c3 = f2_mul_fp(l1, n.fp(0)), c4 = f2_mul_fp(l3, n.fp(8));
+                f12m_mul_by_034_body(fm, l0, c3, c4);
+            }
+        }
+    }
+    uint32_t fine = 3u;
+#pragma unroll 1
+    for (uint32_t p = 0; p < 2; p++) {
+        if (!((mask >> p) & 1u)) continue;
+        SoaRef b = bsrc; b.off += p * step;
+        SoaRW t = tq; t.off += p * step;
+        Fp2 qx, qy; qx.h = b.fp(0); qy.h = b.fp(16);
+        if (!miller_point_closes(t, qx, qy)) fine &= ~(1u << p);
+    }
+    return fine;
+}
 #endif  // ZKV_PAIRED
 
 // ---------------------------------------------------------------- stage FINALEXP

@@ -136,6 +136,44 @@ def test_window_shares_sum_to_the_weighted_vk_x(hsa, real_proofs):
                 if want is not None: assert _pt(o.raw) == want, (vm, k, sub)
 
 
+def test_two_proofs_sharing_the_miller_accumulator(real_proofs, verify_corpus):
+    """miller_loop_p2 (two proofs of a lane pair, one accumulator, running points in memory rows) == the product of the two proofs' own
+    Miller values, for both / one proof taking part, with A at infinity, and a B outside the subgroup reported in its bit."""
+    csrc = os.path.join(HERE, '..', 'stylus_zkvm_verifiers_amd', 'csrc')
+    def build(name, extra):
+        src = os.path.join(HERE, 'host_sim', name + '.cpp'); lib = os.path.join(HERE, 'host_sim', 'lib' + name + '.so')
+        deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith('.h')]
+        if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(d) for d in deps):
+            subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-Wno-unknown-pragmas'] + extra + ['-o', lib, src])
+        return C.CDLL(lib)
+    hs, hp = build('host_sim', []), build('host_sim_paired', ['-pthread'])
+    hs.hs_prepare.restype = C.c_void_p
+    hp.hs2_miller2.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    r0 = real_proofs['risc0']
+    cr, cid = H(r0['control_root']), H(r0['bn254_control_id'])
+    v = m.Risc0Verifier(); v.initialize(cr, cid)
+    rows = []
+    for c in verify_corpus['cases']:
+        if c['vm'] != 'risc0' or c['status'] not in (0, 1): continue
+        sig = v.signals(m.receipt_claim_ok_digest(H(c['image_id']), H(c['journal_digest'])))
+        fl = C.c_uint32(0); norm = (C.c_uint32 * 48)(); b = (C.c_uint32 * 32)()
+        t = hs.hs_prepare(0, cr, cid, H(c['seal'])[4:], m.be32(sig[2]), m.be32(sig[3]), C.byref(fl), norm, b)
+        if t and not (fl.value & (2 | 4)): rows.append((c['name'], t, list(norm), list(b)))
+        if len(rows) >= 4: break
+    assert len(rows) >= 3
+    t = rows[0][1]
+    def run(i, k, mask, abmask):
+        norm96 = (C.c_uint32 * 96)(*(rows[i][2] + rows[k][2]))
+        b96 = (C.c_uint32 * 96)(*(rows[i][3] + [0] * 16 + rows[k][3] + [0] * 16))
+        fine = C.c_uint32(0)
+        return hp.hs2_miller2(t, mask, abmask, norm96, b96, C.byref(fine)), fine.value
+    assert run(0, 1, 3, 3) == (1, 3)
+    assert run(1, 2, 3, 3) == (1, 3)
+    assert run(0, 0, 3, 3) == (1, 3)                   # the same proof twice
+    assert run(0, 1, 1, 1) == (1, 3) and run(0, 1, 2, 2) == (1, 3)          # one proof of the pair only
+    assert run(0, 1, 3, 1) == (1, 3) and run(0, 1, 3, 0) == (1, 3)          # A at infinity: the point is stepped, no line products
+
+
 # ---------------------------------------------------------------------------------------------------------------- GPU
 H = bytes.fromhex
 
@@ -149,6 +187,14 @@ def _risc0_inputs(real_proofs, n, seed, mutate_every, classes=None):
     ids = np.tile(np.frombuffer(H(r['image_id']), dtype=np.uint8), (n, 1))
     jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (n, 1)); jds[flip, 0] ^= 1
     return seals, ids, jds, mut, mclass
+
+
+def _sub_batches(n, sub, pairs=True):
+    """Sub-batches counted for a chunk of n proofs: contiguous runs of `sub` proofs, or -- with two proofs per Miller accumulator, the
+    default -- per 64-proof block 64 / sub groups of sub / 2 proofs of the lower half and their partners 32 further on."""
+    if not pairs: return (n + sub - 1) // sub
+    full, rem = divmod(n, 64)
+    return full * (64 // sub) + (min(rem, 32) + sub // 2 - 1) // (sub // 2)
 
 
 def _run_risc0_dev(v, seals, ids, jds):
@@ -178,14 +224,17 @@ def test_aggregate_check_gives_the_deterministic_statuses(real_proofs, monkeypat
     v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
     plain = _run_risc0_dev(v, seals, ids, jds)
     total = 0
-    for sub in (16, 32, 64):
-        v.set_aggregate_check(True, seed=bytes(range(32)), sub_batch=sub)
-        agg = _run_risc0_dev(v, seals, ids, jds)
-        checked, failed = v.aggregate_counters()
-        assert (agg == plain).all(), sub
-        assert ((agg == 0) == ~mut).all()
-        total += (n + sub - 1) // sub
-        assert checked == total and 0 < failed <= checked
+    for pairs in (True, False):
+        monkeypatch.setenv('ZKV_AGG_PAIRS', '1' if pairs else '0')
+        for sub in (16, 32, 64):
+            v.set_aggregate_check(True, seed=bytes(range(32)), sub_batch=sub)
+            agg = _run_risc0_dev(v, seals, ids, jds)
+            checked, failed = v.aggregate_counters()
+            assert (agg == plain).all(), (pairs, sub)
+            assert ((agg == 0) == ~mut).all()
+            total += _sub_batches(n, sub, pairs)
+            assert checked == total and 0 < failed <= checked
+    monkeypatch.delenv('ZKV_AGG_PAIRS')
     # a second run draws other coefficients (the per-chunk counter): same statuses
     assert (_run_risc0_dev(v, seals, ids, jds) == plain).all()
     k = 512
@@ -250,7 +299,7 @@ def test_aggregate_check_sp1_and_mixed(real_proofs, monkeypatch):
         out.append(d_st.cpu().numpy())
     assert (out[0] == out[1]).all() and ((out[1] == 0) == ~mut).all()
     checked, failed = v.aggregate_counters()
-    assert checked == (n + 63) // 64 and failed > 0
+    assert checked == _sub_batches(n, 64) and failed > 0
     # host-pointer entry point (ragged blobs, several segments)
     hst, _ = v.verify_batch([x.tobytes() for x in vk], [x.tobytes() for x in pv], [x.tobytes() for x in proofs])
     assert (np.asarray(hst) == out[0]).all()
@@ -284,7 +333,7 @@ def test_aggregate_check_on_generic_keys_and_a_verifier_set(real_proofs, monkeyp
         v.set_aggregate_check(True, seed=b'\x55' * 32, sub_batch=32)
         assert list(v.verify_batch(proofs, sigs)) == exp, n_ic
         checked, failed = v.aggregate_counters()
-        assert checked == 3 and 0 < failed <= 3
+        assert checked == _sub_batches(96, 32) and 0 < failed <= checked
         v.close()
     r = real_proofs['risc0']
     roots = [H(r['control_root'])] + [rng.randbytes(32) for _ in range(2)]
@@ -303,7 +352,7 @@ def test_aggregate_check_on_generic_keys_and_a_verifier_set(real_proofs, monkeyp
     st1, rv1 = vs.verify_batch(*args)
     assert (np.asarray(st0) == np.asarray(st1)).all() and (np.asarray(rv0) == np.asarray(rv1)).all()
     assert {0, 1, 5} <= set(int(x) for x in st1)
-    assert vs.aggregate_counters()[0] == (n + 63) // 64
+    assert vs.aggregate_counters()[0] == _sub_batches(n, 64)
     vs.close()
 
 
@@ -331,7 +380,7 @@ def test_aggregate_check_behind_the_mixed_entry_point(real_proofs, monkeypatch):
     st1, rv1 = v.verify_batch(vm, seals, ia, ib)
     assert (st0 == st1).all() and (rv0 == rv1).all() and [x == 0 for x in st1] == want
     checked, failed = v.aggregate_counters()
-    assert checked == 2 * ((n + 15) // 16) and failed > 0
+    assert checked == 2 * _sub_batches(n, 16) and failed > 0
     v.close()
 
 
@@ -356,5 +405,5 @@ def test_aggregate_check_on_a_sharded_verifier(real_proofs, monkeypatch):
     st1, _ = v.verify_batch(*args)
     assert (np.asarray(st0) == np.asarray(st1)).all() and ((np.asarray(st1) == 0) == ~mut).all()
     checked, failed = v.aggregate_counters()
-    assert checked == sum((k + 15) // 16 for k in (1000, 1000, 1000)) and failed > 0
+    assert checked == 3 * _sub_batches(1000, 16) and failed > 0
     v.close()
