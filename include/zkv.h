@@ -313,7 +313,7 @@ int zkv_ctx_set_lanes_per_proof(zkv_ctx* ctx, int lanes);
  * the operating system (getrandom) -- the setting for production; a caller-supplied seed makes runs reproducible (tests) and must
  * not be known to whoever supplies proofs.  Applies to RISC Zero, SP1 (Groth16), verifier-set, generic-key, mixed and sharded
  * contexts; ZKV_ERR_INVALID_ARG on a PLONK or precompile context.  Keys with alpha or beta at infinity fall back to the ordinary path.
- * Throughput: see DESIGN.md (2^20 SP1 proofs: 10.1 M proofs/s all valid, 8.7 M with one proof in 64 rejected, against 5.7 M; a proof
+ * Throughput: see DESIGN.md (2^20 SP1 proofs: 11.4 M proofs/s all valid, 9.6 M with one proof in 64 rejected, against 5.7 M; a proof
  * rejected at the pairing costs its sub-batch a second, ordinary pass, and small chunks gain nothing). */
 int zkv_ctx_set_aggregate_check(zkv_ctx* ctx, int enable, const uint8_t* seed32);
 /* out[0] = sub-batches checked in aggregate, out[1] = those that failed and were verified proof by proof, since device set-up.

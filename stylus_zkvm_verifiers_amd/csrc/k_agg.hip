@@ -114,24 +114,27 @@ __device__ __forceinline__ Fr agg_ld_fr(const uint32_t* agg, size_t cap, int wor
     for (int k = 0; k < 8; k++) r.v[k] = agg[(size_t)(word0 + k) * cap + i];
     return r;
 }
-// pairs != 0 (the Miller values come from k_agg_miller, one per pair of proofs (l, l + 32) of the block): a sub-batch is sub / 2 consecutive
-// lanes of the lower half of the wavefront and their partners in the upper half -- the butterfly's widest exchange is then with lane
-// l ^ 32 whatever `sub` is -- and the number of ML(alpha, beta) factors to balance is the number of PAIRS with a proof in the check.
-__global__ __launch_bounds__(ZKV_BLOCK) void k_agg_reduce(size_t n, uint32_t sub, uint32_t sums, uint32_t pairs, const VkTables* __restrict__ vk, Workspace ws,
+// g proofs share a Miller value (k_agg_miller: members l, l + L, l + 2L, ... of the block, L = 64 / g): a sub-batch is then sub / g
+// consecutive lanes of the lowest L and their partners -- the butterfly exchanges at distances 32 ... L and sub / (2 g) ... 1 -- and the
+// number of ML(alpha, beta) factors to balance is the number of GROUPS with a proof in the check.  g = 1: sub consecutive lanes.
+__global__ __launch_bounds__(ZKV_BLOCK) void k_agg_reduce(size_t n, uint32_t sub, uint32_t sums, uint32_t g, const VkTables* __restrict__ vk, Workspace ws,
                                                           const uint32_t* __restrict__ agg, const AggTables* __restrict__ tab, Workspace ws2,
                                                           uint8_t* __restrict__ status2) {
     const size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
-    const uint32_t half = sub >> 1, top = pairs ? 32u : half;    // the exchange distances are top, half / 2, ..., 1
-    const uint32_t lane = pairs ? (threadIdx.x & (half - 1u)) + (threadIdx.x >> 5) * half : threadIdx.x & (sub - 1u);
-    const size_t sb = pairs ? (size_t)blockIdx.x * (64u / sub) + (threadIdx.x & 31u) / half : i / sub;
+    const uint32_t L = 64u / g, w = sub / g;
+    const uint32_t dist = (63u & ~(L - 1u)) | (w - 1u);         // the exchange distances, one bit each: 32 ... L and w / 2 ... 1
+    const uint32_t lane = (threadIdx.x & (w - 1u)) + (threadIdx.x / L) * w;
+    const size_t sb = (size_t)blockIdx.x * (64u / sub) + (threadIdx.x & (L - 1u)) / w;
     bool in = false;
     if (i < n) in = (agg[(size_t)AGG_W_FLAGS * ws.cap + i] & FL_ALIVE) && !ws.g2bad[i];
     G1J U = g1j_infinity(), W = g1j_infinity();
     Fr Rm = fr_zero(), T0 = fr_zero(), T1 = fr_zero();         // sums of r, r s_0, r s_1 mod r (the scalar form of vk_x)
     uint32_t s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0}, cnt = in ? 1u : 0u;
-    if (pairs) {                                                // count a pair once: at its first proof, or at the second if the first is out
-        const bool mate = __shfl_xor((int)in, 32, 64) != 0;
-        if (threadIdx.x >= 32u && mate) cnt = 0;
+    {                                                           // count a group once: at its first member in the check
+        const unsigned long long inb = __ballot(in);
+        unsigned long long lower = 0;
+        for (uint32_t l = threadIdx.x & (L - 1u); l < threadIdx.x; l += L) lower |= 1ull << l;
+        if (inb & lower) cnt = 0;
     }
     if (in) {
         if (sums) { Rm = agg_ld_fr(agg, ws.cap, AGG_W_U, i); T0 = agg_ld_fr(agg, ws.cap, AGG_W_U + 8, i); T1 = agg_ld_fr(agg, ws.cap, AGG_W_U + 16, i); }
@@ -141,8 +144,8 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_agg_reduce(size_t n, uint32_t sub
         s2[0] = agg[(size_t)(AGG_W_R + 2) * ws.cap + i]; s2[1] = agg[(size_t)(AGG_W_R + 3) * ws.cap + i];
     }
 #pragma unroll 1
-    for (int d = (int)half; d >= 1; d >>= 1) {
-        const int m = d == (int)half ? (int)top : d;
+    for (int m = 32; m >= 1; m >>= 1) {
+        if (!(dist & (uint32_t)m)) continue;
         if (sums) { Rm = fr_add(Rm, fr_xor(Rm, m)); T0 = fr_add(T0, fr_xor(T0, m)); T1 = fr_add(T1, fr_xor(T1, m)); }
         else U = g1j_add(U, g1j_xor(U, m));
         W = g1j_add(W, g1j_xor(W, m));
@@ -159,11 +162,11 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_agg_reduce(size_t n, uint32_t sub
         fr_to_raw(R, Rm); fr_to_raw(T[0], T0); fr_to_raw(T[1], T1);
         U = agg_u_share(*vk, *tab, lane, sub, R, T);
 #pragma unroll 1
-        for (int d = (int)half; d >= 1; d >>= 1) U = g1j_add(U, g1j_xor(U, d == (int)half ? (int)top : d));
+        for (int m = 32; m >= 1; m >>= 1) if (dist & (uint32_t)m) U = g1j_add(U, g1j_xor(U, m));
     }
     G1J E = agg_e_share(*tab, lane, sub, ((uint64_t)s1[1] << 32) | s1[0], s1[2], ((uint64_t)s2[1] << 32) | s2[0], s2[2], cnt + 1u);
 #pragma unroll 1
-    for (int d = (int)half; d >= 1; d >>= 1) E = g1j_add(E, g1j_xor(E, d == (int)half ? (int)top : d));
+    for (int m = 32; m >= 1; m >>= 1) if (dist & (uint32_t)m) E = g1j_add(E, g1j_xor(E, m));
     if (lane != 0) return;                                      // (a sub-batch past the end of the chunk has cnt = 0)
     ws2.g2bad[sb] = 0;
     if (cnt == 0) { ws2.flags[sb] = 0; status2[sb] = ST_OK; return; }       // nothing left to check in this sub-batch
@@ -185,21 +188,21 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_agg_reduce(size_t n, uint32_t sub
 // where they were, a batch whose rejects sit at a fixed position of every 64 used half of the XCDs: 28.7 instead of 14 ms).
 // Proofs PREP rejected or whose B failed the subgroup test already have their final status.  counters: [0] sub-batches checked,
 // [1] sub-batches that failed, [2] length of the list (reset per chunk).
-__global__ __launch_bounds__(ZKV_BLOCK) void k_agg_mark(size_t n, uint32_t sub, uint32_t pairs, Workspace ws, const uint32_t* __restrict__ agg,
+__global__ __launch_bounds__(ZKV_BLOCK) void k_agg_mark(size_t n, uint32_t sub, uint32_t g, Workspace ws, const uint32_t* __restrict__ agg,
                                                         const uint8_t* __restrict__ status2, uint8_t* __restrict__ status, unsigned long long* __restrict__ counters,
                                                         uint32_t* __restrict__ idx) {
     const size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     bool again = false;
     if (i < n) {
-        const uint32_t half = sub >> 1;
-        const size_t sb = pairs ? (size_t)blockIdx.x * (64u / sub) + (threadIdx.x & 31u) / half : i / sub;      // as in k_agg_reduce
-        const bool first = pairs ? (threadIdx.x < 32u && (threadIdx.x & (half - 1u)) == 0) : (i & (sub - 1u)) == 0;
+        const uint32_t L = 64u / g, w = sub / g;
+        const size_t sb = (size_t)blockIdx.x * (64u / sub) + (threadIdx.x & (L - 1u)) / w;      // as in k_agg_reduce
+        const bool first = threadIdx.x < L && (threadIdx.x & (w - 1u)) == 0;
         const bool passed = status2[sb] == ST_OK;
         if (first) { atomicAdd(&counters[0], 1ull); if (!passed) atomicAdd(&counters[1], 1ull); }
         const uint32_t flags0 = agg[(size_t)AGG_W_FLAGS * ws.cap + i];
         const uint32_t bad = ws.g2bad[i];
         if (flags0 & FL_ALIVE) {
-            if (bad == 2u) again = true;                        // its partner's B failed the subgroup test: the pair had no Miller value
+            if (bad == 2u) again = true;                        // another B of its group failed the subgroup test: the group had no Miller value
             else if (!bad) { if (passed) status[i] = ST_OK; else again = true; }
         }
     }
@@ -234,17 +237,17 @@ void launch_agg_g1(size_t n, const VkTables* d_tab, const InstTab* inst_tab, con
     if (!n) return;
     hipLaunchKernelGGL(k_agg_g1, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, d_tab, inst_tab, ws, agg, seed, sums ? 1u : 0u);
 }
-void launch_agg_reduce(size_t n, uint32_t sub, bool sums, bool pairs, const VkTables* d_tab, const Workspace& ws, const uint32_t* agg, const AggTables* tab,
+void launch_agg_reduce(size_t n, uint32_t sub, bool sums, uint32_t g, const VkTables* d_tab, const Workspace& ws, const uint32_t* agg, const AggTables* tab,
                        const Workspace& ws2, uint8_t* status2, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_agg_reduce, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, sub, sums ? 1u : 0u, pairs ? 1u : 0u, d_tab, ws, agg,
+    hipLaunchKernelGGL(k_agg_reduce, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, sub, sums ? 1u : 0u, g, d_tab, ws, agg,
                        tab, ws2, status2);
 }
-void launch_agg_mark(size_t n, uint32_t sub, bool pairs, const Workspace& ws, const uint32_t* agg, const uint8_t* status2, uint8_t* status, unsigned long long* counters,
+void launch_agg_mark(size_t n, uint32_t sub, uint32_t g, const Workspace& ws, const uint32_t* agg, const uint8_t* status2, uint8_t* status, unsigned long long* counters,
                      uint32_t* idx, hipStream_t s) {
     if (!n) return;
     (void)hipMemsetAsync(counters + 2, 0, sizeof(unsigned long long), s);
-    hipLaunchKernelGGL(k_agg_mark, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, sub, pairs ? 1u : 0u, ws, agg, status2, status, counters, idx);
+    hipLaunchKernelGGL(k_agg_mark, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, sub, g, ws, agg, status2, status, counters, idx);
 }
 void launch_agg_gather(size_t n, const Workspace& ws, const uint32_t* agg, const unsigned long long* counters, const uint32_t* idx, const Workspace& ws3,
                        uint8_t* status3, hipStream_t s) {

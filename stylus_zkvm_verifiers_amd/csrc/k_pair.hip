@@ -168,32 +168,45 @@ void launch_pairing(size_t n, uint32_t k, const uint8_t* in, const Workspace& ws
     hipLaunchKernelGGL(k_pairing_finalexp, dim3(grid), dim3(ZKV_BLOCK), 0, s, n, ws, ok, result, k == 0 ? 1u : 0u);
 }
 
-// Aggregate check (zkv_agg.h), Miller loop: TWO PROOFS PER LANE PAIR with one accumulator (miller_loop_p2) -- the squaring of f, a third
-// of a step, is shared.  A wavefront covers a block of 64 proofs: pair q takes proofs 64 b + q and 64 b + 32 + q (consecutive pairs read
-// consecutive rows).  The running points go through the final exponentiation's scratch rows (ws.fe, unused at this stage).  The pair's
-// Miller value times ML(alpha, beta) goes to the F slot of its first proof.  If either B fails the subgroup test the pair has no value:
-// the offender is rejected (g2bad 1) and its partner marked for the ordinary kernels (g2bad 2).
+// Aggregate check (zkv_agg.h), Miller loop: G PROOFS PER LANE PAIR (2, 4 or 8) with one accumulator (miller_loop_pg) -- the squaring of f,
+// a third of a step, is shared.  A block of 64 proofs belongs to L = 64 / G pairs: pair q takes proofs 64 b + q + p L, p < G (consecutive
+// pairs read consecutive rows).  The running points go through the final exponentiation's scratch rows (ws.fe, unused at this stage).
+// The group's Miller value times ML(alpha, beta) goes to the F slot of its first proof.  If a B fails the subgroup test the group has no
+// value: the offender is rejected (g2bad 1) and the others marked for the ordinary kernels (g2bad 2).
+template <int G>
 __global__ __launch_bounds__(PAIR_BLOCK, 2) void k_agg_miller(size_t n, const VkTables* __restrict__ vk, Workspace ws, uint8_t* __restrict__ status) {
     __shared__ uint32_t lds[48 * PAIR_BLOCK];
+    constexpr uint32_t L = 64u / G;
     const size_t gp = ((size_t)blockIdx.x * PAIR_BLOCK + threadIdx.x) >> 1;
-    const size_t i0 = (gp >> 5) * 64 + (gp & 31u), i1 = i0 + 32;
+    const size_t i0 = (gp / L) * 64 + (gp % L);
     if (i0 >= n) return;
-    const uint32_t f0 = ws.flags[i0], f1 = i1 < n ? ws.flags[i1] : 0u;
-    const uint32_t alive = ((f0 & FL_ALIVE) ? 1u : 0u) | ((f1 & FL_ALIVE) ? 2u : 0u);
+    uint32_t alive = 0, mask = 0, abmask = 0;
+#pragma unroll
+    for (uint32_t p = 0; p < (uint32_t)G; p++) {
+        const size_t i = i0 + p * L;
+        const uint32_t f = i < n ? ws.flags[i] : 0u;
+        if (f & FL_ALIVE) {
+            alive |= 1u << p;
+            if (!(f & FL_B_INF)) { mask |= 1u << p; if (!(f & FL_A_INF)) abmask |= 1u << p; }
+        }
+    }
     if (!alive) return;
-    const uint32_t mask = alive & (((f0 & FL_B_INF) ? 0u : 1u) | ((f1 & FL_B_INF) ? 0u : 2u));
-    const uint32_t abmask = mask & (((f0 & FL_A_INF) ? 0u : 1u) | ((f1 & FL_A_INF) ? 0u : 2u));
     const uint32_t par = threadIdx.x & 1u;
     uint32_t* wl = lds + (threadIdx.x >> 6) * (48 * ZKV_BLOCK) + (threadIdx.x & 63u);
     LRef fm = l_ref(wl);
     SoaRef norm = {ws.norm, ws.cap, (uint32_t)i0 * 4u};
     SoaRef bsrc = {ws.prep + 32 * ws.cap, ws.cap, (uint32_t)(8 * par * ws.cap + i0) * 4u};
     SoaRW tq = {ws.fe, ws.cap, (uint32_t)(8 * par * ws.cap + i0) * 4u};
-    const uint32_t fine = miller_loop_p2(mask, abmask, norm, bsrc, tq, 32u * 4u, fm);
+    const uint32_t fine = miller_loop_pg<G>(mask, abmask, norm, bsrc, tq, L * 4u, fm);
     if ((fine & mask) != mask) {
         if (!par) {
-            if (alive & 1u) { const bool bad = (mask & 1u & ~fine) != 0; ws.g2bad[i0] = bad ? 1u : 2u; if (bad) status[i0] = ST_VERIFICATION_FAILED; }
-            if (alive & 2u) { const bool bad = (mask & 2u & ~fine) != 0; ws.g2bad[i1] = bad ? 1u : 2u; if (bad) status[i1] = ST_VERIFICATION_FAILED; }
+#pragma unroll 1
+            for (uint32_t p = 0; p < (uint32_t)G; p++) {
+                if (!((alive >> p) & 1u)) continue;
+                const bool bad = ((mask & ~fine) >> p) & 1u;
+                ws.g2bad[i0 + p * L] = bad ? 1u : 2u;
+                if (bad) status[i0 + p * L] = ST_VERIFICATION_FAILED;
+            }
         }
         return;
     }
@@ -201,16 +214,18 @@ __global__ __launch_bounds__(PAIR_BLOCK, 2) void k_agg_miller(size_t n, const Vk
     MRef out = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i0, (uint32_t)ws.cap, 16);
     f12m_mul_body(out, fm, ab, false);
 }
-void launch_agg_miller(size_t n, const VkTables* d_tab, const Workspace& ws, uint8_t* status, hipStream_t s) {
+void launch_agg_miller(size_t n, uint32_t g, const VkTables* d_tab, const Workspace& ws, uint8_t* status, hipStream_t s) {
     if (!n) return;
-    const size_t pairs = ((n + 63) / 64) * 32;
-    hipLaunchKernelGGL(k_agg_miller, dim3((unsigned)((2 * pairs + PAIR_BLOCK - 1) / PAIR_BLOCK)), dim3(PAIR_BLOCK), 0, s, n, d_tab, ws, status);
+    const size_t pairs = ((n + 63) / 64) * (64 / g);
+    const dim3 grid((unsigned)((2 * pairs + PAIR_BLOCK - 1) / PAIR_BLOCK)), block(PAIR_BLOCK);
+    if (g == 8) hipLaunchKernelGGL(k_agg_miller<8>, grid, block, 0, s, n, d_tab, ws, status);
+    else if (g == 4) hipLaunchKernelGGL(k_agg_miller<4>, grid, block, 0, s, n, d_tab, ws, status);
+    else hipLaunchKernelGGL(k_agg_miller<2>, grid, block, 0, s, n, d_tab, ws, status);
 }
 // Aggregate check: the product of the Miller values of a sub-batch, multiplied into the pseudo-proof's slot between its Miller loop and
-// its final exponentiation.  One sub-batch per lane pair, the running product in LDS.  pairs = 0: one value per proof, sub-batch sb =
-// proofs [sb sub, sb sub + sub).  pairs = 1 (k_agg_miller): one value per pair of proofs (i, i + 32) of a 64-proof block, kept at i; sub-batch
-// sb covers sub / 2 consecutive pairs of its block.
-__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_agg_fprod(size_t n, size_t n2, uint32_t sub, uint32_t pairs, Workspace ws, const uint32_t* __restrict__ agg, Workspace ws2) {
+// its final exponentiation.  One sub-batch per lane pair, the running product in LDS.  g proofs share a Miller value (1: k_miller2, one per
+// proof; 2, 4, 8: k_agg_miller, kept at the group's first proof): sub-batch sb covers sub / g consecutive groups of its 64-proof block.
+__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_agg_fprod(size_t n, size_t n2, uint32_t sub, uint32_t g, Workspace ws, const uint32_t* __restrict__ agg, Workspace ws2) {
     __shared__ uint32_t lds[48 * ZKV_BLOCK];
     const size_t sb = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
     if (sb >= n2) return;
@@ -219,24 +234,25 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_agg_fprod(size_t n, size_t n2,
     LRef acc = l_ref(lds + threadIdx.x);
     MRef P2 = m_ref(ws2.f + (size_t)(8 * par) * ws2.cap + sb, (uint32_t)ws2.cap, 16);
     f12m_copy(acc, P2);
-    const uint32_t per = 64u / sub;                             // sub-batches per 64-proof block (pairs mode)
-    const size_t i0 = pairs ? (sb / per) * 64 + (sb % per) * (sub / 2) : sb * sub;
-    const uint32_t cnt = pairs ? sub / 2 : sub;
+    const uint32_t per = 64u / sub, L = 64u / g, w = sub / g;   // sub-batches per block, groups per block, groups per sub-batch
+    const size_t i0 = (sb / per) * 64 + (sb % per) * w;
 #pragma unroll 1
-    for (uint32_t k = 0; k < cnt; k++) {
-        const size_t i = i0 + k;
-        if (i >= n) break;
-        bool in = (agg[(size_t)AGG_W_FLAGS * ws.cap + i] & FL_ALIVE) && !ws.g2bad[i];      // both lanes of the pair read the same words
-        if (pairs && !in && i + 32 < n) in = (agg[(size_t)AGG_W_FLAGS * ws.cap + i + 32] & FL_ALIVE) && !ws.g2bad[i + 32];
+    for (uint32_t k = 0; k < w; k++) {
+        bool in = false;                                        // both lanes of the pair read the same words
+#pragma unroll 1
+        for (uint32_t p = 0; p < g && !in; p++) {
+            const size_t i = i0 + k + p * L;
+            if (i < n) in = (agg[(size_t)AGG_W_FLAGS * ws.cap + i] & FL_ALIVE) && !ws.g2bad[i];
+        }
         if (!in) continue;
-        MRef Pi = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, (uint32_t)ws.cap, 16);
+        MRef Pi = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i0 + k, (uint32_t)ws.cap, 16);
         f12m_mul(acc, acc, Pi);
     }
     f12m_copy(P2, acc);
 }
-void launch_agg_fprod(size_t n, size_t n2, uint32_t sub, bool pairs, const Workspace& ws, const uint32_t* agg, const Workspace& ws2, hipStream_t s) {
+void launch_agg_fprod(size_t n, size_t n2, uint32_t sub, uint32_t g, const Workspace& ws, const uint32_t* agg, const Workspace& ws2, hipStream_t s) {
     if (!n2) return;
-    hipLaunchKernelGGL(k_agg_fprod, dim3((unsigned)((2 * n2 + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, n2, sub, pairs ? 1u : 0u, ws, agg, ws2);
+    hipLaunchKernelGGL(k_agg_fprod, dim3((unsigned)((2 * n2 + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, n2, sub, g, ws, agg, ws2);
 }
 
 static inline unsigned pair_grid(size_t n) { return (unsigned)((2 * n + ZKV_BLOCK - 1) / ZKV_BLOCK); }

@@ -381,6 +381,15 @@ static size_t agg_min() {
     size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)131072;
     return v < 64 ? 64 : v;
 }
+// Proofs per Miller accumulator in the aggregate check (k_agg_miller; 1 = k_miller2, an accumulator per proof).  ZKV_AGG_GROUP overrides;
+// a sub-batch must hold at least two groups.
+static uint32_t agg_group(uint32_t sub) {
+    const char* e = getenv("ZKV_AGG_GROUP");
+    uint32_t g = e ? (uint32_t)strtoul(e, nullptr, 10) : 4u;
+    if (g != 1 && g != 2 && g != 4 && g != 8) g = 4;
+    while (g > 1 && sub / g < 2) g >>= 1;
+    return g;
+}
 // Miller loop / final exponentiation of n proofs in workspace ws with the kernel family the chunk size selects (as enqueue_chunk does)
 static void launch_miller_by_size(zkv_ctx* c, size_t n, const Workspace& ws, uint8_t* status, hipStream_t s) {
     if (n <= dual_below()) launch_miller_w64d(n, c->d_tab, ws, status, s);
@@ -400,22 +409,22 @@ static void launch_finalexp_by_size(size_t n, const Workspace& ws, uint8_t* stat
 static void enqueue_agg(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed) {
     const uint32_t sub = c->agg_sub;
     const size_t n2 = ((a.n + 63) / 64) * (64 / sub);         // sub-batches, the last 64-proof block counted in full (empty ones switch themselves off)
-    const char* pe = getenv("ZKV_AGG_PAIRS");                 // 0: one Miller accumulator per proof (k_miller2) instead of one per two proofs
-    const bool pairs = !(pe && pe[0] == '0');
+    // proofs per Miller accumulator: ZKV_AGG_GROUP = 1 (k_miller2), 2, 4 or 8 (k_agg_miller); at most the sub-batch's eighth... see agg_group()
+    const uint32_t grp = agg_group(sub);
     const InstTab* inst = a.inst ? c->d_inst : nullptr;
     c->agg_seed.call++;                                       // fresh coefficients for every chunk
     // vk_x through summed scalars: one key (no per-proof base) and at most two per-proof signals
     const bool sums = !inst && (c->vm == ZKV_VM_RISC0 || c->vm == ZKV_VM_SP1 || (c->vm == ZKV_VM_GROTH16 && c->g_n_ic >= 1 && c->g_n_ic - 1 <= (uint32_t)AGG_SUM_VARS));
     launch_agg_g1(a.n, c->d_tab, inst, c->ws, c->d_agg, c->agg_seed, sums, s);
     if (timed) { (void)hipEventRecord(c->ev[2], s); (void)hipEventRecord(c->ev[3], s); }
-    if (pairs) launch_agg_miller(a.n, c->d_tab, c->ws, a.status, s);
+    if (grp > 1) launch_agg_miller(a.n, grp, c->d_tab, c->ws, a.status, s);
     else launch_miller2(a.n, c->d_tab, c->ws, a.status, s);
-    launch_agg_reduce(a.n, sub, sums, pairs, c->d_tab, c->ws, c->d_agg, c->d_agg_tab, c->ws2, c->d_status2, s);
+    launch_agg_reduce(a.n, sub, sums, grp, c->d_tab, c->ws, c->d_agg, c->d_agg_tab, c->ws2, c->d_status2, s);
     launch_miller_by_size(c, n2, c->ws2, c->d_status2, s);
     if (timed) (void)hipEventRecord(c->ev[4], s);
-    launch_agg_fprod(a.n, n2, sub, pairs, c->ws, c->d_agg, c->ws2, s);
+    launch_agg_fprod(a.n, n2, sub, grp, c->ws, c->d_agg, c->ws2, s);
     launch_finalexp_by_size(n2, c->ws2, c->d_status2, s);
-    launch_agg_mark(a.n, sub, pairs, c->ws, c->d_agg, c->d_status2, a.status, c->d_agg_cnt, c->d_agg_idx, s);
+    launch_agg_mark(a.n, sub, grp, c->ws, c->d_agg, c->d_status2, a.status, c->d_agg_cnt, c->d_agg_idx, s);
     launch_agg_gather(a.n, c->ws, c->d_agg, c->d_agg_cnt, c->d_agg_idx, c->ws3, c->d_status3, s);
     launch_msm(a.n, c->d_tab, inst, c->ws3, s);
     launch_miller2(a.n, c->d_tab, c->ws3, c->d_status3, s);

@@ -363,18 +363,18 @@ struct SoaRW {
     ZKV_HD void st(int k, uint32_t v) const { *(uint32_t*)((char*)(p + (size_t)k * stride) + off) = v; }
     ZKV_HD int fw() const { return 16; }
 };
-// The Miller loop of the aggregate check (zkv_agg.h) for TWO proofs of one lane pair that share the accumulator: f <- f^2 once per
+// The Miller loop of the aggregate check (zkv_agg.h) for G proofs of one lane pair that share the accumulator: f <- f^2 once per
 // doubling step, then each proof's line -- only the variable pairs (r A'_p, B_p); the fixed pairs are taken once per sub-batch.  The
-// running points live in HBM rows (tq; proof 1's rows `step` bytes after proof 0's, as in norm and bsrc) and pass through registers
+// running points live in HBM rows (tq; proof p's rows p * `step` bytes after proof 0's, as in norm and bsrc) and pass through registers
 // only while their line is formed: LDS holds nothing but f, which keeps two wavefronts per SIMD.  mask bit p: proof p takes part
 // (alive, B finite); abmask bit p: its pair contributes (A finite as well).  Returns bit p set when proof p's B passed the
 // subgroup test the loop doubles as (miller_loop_p); a proof outside the mask reports set.
-template <class RF>
-ZKV_HD uint32_t miller_loop_p2(uint32_t mask, uint32_t abmask, SoaRef norm, SoaRef bsrc, SoaRW tq, uint32_t step, RF fm) {
+template <int G, class RF>
+ZKV_HD uint32_t miller_loop_pg(uint32_t mask, uint32_t abmask, SoaRef norm, SoaRef bsrc, SoaRW tq, uint32_t step, RF fm) {
     const uint8_t KIND[ZKV_MILLER_STEPS] = ZKV_MILLER_STEP_KIND;
     f12m_set_one(fm);
 #pragma unroll 1
-    for (uint32_t p = 0; p < 2; p++) {
+    for (uint32_t p = 0; p < (uint32_t)G; p++) {
         if (!((mask >> p) & 1u)) continue;
         SoaRef b = bsrc; b.off += p * step;
         SoaRW t = tq; t.off += p * step;
@@ -389,7 +389,7 @@ ZKV_HD uint32_t miller_loop_p2(uint32_t mask, uint32_t abmask, SoaRef norm, SoaR
 #endif
         if (kind == 0 && li != 0) f12m_sqr_body(fm);
 #pragma unroll 1
-        for (uint32_t p = 0; p < 2; p++) {
+        for (uint32_t p = 0; p < (uint32_t)G; p++) {
             if (!((mask >> p) & 1u)) continue;
             SoaRef n = norm; n.off += p * step;
             SoaRef b = bsrc; b.off += p * step;
@@ -411,9 +411,9 @@ ZKV_HD uint32_t miller_loop_p2(uint32_t mask, uint32_t abmask, SoaRef norm, SoaR
             }
         }
     }
-    uint32_t fine = 3u;
+    uint32_t fine = (1u << G) - 1u;
 #pragma unroll 1
-    for (uint32_t p = 0; p < 2; p++) {
+    for (uint32_t p = 0; p < (uint32_t)G; p++) {
         if (!((mask >> p) & 1u)) continue;
         SoaRef b = bsrc; b.off += p * step;
         SoaRW t = tq; t.off += p * step;

@@ -105,10 +105,10 @@ extern "C" int hs2_f2_edge(const uint32_t* in32, uint32_t* out80) {
     return j.ok[0] && j.ok[1];
 }
 
-// Two proofs on one lane pair with a shared accumulator (miller_loop_p2, the aggregate check's Miller kernel) against the product of the
+// Two or four proofs on one lane pair with a shared accumulator (miller_loop_pg, the aggregate check's Miller kernel) against the product of the
 // two proofs' own Miller values from miller_loop_p with the fixed pairs switched off: 1 = equal (and both subgroup verdicts as given).
-struct Job2 { const VkTables* t; uint32_t mask, abmask; const uint32_t* norm96; const uint32_t* b96; int ok[2]; uint32_t fine[2]; };     // 48 words per proof in both arrays
-static uint32_t g_tq[2 * 48];                   // the running points' rows: proof p at words [48 p, 48 p + 48), shared by the two lanes like HBM
+struct Job2 { const VkTables* t; int g; uint32_t mask, abmask; const uint32_t* norm96; const uint32_t* b96; int ok[2]; uint32_t fine[2]; };     // 48 words per proof in both arrays
+static uint32_t g_tq[4 * 48];                   // the running points' rows: proof p at words [48 p, 48 p + 48), shared by the two lanes like HBM
 static void lane2(Job2* j, uint32_t par) {
     tl_par = par;
     static thread_local uint32_t half[48 + 48 + 48 + 24];
@@ -116,10 +116,10 @@ static void lane2(Job2* j, uint32_t par) {
     // rows laid out with stride 1 and proof 1 exactly 48 words (192 bytes) after proof 0
     SoaRef norm = {j->norm96, 1, 0u}, bsrc = {j->b96 + 8 * par, 1, 0u};
     SoaRW tq = {g_tq, 1, 4u * 8u * par};
-    const uint32_t fine = miller_loop_p2(j->mask, j->abmask, norm, bsrc, tq, 4u * 48u, fm);
+    const uint32_t fine = j->g == 4 ? miller_loop_pg<4>(j->mask, j->abmask, norm, bsrc, tq, 4u * 48u, fm) : miller_loop_pg<2>(j->mask, j->abmask, norm, bsrc, tq, 4u * 48u, fm);
     j->fine[par] = fine;
     f12m_set_one(prod);
-    for (uint32_t p = 0; p < 2; p++) {
+    for (uint32_t p = 0; p < (uint32_t)j->g; p++) {
         if (!((j->mask >> p) & 1u)) continue;
         SoaRef n1 = {j->norm96 + 48 * p, 1, 0u}, b1 = {j->b96 + 48 * p + 8 * par, 1, 0u};
         const uint32_t fl = FL_ALIVE | FL_L_INF | FL_C_INF | (((j->abmask >> p) & 1u) ? 0u : (uint32_t)FL_A_INF);
@@ -130,8 +130,8 @@ static void lane2(Job2* j, uint32_t par) {
     for (int k = 0; k < 6; k++) same = f2_eq(m_ld_f2(fm, k), m_ld_f2(prod, k)) && same;
     j->ok[par] = same ? 1 : 0;
 }
-extern "C" int hs2_miller2(const void* tables, uint32_t mask, uint32_t abmask, const uint32_t* norm96, const uint32_t* b96, uint32_t* fine) {
-    Job2 j; j.t = (const VkTables*)tables; j.mask = mask; j.abmask = abmask; j.norm96 = norm96; j.b96 = b96;
+extern "C" int hs2_miller2(const void* tables, int g, uint32_t mask, uint32_t abmask, const uint32_t* norm96, const uint32_t* b96, uint32_t* fine) {
+    Job2 j; j.t = (const VkTables*)tables; j.g = g; j.mask = mask; j.abmask = abmask; j.norm96 = norm96; j.b96 = b96;
     g_cnt = 0;
     std::thread t1(lane2, &j, 1u);
     lane2(&j, 0u);

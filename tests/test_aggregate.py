@@ -137,7 +137,7 @@ def test_window_shares_sum_to_the_weighted_vk_x(hsa, real_proofs):
 
 
 def test_two_proofs_sharing_the_miller_accumulator(real_proofs, verify_corpus):
-    """miller_loop_p2 (two proofs of a lane pair, one accumulator, running points in memory rows) == the product of the two proofs' own
+    """miller_loop_pg (two or four proofs of a lane pair, one accumulator, running points in memory rows) == the product of the proofs' own
     Miller values, for both / one proof taking part, with A at infinity, and a B outside the subgroup reported in its bit."""
     csrc = os.path.join(HERE, '..', 'stylus_zkvm_verifiers_amd', 'csrc')
     def build(name, extra):
@@ -148,7 +148,7 @@ def test_two_proofs_sharing_the_miller_accumulator(real_proofs, verify_corpus):
         return C.CDLL(lib)
     hs, hp = build('host_sim', []), build('host_sim_paired', ['-pthread'])
     hs.hs_prepare.restype = C.c_void_p
-    hp.hs2_miller2.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    hp.hs2_miller2.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     r0 = real_proofs['risc0']
     cr, cid = H(r0['control_root']), H(r0['bn254_control_id'])
     v = m.Risc0Verifier(); v.initialize(cr, cid)
@@ -166,7 +166,14 @@ def test_two_proofs_sharing_the_miller_accumulator(real_proofs, verify_corpus):
         norm96 = (C.c_uint32 * 96)(*(rows[i][2] + rows[k][2]))
         b96 = (C.c_uint32 * 96)(*(rows[i][3] + [0] * 16 + rows[k][3] + [0] * 16))
         fine = C.c_uint32(0)
-        return hp.hs2_miller2(t, mask, abmask, norm96, b96, C.byref(fine)), fine.value
+        return hp.hs2_miller2(t, 2, mask, abmask, norm96, b96, C.byref(fine)), fine.value
+    def run4(idx, mask, abmask):
+        norm = (C.c_uint32 * 192)(*sum((rows[i][2] for i in idx), []))
+        b = (C.c_uint32 * 192)(*sum((rows[i][3] + [0] * 16 for i in idx), []))
+        fine = C.c_uint32(0)
+        return hp.hs2_miller2(t, 4, mask, abmask, norm, b, C.byref(fine)), fine.value
+    assert run4((0, 1, 2, 0), 15, 15) == (1, 15)
+    assert run4((2, 1, 0, 1), 0b1011, 0b0011) == (1, 15)
     assert run(0, 1, 3, 3) == (1, 3)
     assert run(1, 2, 3, 3) == (1, 3)
     assert run(0, 0, 3, 3) == (1, 3)                   # the same proof twice
@@ -189,12 +196,11 @@ def _risc0_inputs(real_proofs, n, seed, mutate_every, classes=None):
     return seals, ids, jds, mut, mclass
 
 
-def _sub_batches(n, sub, pairs=True):
-    """Sub-batches counted for a chunk of n proofs: contiguous runs of `sub` proofs, or -- with two proofs per Miller accumulator, the
-    default -- per 64-proof block 64 / sub groups of sub / 2 proofs of the lower half and their partners 32 further on."""
-    if not pairs: return (n + sub - 1) // sub
+def _sub_batches(n, sub, g=4):
+    """Sub-batches counted for a chunk of n proofs.  g proofs share a Miller accumulator (default 4; members l, l + 64/g, ... of a 64-proof
+    block): a sub-batch is sub / g consecutive proofs of the block's first 64 / g and their partners; g = 1: `sub` consecutive proofs."""
     full, rem = divmod(n, 64)
-    return full * (64 // sub) + (min(rem, 32) + sub // 2 - 1) // (sub // 2)
+    return full * (64 // sub) + (min(rem, 64 // g) + sub // g - 1) // (sub // g)
 
 
 def _run_risc0_dev(v, seals, ids, jds):
@@ -224,17 +230,17 @@ def test_aggregate_check_gives_the_deterministic_statuses(real_proofs, monkeypat
     v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
     plain = _run_risc0_dev(v, seals, ids, jds)
     total = 0
-    for pairs in (True, False):
-        monkeypatch.setenv('ZKV_AGG_PAIRS', '1' if pairs else '0')
+    for g in (4, 1, 2, 8):
+        monkeypatch.setenv('ZKV_AGG_GROUP', str(g))
         for sub in (16, 32, 64):
             v.set_aggregate_check(True, seed=bytes(range(32)), sub_batch=sub)
             agg = _run_risc0_dev(v, seals, ids, jds)
             checked, failed = v.aggregate_counters()
-            assert (agg == plain).all(), (pairs, sub)
+            assert (agg == plain).all(), (g, sub)
             assert ((agg == 0) == ~mut).all()
-            total += _sub_batches(n, sub, pairs)
+            total += _sub_batches(n, sub, g)
             assert checked == total and 0 < failed <= checked
-    monkeypatch.delenv('ZKV_AGG_PAIRS')
+    monkeypatch.delenv('ZKV_AGG_GROUP')
     # a second run draws other coefficients (the per-chunk counter): same statuses
     assert (_run_risc0_dev(v, seals, ids, jds) == plain).all()
     k = 512
