@@ -413,3 +413,36 @@ def test_aggregate_check_on_a_sharded_verifier(real_proofs, monkeypatch):
     checked, failed = v.aggregate_counters()
     assert checked == 3 * _sub_batches(1000, 16) and failed > 0
     v.close()
+
+
+@pytest.mark.gpu
+def test_aggregate_check_engages_at_its_default_threshold(real_proofs):
+    """No environment overrides: a 2^17-proof SP1 chunk takes the aggregate check with the default sub-batch (32) and group (4) sizes, a
+    chunk one proof short of the threshold does not; statuses == the per-proof path == accept <=> not mutated on all 131,072 proofs."""
+    import numpy as np
+    import torch
+    import stylus_zkvm_verifiers_amd as zkv
+    from stylus_zkvm_verifiers_amd import synth
+    for k in ('ZKV_AGG_MIN', 'ZKV_AGG_GROUP', 'ZKV_CHUNK'):
+        assert k not in os.environ
+    dev = torch.device('cuda', 0)
+    s = real_proofs['sp1']
+    n = 1 << 17
+    proofs, mut, _, flip = synth.make_batch_parallel('sp1', H(s['proof']), n, 0x5A4B56AB, mutate_every=64, cache=False)
+    vk = np.tile(np.frombuffer(H(s['vkey']), dtype=np.uint8), (n, 1))
+    pv = np.tile(np.frombuffer(H(s['public_values']), dtype=np.uint8), (n, 1)); pv[flip, -1] ^= 1
+    d_p, d_vk, d_pv = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (proofs, vk, pv))
+    v = zkv.Sp1Verifier()
+    def run(m):
+        d_st = torch.full((m,), 255, dtype=torch.uint8, device=dev)
+        v.verify_batch_dev(m, d_vk.data_ptr(), d_pv.data_ptr(), 96, d_p.data_ptr(), d_st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return d_st.cpu().numpy()
+    plain = run(n)
+    v.set_aggregate_check(True)                                 # secret from the operating system
+    assert (run(n - 1) == plain[:n - 1]).all() and v.aggregate_counters() == (0, 0)
+    agg = run(n)
+    checked, failed = v.aggregate_counters()
+    assert (agg == plain).all() and ((agg == 0) == ~mut).all()
+    assert checked == n // 32 and 0 < failed < checked // 4
+    v.close()
