@@ -312,7 +312,9 @@ int zkv_ctx_set_lanes_per_proof(zkv_ctx* ctx, int lanes);
  * sub-batch over the coefficients -- provided the proofs were fixed before the secret was drawn.  seed32 = NULL draws the secret from
  * the operating system (getrandom) -- the setting for production; a caller-supplied seed makes runs reproducible (tests) and must
  * not be known to whoever supplies proofs.  Applies to RISC Zero, SP1 (Groth16), verifier-set, generic-key, mixed and sharded
- * contexts; ZKV_ERR_INVALID_ARG on a PLONK or precompile context.  Keys with alpha or beta at infinity fall back to the ordinary path.
+ * contexts, and to SP1 PLONK contexts (both pairs of a PLONK check are fixed: prod_i (e(D_i, [1]_2) e(-Q_i, [tau]_2))^{r_i} needs two
+ * scalar multiplications per proof and one pairing product per sub-batch -- no per-proof Miller loop is left); ZKV_ERR_INVALID_ARG on
+ * a precompile context.  Keys with alpha or beta at infinity fall back to the ordinary path.
  * Throughput: see DESIGN.md (2^20 SP1 proofs: 11.4 M proofs/s all valid, 9.6 M with one proof in 64 rejected, against 5.7 M; a proof
  * rejected at the pairing costs its sub-batch a second, ordinary pass, and small chunks gain nothing). */
 int zkv_ctx_set_aggregate_check(zkv_ctx* ctx, int enable, const uint8_t* seed32);

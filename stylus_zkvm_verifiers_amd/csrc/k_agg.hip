@@ -164,9 +164,12 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_agg_reduce(size_t n, uint32_t sub
 #pragma unroll 1
         for (int m = 32; m >= 1; m >>= 1) if (dist & (uint32_t)m) U = g1j_add(U, g1j_xor(U, m));
     }
-    G1J E = agg_e_share(*tab, lane, sub, ((uint64_t)s1[1] << 32) | s1[0], s1[2], ((uint64_t)s2[1] << 32) | s2[0], s2[2], cnt + 1u);
+    G1J E = g1j_infinity();
+    if (tab) {                                                  // (a PLONK context has no (alpha, beta) pair: no table, no E)
+        E = agg_e_share(*tab, lane, sub, ((uint64_t)s1[1] << 32) | s1[0], s1[2], ((uint64_t)s2[1] << 32) | s2[0], s2[2], cnt + 1u);
 #pragma unroll 1
-    for (int m = 32; m >= 1; m >>= 1) if (dist & (uint32_t)m) E = g1j_add(E, g1j_xor(E, m));
+        for (int m = 32; m >= 1; m >>= 1) if (dist & (uint32_t)m) E = g1j_add(E, g1j_xor(E, m));
+    }
     if (lane != 0) return;                                      // (a sub-batch past the end of the chunk has cnt = 0)
     ws2.g2bad[sb] = 0;
     if (cnt == 0) { ws2.flags[sb] = 0; status2[sb] = ST_OK; return; }       // nothing left to check in this sub-batch
@@ -176,8 +179,10 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_agg_reduce(size_t n, uint32_t sub
     ws_st(ws2.norm, ws2.cap, 0, sb, o.axs); ws_st(ws2.norm, ws2.cap, 8, sb, o.ays);
     ws_st(ws2.norm, ws2.cap, 16, sb, o.lxs); ws_st(ws2.norm, ws2.cap, 24, sb, o.lys);
     ws_st(ws2.norm, ws2.cap, 32, sb, o.cxs); ws_st(ws2.norm, ws2.cap, 40, sb, o.cys);
+    if (tab) {
 #pragma unroll 1
-    for (int k = 0; k < 4; k++) ws_st(ws2.prep, ws2.cap, 32 + 8 * k, sb, tab->beta[k]);
+        for (int k = 0; k < 4; k++) ws_st(ws2.prep, ws2.cap, 32 + 8 * k, sb, tab->beta[k]);
+    } else flags |= FL_B_INF;
     ws2.flags[sb] = flags;
     status2[sb] = ST_VERIFICATION_FAILED;
 }
@@ -231,6 +236,55 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_agg_scatter(size_t n, const unsig
                                                            const uint8_t* __restrict__ status3, uint8_t* __restrict__ status) {
     const size_t j = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (j < n && j < counters[2]) status[idx[j]] = status3[j];
+}
+
+// PLONK contexts (two FIXED pairs: e(D, [1]_2) e(-Q, [tau]_2) == 1): the aggregate check needs no per-proof Miller loop at all --
+// prod_i (e(D_i, [1]_2) e(-Q_i, [tau]_2))^{r_i} = e(sum r_i D_i, [1]_2) e(sum r_i (-Q_i), [tau]_2).  k_plonk_prep runs unchanged; this
+// kernel turns its normalised rows (x/y, 1/y of D and -Q) back into affine points (one inversion), scales them by r_i and parks them
+// where the Groth16 form keeps U and W.  A zero coefficient (probability 2^-128) is replaced by 1: the second pass re-checks a proof
+// through its SCALED points, which is the proof's own check raised to r_i.
+__global__ __launch_bounds__(ZKV_BLOCK) void k_agg_plonk_g1(size_t n, Workspace ws, uint32_t* __restrict__ agg, AggSeed seed) {
+    size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t flags = ws.flags[i];
+    agg[(size_t)AGG_W_FLAGS * ws.cap + i] = flags;
+    if (!(flags & FL_ALIVE)) return;
+    uint64_t r1, r2;
+    agg_coeff(seed, (uint32_t)i, r1, r2);
+    if (!(r1 | r2)) r1 = 1;
+    const bool dinf = (flags & FL_L_INF) != 0, qinf = (flags & FL_C_INF) != 0;
+    const Fp one = fp_one();
+    const Fp dys = dinf ? one : ws_ld(ws.norm, ws.cap, 24, i), qys = qinf ? one : ws_ld(ws.norm, ws.cap, 40, i);      // 1 / y
+    const Fp inv = fp_inv(fp_mul(dys, qys));
+    const Fp dy = fp_mul(inv, qys), qy = fp_mul(inv, dys);
+    agg_st_g1j(agg, ws.cap, AGG_W_U, i, dinf ? g1j_infinity() : agg_mul(fp_mul(ws_ld(ws.norm, ws.cap, 16, i), dy), dy, r1, r2));
+    agg_st_g1j(agg, ws.cap, AGG_W_W, i, qinf ? g1j_infinity() : agg_mul(fp_mul(ws_ld(ws.norm, ws.cap, 32, i), qy), qy, r1, r2));
+}
+// ... and for the second pass: the scaled points of the listed proofs, normalised into the dense workspace's rows
+__global__ __launch_bounds__(ZKV_BLOCK) void k_agg_plonk_norm(size_t n, Workspace ws, const uint32_t* __restrict__ agg, const unsigned long long* __restrict__ counters,
+                                                              const uint32_t* __restrict__ idx, Workspace ws3, uint8_t* __restrict__ status3) {
+    const size_t j = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
+    if (j >= n) return;
+    if (j >= counters[2]) { ws3.flags[j] = 0; return; }
+    const size_t i = idx[j];
+    uint32_t flags = FL_ALIVE | FL_B_INF;
+    G1Norm o;
+    agg_normalize3(g1j_infinity(), agg_ld_g1j(agg, ws.cap, AGG_W_U, i), agg_ld_g1j(agg, ws.cap, AGG_W_W, i), flags, o);
+    ws_st(ws3.norm, ws3.cap, 0, j, o.axs); ws_st(ws3.norm, ws3.cap, 8, j, o.ays);
+    ws_st(ws3.norm, ws3.cap, 16, j, o.lxs); ws_st(ws3.norm, ws3.cap, 24, j, o.lys);
+    ws_st(ws3.norm, ws3.cap, 32, j, o.cxs); ws_st(ws3.norm, ws3.cap, 40, j, o.cys);
+    ws3.flags[j] = flags;
+    ws3.g2bad[j] = 0;
+    status3[j] = ST_VERIFICATION_FAILED;
+}
+void launch_agg_plonk_g1(size_t n, const Workspace& ws, uint32_t* agg, const AggSeed& seed, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_agg_plonk_g1, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, ws, agg, seed);
+}
+void launch_agg_plonk_norm(size_t n, const Workspace& ws, const uint32_t* agg, const unsigned long long* counters, const uint32_t* idx, const Workspace& ws3,
+                           uint8_t* status3, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_agg_plonk_norm, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, ws, agg, counters, idx, ws3, status3);
 }
 
 void launch_agg_g1(size_t n, const VkTables* d_tab, const InstTab* inst_tab, const Workspace& ws, uint32_t* agg, const AggSeed& seed, bool sums, hipStream_t s) {

@@ -228,10 +228,12 @@ static int ctx_device_setup(zkv_ctx* c) {
         launch_setup(d_raw, c->d_tab, c->stream);
         HIP_TRY(hipGetLastError());
         const bool agg_vm = c->vm == ZKV_VM_RISC0 || c->vm == ZKV_VM_RISC0_SET || c->vm == ZKV_VM_SP1 || c->vm == ZKV_VM_GROTH16;
-        if (agg_vm) {
-            HIP_TRY(hipMalloc(&c->d_agg_tab, sizeof(AggTables)));
+        if (agg_vm || c->vm == ZKV_VM_SP1_PLONK) {
             HIP_TRY(hipMalloc(&c->d_agg_cnt, 3 * sizeof(unsigned long long)));
             HIP_TRY(hipMemsetAsync(c->d_agg_cnt, 0, 3 * sizeof(unsigned long long), c->stream));
+        }
+        if (agg_vm) {
+            HIP_TRY(hipMalloc(&c->d_agg_tab, sizeof(AggTables)));
             launch_setup_agg(d_raw, c->d_tab, c->d_agg_tab, c->stream);
             HIP_TRY(hipGetLastError());
         }
@@ -266,6 +268,7 @@ static int ctx_device_setup(zkv_ctx* c) {
             HIP_TRY(hipMemcpy(&ok, &c->d_agg_tab->ok, sizeof ok, hipMemcpyDeviceToHost));
             c->agg_key_ok = ok != 0;
         }
+        if (c->vm == ZKV_VM_SP1_PLONK) c->agg_key_ok = !c->vk_invalid;      // (no (alpha, beta) pair: nothing else to tabulate)
     }
     return ZKV_OK;
 }
@@ -433,6 +436,25 @@ static void enqueue_agg(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed
     if (timed) (void)hipEventRecord(c->ev[5], s);
 }
 
+// The aggregate check of a PLONK chunk, after the unchanged PREP stage (k_agg_plonk_g1 explains why there is no per-proof Miller loop).
+static void enqueue_agg_plonk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed) {
+    const uint32_t sub = c->agg_sub;
+    const size_t n2 = ((a.n + 63) / 64) * (64 / sub);
+    c->agg_seed.call++;
+    launch_agg_plonk_g1(a.n, c->ws, c->d_agg, c->agg_seed, s);
+    if (timed) { (void)hipEventRecord(c->ev[2], s); (void)hipEventRecord(c->ev[3], s); }
+    launch_agg_reduce(a.n, sub, false, 1, c->d_tab, c->ws, c->d_agg, nullptr, c->ws2, c->d_status2, s);
+    launch_miller_by_size(c, n2, c->ws2, c->d_status2, s);
+    if (timed) (void)hipEventRecord(c->ev[4], s);
+    launch_finalexp_by_size(n2, c->ws2, c->d_status2, s);
+    launch_agg_mark(a.n, sub, 1, c->ws, c->d_agg, c->d_status2, a.status, c->d_agg_cnt, c->d_agg_idx, s);
+    launch_agg_plonk_norm(a.n, c->ws, c->d_agg, c->d_agg_cnt, c->d_agg_idx, c->ws3, c->d_status3, s);
+    launch_miller2(a.n, c->d_tab, c->ws3, c->d_status3, s);
+    launch_finalexp2(a.n, c->ws3, c->d_status3, s);
+    launch_agg_scatter(a.n, c->d_agg_cnt, c->d_agg_idx, c->d_status3, a.status, s);
+    if (timed) (void)hipEventRecord(c->ev[5], s);
+}
+
 // Enqueues the five stages for one chunk (all pointers device-resident).
 static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed) {
     if (timed) (void)hipEventRecord(c->ev[0], s);
@@ -442,6 +464,11 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
         PrepArgs ap = a;
         ap.plonk_tab = c->d_plonk_tab;
         launch_plonk_prep(ap, c->d_pkey, c->ws, s);
+        if (c->agg_on && c->agg_key_ok && c->agg_cap >= c->ws.cap && c->lanes == 0 && a.n >= agg_min()) {
+            if (timed) (void)hipEventRecord(c->ev[1], s);
+            enqueue_agg_plonk(c, a, s, timed);
+            return;
+        }
         if (timed) { (void)hipEventRecord(c->ev[1], s); (void)hipEventRecord(c->ev[2], s); (void)hipEventRecord(c->ev[3], s); }
         const int pl = c->lanes ? c->lanes : 2;
         const bool wave_p = pl == 64 || pl == 128 || (c->lanes == 0 && a.n <= wave_below());      // (no variable pair: nothing for a second wavefront to do)
@@ -1701,7 +1728,8 @@ ZKV_EXPORT int zkv_ctx_set_aggregate_check(zkv_ctx* c, int enable, const uint8_t
         }
         return ZKV_OK;
     }
-    if (c->vm != ZKV_VM_RISC0 && c->vm != ZKV_VM_RISC0_SET && c->vm != ZKV_VM_SP1 && c->vm != ZKV_VM_GROTH16) return enable ? ZKV_ERR_INVALID_ARG : ZKV_OK;
+    if (c->vm != ZKV_VM_RISC0 && c->vm != ZKV_VM_RISC0_SET && c->vm != ZKV_VM_SP1 && c->vm != ZKV_VM_GROTH16 && c->vm != ZKV_VM_SP1_PLONK)
+        return enable ? ZKV_ERR_INVALID_ARG : ZKV_OK;
     std::lock_guard<std::mutex> lk(c->mu);
     c->agg_on = enable != 0;
     if (enable) c->agg_sub = enable == 1 ? 32u : (uint32_t)enable;

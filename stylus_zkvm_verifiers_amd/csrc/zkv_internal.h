@@ -133,6 +133,9 @@ void launch_agg_mark(size_t n, uint32_t sub, uint32_t g, const Workspace& ws, co
                      uint32_t* idx, hipStream_t s);
 void launch_agg_gather(size_t n, const Workspace& ws, const uint32_t* agg, const unsigned long long* counters, const uint32_t* idx, const Workspace& ws3,
                        uint8_t* status3, hipStream_t s);
+void launch_agg_plonk_g1(size_t n, const Workspace& ws, uint32_t* agg, const AggSeed& seed, hipStream_t s);
+void launch_agg_plonk_norm(size_t n, const Workspace& ws, const uint32_t* agg, const unsigned long long* counters, const uint32_t* idx, const Workspace& ws3,
+                           uint8_t* status3, hipStream_t s);
 void launch_agg_scatter(size_t n, const unsigned long long* counters, const uint32_t* idx, const uint8_t* status3, uint8_t* status, hipStream_t s);
 
 // precompile-level batches (k_precompile.hip)

@@ -147,6 +147,14 @@ class Sp1PlonkVerifier:
     def reserve(self, n):
         _lib.check(self._L.zkv_ctx_reserve(self._h, n), 'zkv_ctx_reserve')
 
+    def set_aggregate_check(self, enable=True, seed=None, sub_batch=32):
+        """Opt-in (include/zkv.h): sub-batches share the two-pair check -- e(sum r D, [1]_2) e(sum r (-Q), [tau]_2) -- so no per-proof Miller
+        loop or final exponentiation is left; statuses stay the per-proof ones (failed sub-batches are checked again proof by proof)."""
+        _set_aggregate_check(self._L, self._h, enable, seed, sub_batch)
+
+    def aggregate_counters(self):
+        return _aggregate_counters(self._L, self._h)
+
     def synchronize(self):
         _lib.check(self._L.zkv_ctx_synchronize(self._h), 'zkv_ctx_synchronize')
 

@@ -333,3 +333,50 @@ def test_plonk_differential_fuzz_against_the_oracle(zkv, pool):
     assert (st == ost).all() and (rv.reshape(-1) == orv).all()
     assert (st == 0).sum() >= 25 and len(set(st.tolist())) >= 3
     v.close()
+
+
+@pytest.mark.gpu
+def test_plonk_aggregate_check_gives_the_per_proof_statuses(zkv, pool, monkeypatch):
+    """The opt-in aggregate check on a PLONK context (include/zkv.h; no per-proof Miller loop: scaled points summed per sub-batch): 2,000
+    pool proofs with one in seven damaged (a proof word, a public-values byte, the selector), sub-batches of 16 / 32 / 64: statuses ==
+    the per-proof path == the oracle; an all-valid batch has no failed sub-batch; and at its default threshold on 2^17 proofs."""
+    import torch
+    dev = torch.device('cuda', 0)
+    vk, vh = H(pool['vk']), H(pool['verifier_hash'])
+    v = zkv.Sp1PlonkVerifier(vk, vh)
+    def run(P, V, W):
+        n = len(P)
+        d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (V, W, P)]
+        d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev); d_rv = torch.zeros((n, 4), dtype=torch.uint8, device=dev)
+        v.verify_batch_dev(n, d[0].data_ptr(), d[1].data_ptr(), 96, d[2].data_ptr(), d_st.data_ptr(), d_rv.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return d_st.cpu().numpy(), d_rv.cpu().numpy()
+    monkeypatch.setenv('ZKV_AGG_MIN', '64')
+    n = 2000
+    P, V, W, mut, _ = _pool_batch(pool, n, 0x5A4B56AC, 7)
+    st0, rv0 = run(P, V, W)
+    ost, _ = ol.sp1_plonk_verify_batch(vk, vh, [x.tobytes() for x in V[:256]], [x.tobytes() for x in W[:256]], [x.tobytes() for x in P[:256]], threads=8)
+    assert (st0[:256] == ost).all() and ((st0 == 0) == ~mut).all()
+    total = 0
+    for sub in (16, 32, 64):
+        v.set_aggregate_check(True, seed=bytes(range(32)), sub_batch=sub)
+        st1, rv1 = run(P, V, W)
+        assert (st1 == st0).all() and (rv1 == rv0).all(), sub
+        checked, failed = v.aggregate_counters()
+        total += (n // 64) * (64 // sub) + (n % 64 + sub - 1) // sub
+        assert checked == total and 0 < failed <= checked
+    P, V, W, mut, _ = _pool_batch(pool, 1024, 0x5A4B56AD, 0)
+    c0 = v.aggregate_counters()
+    st, _ = run(P, V, W)
+    assert (st == 0).all() and v.aggregate_counters() == (c0[0] + 16, c0[1])
+    monkeypatch.delenv('ZKV_AGG_MIN')
+    v.set_aggregate_check(True)                                  # defaults, secret from the operating system
+    n = 1 << 17
+    P, V, W, mut, _ = _pool_batch(pool, n, 0x5A4B56AE, 64)
+    c0 = v.aggregate_counters()
+    st, _ = run(P, V, W)
+    assert ((st == 0) == ~mut).all() and v.aggregate_counters()[0] == c0[0] + n // 32
+    v.set_aggregate_check(False)
+    st2, _ = run(P, V, W)
+    assert (st2 == st).all()
+    v.close()

@@ -25,7 +25,8 @@ def main():
     hosts = {}
     for lg in [int(x) for x in args.log2.split(',')]:
         for mu in [int(x) for x in args.mutate.split(',')]:
-            hosts[(lg, mu)] = bench.synthesize(args.vm, 1 << lg, 0x5A4B5602 if args.vm == 'sp1' else 0x5A4B5601, g, mu)
+            hosts[(lg, mu)] = (bench.synthesize_plonk(1 << lg, 0x5A4B5605, mu) if args.vm == 'plonk' else
+                               bench.synthesize(args.vm, 1 << lg, 0x5A4B5602 if args.vm == 'sp1' else 0x5A4B5601, g, mu))
     import torch
     dev = torch.device('cuda', 0)
     stream = torch.cuda.current_stream().cuda_stream
