@@ -314,7 +314,10 @@ int zkv_ctx_set_lanes_per_proof(zkv_ctx* ctx, int lanes);
  * not be known to whoever supplies proofs.  Applies to RISC Zero, SP1 (Groth16), verifier-set, generic-key, mixed and sharded
  * contexts, and to SP1 PLONK contexts (both pairs of a PLONK check are fixed: prod_i (e(D_i, [1]_2) e(-Q_i, [tau]_2))^{r_i} needs two
  * scalar multiplications per proof and one pairing product per sub-batch -- no per-proof Miller loop is left); ZKV_ERR_INVALID_ARG on
- * a precompile context.  Keys with alpha or beta at infinity fall back to the ordinary path.
+ * a precompile context.  Keys with alpha or beta at infinity fall back to the ordinary path, and so does a context whose extra buffers
+ * (about 0.9 KB of HBM per proof in flight on top of the workspace's 3.7 KB) cannot be allocated -- zkv_ctx_aggregate_counters shows
+ * whether chunks were checked in aggregate.  zkv_ctx_last_stage_ms then reports: [1] the per-proof G1 scalar multiplications, [3] the
+ * Miller loops (variable pairs, sub-batch sums, pseudo-proofs), [4] everything after (pseudo-proofs' final exponentiation, second pass).
  * Throughput: see DESIGN.md (2^20 SP1 proofs: 11.4 M proofs/s all valid, 9.6 M with one proof in 64 rejected, against 5.7 M; a proof
  * rejected at the pairing costs its sub-batch a second, ordinary pass, and small chunks gain nothing). */
 int zkv_ctx_set_aggregate_check(zkv_ctx* ctx, int enable, const uint8_t* seed32);

@@ -289,7 +289,8 @@ static int ctx_device_init(zkv_ctx* c) {
 // of two, at most ZKV_CHUNK (default 2^20) proofs: a context that only ever verifies single proofs stays small, a 2^20-proof
 // batch runs as one chunk (larger launches amortise kernel tails: 4.12 M proofs/s at 2^18 per chunk against 4.00 at 2^17).
 // Growing frees the old buffers, which synchronises the device, so work in flight on them has finished.
-// Buffers of the aggregate check, sized with the workspace: 224 B of rows per proof and one pseudo-proof workspace per 16 proofs (the smallest sub-batch).
+// Buffers of the aggregate check, sized with the workspace (about 0.9 KB per proof in flight on top of its 3.7 KB): 224 B of rows per proof, one
+// pseudo-proof workspace per 16 proofs (the smallest sub-batch), and the dense workspace of the second pass (own PREP rows, flags, statuses, index list).
 static int agg_reserve(zkv_ctx* c) {
     if (!c->agg_on || !c->agg_key_ok || c->agg_cap >= c->ws.cap) return ZKV_OK;
     void** bufs[] = {(void**)&c->d_agg, (void**)&c->ws2.prep, (void**)&c->ws2.norm, (void**)&c->ws2.f, (void**)&c->ws2.fe, (void**)&c->ws2.flags,
@@ -308,8 +309,10 @@ static int agg_reserve(zkv_ctx* c) {
         hipMalloc(&c->ws3.prep, sizeof(uint32_t) * WS_PREP_WORDS * cap) != hipSuccess || hipMalloc(&c->ws3.flags, sizeof(uint32_t) * cap) != hipSuccess ||
         hipMalloc(&c->ws3.g2bad, sizeof(uint32_t) * cap) != hipSuccess || hipMalloc(&c->d_status3, cap) != hipSuccess ||
         hipMalloc(&c->d_agg_idx, sizeof(uint32_t) * cap) != hipSuccess) {
+        // no room for the extra 0.9 KB per proof in flight: the chunk takes the ordinary kernels (enqueue_chunk looks at agg_cap)
         (void)hipGetLastError();
-        return ZKV_ERR_OOM;
+        for (void** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+        return ZKV_OK;
     }
     c->ws3.norm = c->ws.norm; c->ws3.f = c->ws.f; c->ws3.fe = c->ws.fe; c->ws3.cap = cap;
     c->ws2.cap = cap2; c->agg_cap = cap;
