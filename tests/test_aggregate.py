@@ -446,3 +446,37 @@ def test_aggregate_check_engages_at_its_default_threshold(real_proofs):
     assert (agg == plain).all() and ((agg == 0) == ~mut).all()
     assert checked == n // 32 and 0 < failed < checked // 4
     v.close()
+
+
+@pytest.mark.gpu
+def test_aggregate_check_on_the_golden_corpus(real_proofs, verify_corpus, monkeypatch):
+    """Every case of the golden corpus (points at infinity in A, B, C, a B outside the subgroup, a valid but wrong B, selector and length
+    errors, ...), the RISC Zero and the SP1 ones each as one batch of several shuffled copies, through the aggregate check with every
+    sub-batch and group size: status and received selector as in the fixture."""
+    import numpy as np
+    import stylus_zkvm_verifiers_amd as zkv
+    monkeypatch.setenv('ZKV_AGG_MIN', '64')
+    r = real_proofs['risc0']
+    rng = random.Random(0xC0)
+    r0 = [c for c in verify_corpus['cases'] if c['vm'] == 'risc0']
+    s1 = [c for c in verify_corpus['cases'] if c['vm'] == 'sp1']
+    order0 = [k % len(r0) for k in range(6 * len(r0))]; rng.shuffle(order0)
+    order1 = [k % len(s1) for k in range(8 * len(s1))]; rng.shuffle(order1)
+    v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    sp = zkv.Sp1Verifier()
+    a0 = ([H(r0[k]['seal']) for k in order0], [H(r0[k]['image_id']) for k in order0], [H(r0[k]['journal_digest']) for k in order0])
+    a1 = ([H(s1[k]['vkey']) for k in order1], [H(s1[k]['public_values']) for k in order1], [H(s1[k]['proof']) for k in order1])
+    want0 = [r0[k]['status'] for k in order0]; want1 = [s1[k]['status'] for k in order1]
+    st, rv = v.verify_batch(*a0); assert [int(x) for x in st] == want0
+    st, rv1 = sp.verify_batch(*a1); assert [int(x) for x in st] == want1
+    for g in (4, 1, 2, 8):
+        monkeypatch.setenv('ZKV_AGG_GROUP', str(g))
+        for sub in (16, 32, 64):
+            v.set_aggregate_check(True, seed=bytes([sub + g]) * 32, sub_batch=sub)
+            sp.set_aggregate_check(True, seed=bytes([sub + g + 1]) * 32, sub_batch=sub)
+            st, rv_ = v.verify_batch(*a0)
+            assert [int(x) for x in st] == want0 and (np.asarray(rv_) == np.asarray(rv)).all(), (g, sub)
+            st, rv_ = sp.verify_batch(*a1)
+            assert [int(x) for x in st] == want1 and (np.asarray(rv_) == np.asarray(rv1)).all(), (g, sub)
+    assert v.aggregate_counters()[0] > 0 and sp.aggregate_counters()[0] > 0
+    v.close(); sp.close()
