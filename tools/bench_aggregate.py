@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--mutate', default='64,0')
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--sub', default='64')
+    ap.add_argument('--no-baseline', action='store_true', help='skip the run with the aggregate check off')
     args = ap.parse_args()
     g = bench.golden()
     hosts = {}
@@ -32,7 +33,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     for (lg, mu), h in hosts.items():
         s = bench.Shard(h, dev, g)
-        for on in [0] + [int(x) for x in args.sub.split(',')]:
+        for on in ([] if args.no_baseline else [0]) + [int(x) for x in args.sub.split(',')]:
             s.ctx.set_aggregate_check(bool(on), seed=bytes(range(32)) if on else None, sub_batch=on or 64)
             s.ctx.reserve(s.n); s.ctx.synchronize()
             c0 = s.ctx.aggregate_counters()
