@@ -201,3 +201,29 @@ def test_bench_self_launches_its_ranks_and_propagates_failure(z):
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--workload', 'risc0_2p16', '--proofs', '64'],
                        capture_output=True, text=True, timeout=600, env=dict(env, WORLD_SIZE='1', RANK='0'))
     assert p.returncode != 0 and 'launch one process per GPU' in p.stderr
+
+
+def test_aggregate_check_switch_host_side(z, real_proofs):
+    """zkv_ctx_set_aggregate_check touches no device: accepted values (0, 1, 16, 32, 64) on every context kind that has a pairing equation
+    of its own, a caller's seed or the operating system's, refused on a precompile context and for other sub-batch sizes; the counters of a
+    context that never ran are zero."""
+    import ctypes as C
+    L = z._lib.lib()
+    r = real_proofs['risc0']
+    v = z.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    sp = z.Sp1Verifier()
+    mx = z.MixedVerifier(H(r['control_root']), H(r['bn254_control_id']))
+    for ctx in (v, sp, mx):
+        for en in (1, 16, 32, 64, 0):
+            assert L.zkv_ctx_set_aggregate_check(ctx._h, en, None) == 0
+            assert L.zkv_ctx_set_aggregate_check(ctx._h, en, bytes(32)) == 0
+        for en in (2, 8, 48, 128, -1):
+            assert L.zkv_ctx_set_aggregate_check(ctx._h, en, None) != 0
+        assert ctx.aggregate_counters() == (0, 0)
+    assert L.zkv_ctx_set_aggregate_check(None, 1, None) != 0
+    pc = z.Bn254Precompiles()
+    assert L.zkv_ctx_set_aggregate_check(pc._h, 1, None) != 0 and L.zkv_ctx_set_aggregate_check(pc._h, 0, None) == 0
+    with pytest.raises(ValueError):
+        v.set_aggregate_check(True, seed=b'short')
+    for ctx in (v, sp, mx, pc):
+        ctx.close()
