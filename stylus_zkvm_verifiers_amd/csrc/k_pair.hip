@@ -91,16 +91,19 @@ ZKV_HD bool pair_all(bool mine) {          // AND over the two lanes of a pair
 // only the point is stepped), k_pairing_miller runs the Miller loop - the subgroup test of Q as well - and multiplies into the call's
 // F slot; ok[] collects the verdict on the inputs.  Then the final exponentiation of the valid calls.  (As one kernel per pair the
 // check's inversion and the Miller loop shared a frame of 70 spilled VGPRs; with the pair loop inside as well, 217.)
-__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_check(size_t n, uint32_t k, uint32_t j, const uint8_t* __restrict__ in, Workspace ws,
+// slot_off: where pair j's rows go -- 0 (the call's own slot, one pair at a time) or j * n (all pairs of a call resident at once, for
+// k_pairing_miller_g).
+__global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_check(size_t n, uint32_t k, uint32_t j, size_t slot_off, const uint8_t* __restrict__ in, Workspace ws,
                                                                 uint8_t* __restrict__ ok) {
-    size_t i = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
-    if (i >= n) return;
+    const size_t call = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
+    if (call >= n) return;
+    const size_t i = call + slot_off;
     const uint32_t par = threadIdx.x & 1u;
     if (j == 0) {
-        f12m_set_one(m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, (uint32_t)ws.cap, 16));
-        if (!par) ok[i] = 1;
-    } else if (!ok[i]) { if (!par) ws.flags[i] = 0; return; }   // an earlier pair of this call was invalid (both lanes read the same byte)
-    const uint8_t* p = in + (size_t)192 * ((size_t)k * i + j);
+        f12m_set_one(m_ref(ws.f + (size_t)(8 * par) * ws.cap + call, (uint32_t)ws.cap, 16));
+        if (!par) ok[call] = 1;
+    } else if (!ok[call]) { if (!par) ws.flags[i] = 0; return; }   // an earlier pair of this call was invalid (both lanes read the same byte)
+    const uint8_t* p = in + (size_t)192 * ((size_t)k * call + j);
     uint32_t gx[8], gy[8], qxw[8], qyw[8];
     load_be256(gx, p); load_be256(gy, p + 32);
     load_be256(qxw, p + 64 + 32 * (1 - par));                   // wire order (imaginary, real): the even lane takes the real parts
@@ -122,7 +125,34 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_check(size_t n, uint32
             run = pinf ? 2u : 1u;
         }
     }
-    if (!par) { ws.flags[i] = run; if (!okj) ok[i] = 0; }
+    if (!par) { ws.flags[i] = run; if (!okj) ok[call] = 0; }
+}
+// All pairs of a call in ONE Miller loop with one accumulator (miller_loop_pg: f is squared once per step for the whole call instead of once per
+// pair -- for the reference's four pairs, common/groth16.rs:109-128, 24.0 k instead of 32.8 k multiply-adds per step and lane).  Pair p's rows are in
+// slot call + p n (k_pairing_check with slot_off = p n), its running point in the final exponentiation's scratch rows of that slot.  k <= G.
+template <int G>
+__global__ __launch_bounds__(PAIR_BLOCK, 2) void k_pairing_miller_g(size_t n, uint32_t k, Workspace ws, uint8_t* __restrict__ ok) {
+    __shared__ uint32_t lds[48 * PAIR_BLOCK];
+    const size_t i = ((size_t)blockIdx.x * PAIR_BLOCK + threadIdx.x) >> 1;
+    if (i >= n) return;
+    if (!ok[i]) return;                                         // both lanes of the pair read the same byte
+    uint32_t mask = 0, abmask = 0;
+#pragma unroll
+    for (uint32_t p = 0; p < (uint32_t)G; p++) {
+        const uint32_t run = p < k ? ws.flags[i + p * n] : 0u;
+        if (run) { mask |= 1u << p; if (run == 1u) abmask |= 1u << p; }
+    }
+    const uint32_t par = threadIdx.x & 1u;
+    MRef P = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, (uint32_t)ws.cap, 16);
+    if (!mask) return;                                          // every pair is the identity: the F slot holds 1 (k_pairing_check, j = 0)
+    uint32_t* wl = lds + (threadIdx.x >> 6) * (48 * ZKV_BLOCK) + (threadIdx.x & 63u);
+    LRef fm = l_ref(wl);
+    SoaRef norm = {ws.norm, ws.cap, (uint32_t)i * 4u};
+    SoaRef bsrc = {ws.prep + 32 * ws.cap, ws.cap, (uint32_t)(8 * par * ws.cap + i) * 4u};
+    SoaRW tq = {ws.fe, ws.cap, (uint32_t)(8 * par * ws.cap + i) * 4u};
+    const uint32_t fine = miller_loop_pg<G>(mask, abmask, norm, bsrc, tq, (uint32_t)n * 4u, fm);
+    if ((fine & mask) != mask) { if (!par) ok[i] = 0; return; }       // a G2 point outside the subgroup
+    f12m_copy(P, fm);
 }
 __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_miller(size_t n, Workspace ws, uint8_t* __restrict__ ok) {
     __shared__ uint32_t lds[(48 + 24) * ZKV_BLOCK];
@@ -157,12 +187,21 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_finalexp(size_t n, Wor
     }
     if (!par) result[i] = res;
 }
+// Pairs per call the one-loop kernel is built for (0: that many pairs take one loop each)
+uint32_t pairing_group(uint32_t k) { return k < 2 ? 0u : k <= 2 ? 2u : k <= 4 ? 4u : k <= 8 ? 8u : 0u; }
 void launch_pairing(size_t n, uint32_t k, const uint8_t* in, const Workspace& ws, uint8_t* result, uint8_t* ok, hipStream_t s) {
     if (!n) return;
     const unsigned grid = (unsigned)((2 * n + ZKV_BLOCK - 1) / ZKV_BLOCK);
     if (k == 0) (void)hipMemsetAsync(ok, 1, n, s);              // the empty product: valid input, result 1 (its F slot is set below)
-    for (uint32_t j = 0; j < k; j++) {
-        hipLaunchKernelGGL(k_pairing_check, dim3(grid), dim3(ZKV_BLOCK), 0, s, n, k, j, in, ws, ok);
+    const uint32_t g = pairing_group(k);
+    if (g && (size_t)k * n <= ws.cap) {                         // all pairs of a call resident: one Miller loop per call
+        for (uint32_t j = 0; j < k; j++) hipLaunchKernelGGL(k_pairing_check, dim3(grid), dim3(ZKV_BLOCK), 0, s, n, k, j, (size_t)j * n, in, ws, ok);
+        const dim3 hg((unsigned)((2 * n + PAIR_BLOCK - 1) / PAIR_BLOCK)), hb(PAIR_BLOCK);
+        if (g == 2) hipLaunchKernelGGL(k_pairing_miller_g<2>, hg, hb, 0, s, n, k, ws, ok);
+        else if (g == 4) hipLaunchKernelGGL(k_pairing_miller_g<4>, hg, hb, 0, s, n, k, ws, ok);
+        else hipLaunchKernelGGL(k_pairing_miller_g<8>, hg, hb, 0, s, n, k, ws, ok);
+    } else for (uint32_t j = 0; j < k; j++) {
+        hipLaunchKernelGGL(k_pairing_check, dim3(grid), dim3(ZKV_BLOCK), 0, s, n, k, j, (size_t)0, in, ws, ok);
         hipLaunchKernelGGL(k_pairing_miller, dim3(grid), dim3(ZKV_BLOCK), 0, s, n, ws, ok);
     }
     hipLaunchKernelGGL(k_pairing_finalexp, dim3(grid), dim3(ZKV_BLOCK), 0, s, n, ws, ok, result, k == 0 ? 1u : 0u);

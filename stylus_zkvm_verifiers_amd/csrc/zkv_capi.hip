@@ -1549,9 +1549,12 @@ static int run_precompile(zkv_ctx* c, int kind, size_t n, size_t k, const uint8_
     if (n && (!in || !out || !ok)) return ZKV_ERR_INVALID_ARG;
     if (!n) return ZKV_OK;
     std::lock_guard<std::mutex> lk(c->mu);
-    int rc = ctx_ready(c, n);
+    const bool resident = kind == 2 && pairing_group((uint32_t)k) && n > dual_below();
+    int rc = ctx_ready(c, resident ? n * k : n);
     if (rc != ZKV_OK) return rc;
-    const size_t in_sz = kind == 0 ? 128 : kind == 1 ? 96 : 192 * k, out_sz = kind == 2 ? 1 : 64, cap = c->ws.cap;
+    const size_t in_sz = kind == 0 ? 128 : kind == 1 ? 96 : 192 * k, out_sz = kind == 2 ? 1 : 64;
+    // ecPairing calls of 2 .. 8 pairs keep all their pairs resident (one Miller loop per call, launch_pairing): k workspace slots per call
+    const size_t cap = resident ? c->ws.cap / k : c->ws.cap;
     if ((rc = order_after_previous(c, c->stream)) != ZKV_OK) return rc;
     for (size_t base = 0; base < n; base += cap) {
         size_t m = n - base < cap ? n - base : cap;

@@ -142,6 +142,7 @@ void launch_agg_scatter(size_t n, const unsigned long long* counters, const uint
 void launch_ecadd(size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok, hipStream_t s);
 void launch_ecmul(size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok, hipStream_t s);
 void launch_pairing(size_t n, uint32_t k, const uint8_t* in, const Workspace& ws, uint8_t* result, uint8_t* ok, hipStream_t s);
+uint32_t pairing_group(uint32_t k);      // pairs per call of the one-loop kernel (k_pairing_miller_g), 0 = none: the workspace then needs k slots per call
 // the same for small batches of calls: one call per workgroup of two wavefronts (k_wide.hip)
 void launch_pairing_w(size_t n, uint32_t k, const uint8_t* in, const Workspace& ws, uint8_t* result, uint8_t* ok, hipStream_t s);
 
