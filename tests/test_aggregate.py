@@ -416,7 +416,7 @@ def test_aggregate_check_on_a_sharded_verifier(real_proofs, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_aggregate_check_engages_at_its_default_threshold(real_proofs):
+def test_aggregate_check_engages_at_its_default_threshold(real_proofs, monkeypatch):
     """No environment overrides: a 2^17-proof SP1 chunk takes the aggregate check with the default sub-batch (32) and group (4) sizes, a
     chunk one proof short of the threshold does not; statuses == the per-proof path == accept <=> not mutated on all 131,072 proofs."""
     import numpy as np
@@ -424,7 +424,7 @@ def test_aggregate_check_engages_at_its_default_threshold(real_proofs):
     import stylus_zkvm_verifiers_amd as zkv
     from stylus_zkvm_verifiers_amd import synth
     for k in ('ZKV_AGG_MIN', 'ZKV_AGG_GROUP', 'ZKV_CHUNK'):
-        assert k not in os.environ
+        monkeypatch.delenv(k, raising=False)
     dev = torch.device('cuda', 0)
     s = real_proofs['sp1']
     n = 1 << 17
