@@ -255,6 +255,9 @@ int zkv_bn254_ecmul_batch(zkv_ctx* ctx, size_t n, const uint8_t* in, uint8_t* ou
 /* in: n calls of k pairs each, k x 192 bytes per call (G1 x y, G2 x_im x_re y_im y_re); result[i] = 1 iff the product
  * of the k pairings is 1 (the precompile's 32-byte output word), meaningful when ok[i] = 1. */
 int zkv_bn254_pairing_batch(zkv_ctx* ctx, size_t n, size_t k, const uint8_t* in, uint8_t* result, uint8_t* ok);
+/* The same with calldata, results and verdicts resident in HBM (device pointers), enqueued on `stream` (a hipStream_t; NULL = the context's
+ * stream) without copies or synchronisation: zkv_ctx_synchronize or the stream tells when result / ok are written. */
+int zkv_bn254_pairing_batch_dev(zkv_ctx* ctx, size_t n, size_t k, const uint8_t* d_in, uint8_t* d_result, uint8_t* d_ok, void* stream);
 
 /* ------------------------------------------------------------------ Groth16 core, arbitrary verification key
  * Groth16Verifier::verify_proof_with_key(vm_type, &vk, a, b, c, &signals) -> bool (common/groth16.rs:23-49) is generic over the

@@ -55,6 +55,7 @@ SYMBOLS = {
     'zkv_bn254_ecadd_batch': (_i, [_vp, _sz, _vp, _vp, _vp]),
     'zkv_bn254_ecmul_batch': (_i, [_vp, _sz, _vp, _vp, _vp]),
     'zkv_bn254_pairing_batch': (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
+    'zkv_bn254_pairing_batch_dev': (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp]),
     'zkv_groth16_ctx_create': (_vp, [_cp, _sz, _i, _i]),
     'zkv_groth16_verify_batch': (_i, [_vp, _sz, _vp, _vp, _vp]),
     'zkv_ctx_vk_x_batch': (_i, [_vp, _sz, _vp, _vp]),

@@ -38,6 +38,13 @@ class Bn254Precompiles:
         out, ok = self._run(self._L.zkv_bn254_ecmul_batch, 'zkv_bn254_ecmul_batch', inputs, 96, 64)
         return [out[64 * i:64 * i + 64].tobytes() if ok[i] else None for i in range(len(inputs))]
 
+    def pairing_dev(self, n, k, d_in, d_result, d_ok, stream=0):
+        """n calls of k pairs resident in HBM (device pointers as ints): result / ok bytes are written by the kernels on `stream`."""
+        _lib.check(self._L.zkv_bn254_pairing_batch_dev(self._h, n, k, d_in, d_result, d_ok, stream or None), 'zkv_bn254_pairing_batch_dev')
+
+    def synchronize(self):
+        _lib.check(self._L.zkv_ctx_synchronize(self._h), 'zkv_ctx_synchronize')
+
     def pairing(self, inputs, k):
         """inputs: calls of k pairs (k*192 bytes each) -> list of True/False (None where the precompile fails)."""
         out, ok = self._run(self._L.zkv_bn254_pairing_batch, 'zkv_bn254_pairing_batch', inputs, 192 * k, 1, k)

@@ -1574,6 +1574,28 @@ static int run_precompile(zkv_ctx* c, int kind, size_t n, size_t k, const uint8_
 }
 ZKV_EXPORT int zkv_bn254_ecadd_batch(zkv_ctx* c, size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok) { return run_precompile(c, 0, n, 0, in, out, ok); }
 ZKV_EXPORT int zkv_bn254_ecmul_batch(zkv_ctx* c, size_t n, const uint8_t* in, uint8_t* out, uint8_t* ok) { return run_precompile(c, 1, n, 0, in, out, ok); }
+// The ecPairing seam with calldata, results and verdicts resident in HBM: enqueued on the caller's stream (or the context's), no copy,
+// no synchronisation.
+ZKV_EXPORT int zkv_bn254_pairing_batch_dev(zkv_ctx* c, size_t n, size_t k, const uint8_t* d_in, uint8_t* d_result, uint8_t* d_ok, void* stream) {
+    if (!c || c->vm != ZKV_VM_BN254) return ZKV_ERR_WRONG_CTX;
+    if (k > 64 || (n && (!d_result || !d_ok || (k && !d_in)))) return ZKV_ERR_INVALID_ARG;
+    if (!n) return ZKV_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const bool resident = pairing_group((uint32_t)k) && n > dual_below();
+    int rc = ctx_ready(c, resident ? n * k : n);
+    if (rc != ZKV_OK) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if ((rc = order_after_previous(c, s)) != ZKV_OK) return rc;
+    const size_t cap = resident ? c->ws.cap / k : c->ws.cap;
+    for (size_t base = 0; base < n; base += cap) {
+        const size_t m = n - base < cap ? n - base : cap;
+        const uint8_t* in = k ? d_in + base * 192 * k : d_in;
+        if (m <= dual_below()) launch_pairing_w(m, (uint32_t)k, in, c->ws, d_result + base, d_ok + base, s);
+        else launch_pairing(m, (uint32_t)k, in, c->ws, d_result + base, d_ok + base, s);
+        HIP_TRY(hipGetLastError());
+    }
+    return mark_done(c, s);
+}
 ZKV_EXPORT int zkv_bn254_pairing_batch(zkv_ctx* c, size_t n, size_t k, const uint8_t* in, uint8_t* result, uint8_t* ok) {
     if (k > 64) return ZKV_ERR_INVALID_ARG;
     uint8_t dummy = 0;

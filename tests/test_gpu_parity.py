@@ -161,6 +161,22 @@ def test_groth16_pairing_through_the_precompile_seam(zkv, real_proofs):
         batch = [bytes(bad), inf_g1, inf_g2, off_g2, data, data[:192] + data[:192] + data[384:]]
         assert pc.pairing(batch, 4) == [want(x) for x in batch], dual
     del os.environ['ZKV_DUAL_BELOW']
+    # calls of 1, 2, 3, 4 and 9 pairs cut from the same inputs (2 .. 8 pairs run ONE Miller loop per call, 1 and 9 one loop per pair), a batch
+    # large enough for the lane-pair kernels, host buffers and device-resident buffers: equal to the oracle
+    import torch
+    dev = torch.device('cuda', 0)
+    base = [bytes(bad), inf_g1, inf_g2, off_g2, data, data[:192] + data[:192] + data[384:], data[192:] + data[:192]]
+    for k in (4, 1, 2, 3, 9):
+        calls = [(x * 3)[:192 * k] for x in base] * 150          # 1,050 calls
+        exp = [want(x) for x in calls[:len(base)]] * 150
+        assert pc.pairing(calls, k) == exp, k
+        n = len(calls)
+        d_in = torch.from_numpy(np.frombuffer(b''.join(calls), dtype=np.uint8).copy()).to(dev)
+        d_res = torch.full((n,), 255, dtype=torch.uint8, device=dev); d_ok = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+        pc.pairing_dev(n, k, d_in.data_ptr(), d_res.data_ptr(), d_ok.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        res, ok = d_res.cpu().numpy(), d_ok.cpu().numpy()
+        assert [bool(res[i]) if ok[i] else None for i in range(n)] == exp, k
     pc.close()
 
 

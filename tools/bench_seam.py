@@ -44,6 +44,18 @@ def main():
                 t0 = time.perf_counter(); call(); best = min(best, time.perf_counter() - t0)
             out = {'calls': n, 'pairs_per_call': k, 'ms': round(best * 1e3, 3), 'calls_per_s': round(n / best), 'true_results': int(((out_b == 1) & (ok_b == 1)).sum()),
                    'invalid_inputs': int((ok_b == 0).sum())}
+            import torch
+            dev = torch.device('cuda', 0)
+            d_in = torch.from_numpy(blob).to(dev); d_res = torch.zeros(n, dtype=torch.uint8, device=dev); d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+            st = torch.cuda.current_stream().cuda_stream
+            dcall = lambda: z._lib.check(L.zkv_bn254_pairing_batch_dev(pc._h, n, k, d_in.data_ptr(), d_res.data_ptr(), d_ok.data_ptr(), st), 'zkv_bn254_pairing_batch_dev')
+            dcall(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5): dcall()
+            torch.cuda.synchronize()
+            dms = (time.perf_counter() - t0) * 1e3 / 5
+            out['device_resident_ms'] = round(dms, 3); out['device_resident_calls_per_s'] = round(n / dms * 1e3)
+            out['device_resident_equals_host'] = bool((d_res.cpu().numpy() == out_b).all() and (d_ok.cpu().numpy() == ok_b).all())
             print(json.dumps(out), flush=True)
 
 
