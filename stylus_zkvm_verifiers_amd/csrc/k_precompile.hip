@@ -3,6 +3,7 @@
 // EIP-196/197 semantics: every coordinate < Q, G1 on curve or (0,0), G2 on the twist AND in the order-r subgroup or
 // all-zero; any violation fails the call (ok = 0); pairs containing infinity contribute 1.  One call per lane.
 #include "zkv_internal.h"
+#include "zkv_plonk.h"      // glv_split / g1_mul_glv
 
 namespace zkv {
 
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_ecmul(size_t n, const uint8_t* __
     uint32_t k[8];
     load_be256(k, p + 64);                                   // any 256-bit scalar
     G1J acc = g1j_infinity();
-    if (good && !inf) acc = g1_mul_raw(x, y, k);
+    if (good && !inf) acc = g1_mul_glv(x, y, k);            // (round 3: 256 doublings and additions before)
     wr_g1(out + 64 * i, acc);
     ok[i] = good ? 1 : 0;
 }

@@ -293,6 +293,37 @@ ZKV_HD void glv_split(const uint32_t (&k)[8], uint32_t (&m1)[5], uint32_t& neg1,
     neg1 = glv_diff(k, t1, t2, 5, m1);                      // k - c1 a1 - c2 n   (low six words are enough)
     neg2 = glv_diff(u1, u2, nullptr, 0, m2);               // c1 n - c2 b2
 }
+// k P for ANY 256-bit k (the ecMul precompile, EIP-196: the group has order r, so k is reduced first): the two GLV halves walked jointly, one
+// bit of each per step, from the table {P1, P2, P1 + P2} with P1 = +-P, P2 = +-phi(P) carrying the halves' signs -- 131 doublings and
+// mixed additions instead of 256 (in a wavefront the addition of a one-bit-per-step loop is executed at every step anyway, so halving
+// the steps halves the work), plus one inversion for the affine P1 + P2.  P is affine and not infinity.
+ZKV_HD G1J g1_mul_glv(const Fp& x, const Fp& y, const uint32_t kraw[8]) {
+    const uint32_t M[8] = ZKV_FR_R_LIMBS;
+    uint32_t k[8];
+    for (int i = 0; i < 8; i++) k[i] = kraw[i];
+#pragma unroll 1
+    for (int t = 0; t < 5; t++) {                           // 2^256 < 6 r
+        uint32_t d[8], br = 0;
+        for (int i = 0; i < 8; i++) d[i] = subb(k[i], M[i], br);
+        if (!br) for (int i = 0; i < 8; i++) k[i] = d[i];
+    }
+    uint32_t m1[5], m2[5], n1, n2;
+    glv_split(k, m1, n1, m2, n2);
+    const Fp beta = ZKV_GLV_BETA;
+    const Fp y1 = n1 ? fp_neg(y) : y, x2 = fp_mul(x, beta), y2 = n2 ? fp_neg(y) : y;
+    G1J s; s.x = x; s.y = y1; s.z = fp_one();
+    s = g1j_add_affine(s, x2, y2);                          // phi(P) != +-P for P != O: a chord, never infinity
+    G1A p3; uint32_t inf3;
+    g1j_to_affine(s, p3, inf3);
+    G1J acc = g1j_infinity();
+#pragma unroll 1
+    for (int b = 130; b >= 0; b--) {
+        acc = g1j_dbl(acc);
+        const uint32_t d = ((m1[b >> 5] >> (b & 31)) & 1u) | (((m2[b >> 5] >> (b & 31)) & 1u) << 1);
+        if (d) acc = g1j_add_affine(acc, d == 1 ? x : d == 2 ? x2 : p3.x, d == 1 ? y1 : d == 2 ? y2 : p3.y);
+    }
+    return acc;
+}
 // 33 signed 4-bit digits of a magnitude below 2^131, packed 4 bits each as d + 8
 ZKV_HD void glv_digits(const uint32_t (&m)[5], uint32_t (&dig)[5]) {
     uint32_t carry = 0;

@@ -87,3 +87,10 @@ extern "C" int hsa_u(int vm, const uint8_t* cr, const uint8_t* cid, uint32_t sub
     for (uint32_t lane = 0; lane < sub; lane++) acc = g1j_add(acc, agg_u_share(*vt, *at, lane, sub, R, T));
     return affine_out(acc, out64);
 }
+
+// k P through the GLV walk of the ecMul kernel (g1_mul_glv) for any 256-bit k
+extern "C" int hsa_ecmul_glv(const uint8_t* xy64, const uint8_t* k32, uint8_t* out64) {
+    uint32_t x[8], y[8], k[8];
+    be_to_limbs(x, xy64); be_to_limbs(y, xy64 + 32); be_to_limbs(k, k32);
+    return affine_out(g1_mul_glv(fp_from_raw(x), fp_from_raw(y), k), out64);
+}

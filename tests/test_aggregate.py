@@ -181,6 +181,23 @@ def test_two_proofs_sharing_the_miller_accumulator(real_proofs, verify_corpus):
     assert run(0, 1, 3, 1) == (1, 3) and run(0, 1, 3, 0) == (1, 3)          # A at infinity: the point is stepped, no line products
 
 
+def test_ecmul_glv_walk_matches_the_spec_model_for_any_256_bit_scalar(hsa):
+    """g1_mul_glv (k_ecmul, the ecMul seam): scalars 0, 1, r - 1, r, r + 1, 2^256 - 1, multiples of r, values around 2^128 and lambda,
+    and random ones -- the EIP-196 answer is (k mod r) P."""
+    rng = random.Random(0xEC)
+    g = (1, 2)
+    pts = [g, m.g1_mul(g, 7), m.g1_mul(g, rng.randrange(m.R))]
+    ks = [0, 1, 2, m.R - 1, m.R, m.R + 1, 2 * m.R, 5 * m.R + 3, (1 << 256) - 1, (1 << 128) - 1, 1 << 128, (1 << 128) + 1, LAMBDA, LAMBDA + 1, m.R - LAMBDA,
+          (1 << 255), (1 << 254) + 12345] + [rng.randrange(1 << 256) for _ in range(40)] + [rng.randrange(1 << 64) for _ in range(5)]
+    for p in pts:
+        for k in ks:
+            o = C.create_string_buffer(64)
+            inf = hsa.hsa_ecmul_glv(_xy(p), m.be32(k), o)
+            want = m.g1_mul(p, k % m.R)
+            assert (inf == 1) == (want is None), hex(k)
+            if want is not None: assert _pt(o.raw) == want, hex(k)
+
+
 # ---------------------------------------------------------------------------------------------------------------- GPU
 H = bytes.fromhex
 

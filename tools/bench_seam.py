@@ -9,10 +9,31 @@ import spec_model as m
 H = bytes.fromhex
 
 
+def ecmul(pc, z, sizes):
+    rng = np.random.default_rng(0xEC)
+    pts = [m.g1_mul((1, 2), k) for k in (1, 5, 0x1234567)]
+    for lg in sizes:
+        n = 1 << lg
+        blob = np.zeros((n, 96), dtype=np.uint8)
+        for i in range(n):
+            p = pts[i % 3]
+            blob[i, :64] = np.frombuffer(m.be32(p[0]) + m.be32(p[1]), dtype=np.uint8)
+        blob[:, 64:] = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        out = np.zeros((n, 64), dtype=np.uint8); ok = np.zeros(n, dtype=np.uint8)
+        call = lambda: z._lib.check(pc._L.zkv_bn254_ecmul_batch(pc._h, n, blob.ctypes.data, out.ctypes.data, ok.ctypes.data), 'zkv_bn254_ecmul_batch')
+        call()
+        best = 1e9
+        for _ in range(5):
+            t0 = time.perf_counter(); call(); best = min(best, time.perf_counter() - t0)
+        chk = all(out[i].tobytes() == (lambda q: m.be32(q[0]) + m.be32(q[1]))(m.g1_mul(pts[i % 3], int.from_bytes(blob[i, 64:].tobytes(), 'big') % m.R)) for i in range(0, n, max(1, n // 50)))
+        print(json.dumps({'ecmul_calls': n, 'ms': round(best * 1e3, 3), 'calls_per_s': round(n / best), 'all_ok': bool(ok.all()), 'sample_equals_spec_model': bool(chk)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--log2', default='12,16')
     ap.add_argument('--pairs', default='4')
+    ap.add_argument('--ecmul', action='store_true', help='time zkv_bn254_ecmul_batch (random 256-bit scalars on a few points) instead')
     args = ap.parse_args()
     g = bench.golden()
     r = g['risc0']
@@ -21,6 +42,8 @@ def main():
     tail = (m.be32(vk['alpha1'][0]) + m.be32(vk['alpha1'][1]) + g2(vk['beta2']), H(r['vk_x'][0]) + H(r['vk_x'][1]) + g2(vk['gamma2']), g2(vk['delta2']))
     import stylus_zkvm_verifiers_amd as z
     pc = z.Bn254Precompiles()
+    if args.ecmul:
+        return ecmul(pc, z, [int(x) for x in args.log2.split(',')])
     for lg in [int(x) for x in args.log2.split(',')]:
         n = 1 << lg
         host = bench.synthesize('risc0', n, 0x5A4B5601, g, 64)          # every 64th proof mutated; flip-input ones stay valid here (vk_x is the real one)
