@@ -3,7 +3,7 @@
 // EIP-196/197 semantics: every coordinate < Q, G1 on curve or (0,0), G2 on the twist AND in the order-r subgroup or
 // all-zero; any violation fails the call (ok = 0); pairs containing infinity contribute 1.  One call per lane.
 #include "zkv_internal.h"
-#include "zkv_plonk.h"      // glv_split / g1_mul_glv
+#include "zkv_scalar.h"     // glv_split / g1_mul_glv
 
 namespace zkv {
 

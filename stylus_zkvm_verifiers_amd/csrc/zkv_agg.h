@@ -20,7 +20,7 @@
 #pragma once
 #include "zkv_verify.h"
 #if !defined(ZKV_PAIRED)
-#include "zkv_plonk.h"      // the scalar field Fr
+#include "zkv_scalar.h"     // the scalar field Fr
 #endif
 
 namespace zkv {

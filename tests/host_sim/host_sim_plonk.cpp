@@ -54,7 +54,7 @@ void hsp_fr_mulmod(const uint8_t* a, const uint8_t* b, uint8_t* out) {
     fr_to_raw(r, fr_mul(fr_from_raw_reduce(x), fr_from_raw_reduce(y)));
     wr_be(out, r);
 }
-// GLV split of a canonical scalar (zkv_plonk.h glv_split): out = |k1| (5 words), sign, |k2| (5 words), sign, little-endian words
+// GLV split of a canonical scalar (zkv_scalar.h glv_split): out = |k1| (5 words), sign, |k2| (5 words), sign, little-endian words
 void hsp_glv_split(const uint8_t* k32, uint32_t* out12) {
     uint32_t k[8], m1[5], m2[5], n1, n2;
     host::be_to_limbs(k, k32);
