@@ -221,21 +221,27 @@ def broadcast_context(blob, device, src=0):
     return broadcast_bytes(blob, int(n.item()), device, src=src)
 
 
-def make_verifier(blob, device_index=0):
-    """The verifier a context blob describes, bound to HIP device `device_index` (the same object on every rank)."""
+def make_verifier(blob, device_index=0, aggregate_sub_batch=0):
+    """The verifier a context blob describes, bound to HIP device `device_index` (the same object on every rank).  aggregate_sub_batch =
+    16 / 32 / 64 switches the opt-in aggregate check on (include/zkv.h): every rank draws its OWN secret from its operating system -- the
+    coefficients are never part of the broadcast blob."""
     from . import Groth16Verifier, MixedVerifier, RiscZeroVerifier, Sp1PlonkVerifier, Sp1Verifier
     c = unpack_context(blob)
     if c['kind'] == CTX_RISC0:
-        v = RiscZeroVerifier(device_index); v.initialize(c['control_root'], c['bn254_control_id']); return v
-    if c['kind'] == CTX_SP1:
-        return Sp1Verifier(device_index)
-    if c['kind'] == CTX_MIXED:
-        return MixedVerifier(c['control_root'], c['bn254_control_id'], device_index)
-    if c['kind'] == CTX_GROTH16:
-        return Groth16Verifier(c['vk'], c['n_ic'], c['vm_type'], device_index)
-    if c['kind'] == CTX_PLONK:
-        return Sp1PlonkVerifier(c['vk'], c['verifier_hash'], device_index)
-    raise ValueError('unknown context kind %d' % c['kind'])
+        v = RiscZeroVerifier(device_index); v.initialize(c['control_root'], c['bn254_control_id'])
+    elif c['kind'] == CTX_SP1:
+        v = Sp1Verifier(device_index)
+    elif c['kind'] == CTX_MIXED:
+        v = MixedVerifier(c['control_root'], c['bn254_control_id'], device_index)
+    elif c['kind'] == CTX_GROTH16:
+        v = Groth16Verifier(c['vk'], c['n_ic'], c['vm_type'], device_index)
+    elif c['kind'] == CTX_PLONK:
+        v = Sp1PlonkVerifier(c['vk'], c['verifier_hash'], device_index)
+    else:
+        raise ValueError('unknown context kind %d' % c['kind'])
+    if aggregate_sub_batch:
+        v.set_aggregate_check(True, seed=None, sub_batch=aggregate_sub_batch)
+    return v
 
 
 # ---------------------------------------------------------------- one sharded pass: broadcast context, scatter rows in pieces, verify, gather
