@@ -163,6 +163,12 @@ def test_hot_kernels_keep_their_resources(z):
         assert int(r['Occupancy [waves/SIMD]']) >= 2 and int(r['AGPRs']) == 0, (name, r)
         if 'w64d' in name:
             assert int(r['ScratchSize [bytes/lane]']) == 0 and int(r['LDS Size [bytes/block]']) <= 20480, (name, r)
+    # the shared-accumulator Miller kernels (aggregate check, ecPairing seam): the running points live in HBM rows so that LDS holds f only
+    shared = {k: v for k, v in rep.items() if 'k_agg_miller' in k or 'k_pairing_miller_g' in k}
+    assert len(shared) >= 6, sorted(shared)
+    for name, r in shared.items():
+        assert int(r['ScratchSize [bytes/lane]']) == 0 and int(r['VGPRs Spill']) == 0 and int(r['AGPRs']) == 0, (name, r)
+        assert int(r['Occupancy [waves/SIMD]']) >= 2 and int(r['LDS Size [bytes/block]']) <= 12288, (name, r)
 
 
 def test_chunk_capacity_is_clamped(z):
