@@ -304,9 +304,9 @@ int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_* */
 int zkv_ctx_set_lanes_per_proof(zkv_ctx* ctx, int lanes);
 /* Aggregate check (no reference counterpart; off by default).  The reference answers one proof per call with one pairing check
  * (common/groth16.rs:60-72, 109-128).  A batch may share that check: with enable != 0, chunks of at least ZKV_AGG_MIN proofs
- * (environment, default 131072) are checked in sub-batches of 32 proofs (enable = 1 or 32; enable = 16 or 64 selects smaller or
- * larger sub-batches: more shared checks but fewer proofs verified again when one fails, or the reverse) through ONE product of
- * pairings per sub-batch,
+ * (environment, default 131072) are checked in sub-batches of 32 proofs (enable = 1 or 32; enable = 16, 64, 128 or 256 selects
+ * smaller or larger sub-batches: more shared checks but fewer proofs verified again when one fails, or the reverse) through ONE
+ * product of pairings per sub-batch,
  *     prod_i e(r_i (-A_i), B_i) * e(sum_i r_i vk_x_i, gamma) * e(sum_i r_i C_i, delta) * e((sum_i r_i) alpha, beta) == 1,
  * with 128-bit coefficients r_i derived (SHA-256) from 32 secret bytes and a per-chunk counter.  Every check before the pairing
  * equation stays per proof and deterministic (seal format, selector, signal ranges, curve membership of A and C, curve and subgroup
@@ -321,7 +321,7 @@ int zkv_ctx_set_lanes_per_proof(zkv_ctx* ctx, int lanes);
  * (about 0.9 KB of HBM per proof in flight on top of the workspace's 3.7 KB) cannot be allocated -- zkv_ctx_aggregate_counters shows
  * whether chunks were checked in aggregate.  zkv_ctx_last_stage_ms then reports: [1] the per-proof G1 scalar multiplications, [3] the
  * Miller loops (variable pairs, sub-batch sums, pseudo-proofs), [4] everything after (pseudo-proofs' final exponentiation, second pass).
- * Throughput: see DESIGN.md (2^20 SP1 proofs: 11.4 M proofs/s all valid, 9.6 M with one proof in 64 rejected, against 5.7 M; a proof
+ * Throughput: see DESIGN.md (2^20 SP1 proofs: 12.0 M proofs/s all valid with sub-batches of 128, 9.6 M with one proof in 64 rejected and sub-batches of 16, against 5.7 M; a proof
  * rejected at the pairing costs its sub-batch a second, ordinary pass, and small chunks gain nothing). */
 int zkv_ctx_set_aggregate_check(zkv_ctx* ctx, int enable, const uint8_t* seed32);
 /* out[0] = sub-batches checked in aggregate, out[1] = those that failed and were verified proof by proof, since device set-up.

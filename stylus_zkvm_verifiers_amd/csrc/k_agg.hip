@@ -119,7 +119,7 @@ __device__ __forceinline__ Fr agg_ld_fr(const uint32_t* agg, size_t cap, int wor
 // number of ML(alpha, beta) factors to balance is the number of GROUPS with a proof in the check.  g = 1: sub consecutive lanes.
 __global__ __launch_bounds__(ZKV_BLOCK) void k_agg_reduce(size_t n, uint32_t sub, uint32_t sums, uint32_t g, const VkTables* __restrict__ vk, Workspace ws,
                                                           const uint32_t* __restrict__ agg, const AggTables* __restrict__ tab, Workspace ws2,
-                                                          uint8_t* __restrict__ status2) {
+                                                          uint8_t* __restrict__ status2, uint32_t park) {
     const size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     const uint32_t L = 64u / g, w = sub / g;
     const uint32_t dist = (63u & ~(L - 1u)) | (w - 1u);         // the exchange distances, one bit each: 32 ... L and w / 2 ... 1
@@ -171,6 +171,14 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_agg_reduce(size_t n, uint32_t sub
         for (int m = 32; m >= 1; m >>= 1) if (dist & (uint32_t)m) E = g1j_add(E, g1j_xor(E, m));
     }
     if (lane != 0) return;                                      // (a sub-batch past the end of the chunk has cnt = 0)
+    if (park) {                                                 // sub-batches of 128 / 256 proofs: the 64-proof sums wait (Jacobian) for k_agg_combine
+        uint32_t* row = ws2.fe;                                 // the pseudo-proofs' final-exponentiation scratch, unused until then
+        ws_st(row, ws2.cap, 0, sb, E.x); ws_st(row, ws2.cap, 8, sb, E.y); ws_st(row, ws2.cap, 16, sb, E.z);
+        ws_st(row, ws2.cap, 24, sb, U.x); ws_st(row, ws2.cap, 32, sb, U.y); ws_st(row, ws2.cap, 40, sb, U.z);
+        ws_st(row, ws2.cap, 48, sb, W.x); ws_st(row, ws2.cap, 56, sb, W.y); ws_st(row, ws2.cap, 64, sb, W.z);
+        row[(size_t)72 * ws2.cap + sb] = cnt;
+        return;
+    }
     ws2.g2bad[sb] = 0;
     if (cnt == 0) { ws2.flags[sb] = 0; status2[sb] = ST_OK; return; }       // nothing left to check in this sub-batch
     uint32_t flags = FL_ALIVE;
@@ -187,6 +195,53 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_agg_reduce(size_t n, uint32_t sub
     status2[sb] = ST_VERIFICATION_FAILED;
 }
 
+// Sub-batches of 128 / 256 proofs: the sums of `wide` = 2 / 4 consecutive 64-proof blocks (parked by k_agg_reduce) are added up by one lane
+// and become ONE pseudo-proof.  Every block's E carries a "- 1" for a pseudo-proof's ML(alpha, beta) of its own, but only one pseudo-proof
+// exists: the others' alpha are added back.
+__global__ __launch_bounds__(ZKV_BLOCK) void k_agg_combine(size_t n64, size_t n2, uint32_t wide, const AggTables* __restrict__ tab, Workspace ws2,
+                                                           uint8_t* __restrict__ status2) {
+    const size_t j = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
+    if (j >= n2) return;
+    const uint32_t* row = ws2.fe;
+    G1J E = g1j_infinity(), U = g1j_infinity(), W = g1j_infinity();
+    uint32_t cnt = 0, blocks = 0;
+#pragma unroll 1
+    for (uint32_t t = 0; t < wide; t++) {
+        const size_t sb = j * wide + t;
+        if (sb >= n64) break;
+        const uint32_t c = row[(size_t)72 * ws2.cap + sb];
+        if (!c) continue;
+        cnt += c; blocks++;
+        G1J p;
+        p.x = ws_ld(row, ws2.cap, 0, sb); p.y = ws_ld(row, ws2.cap, 8, sb); p.z = ws_ld(row, ws2.cap, 16, sb); E = g1j_add(E, p);
+        p.x = ws_ld(row, ws2.cap, 24, sb); p.y = ws_ld(row, ws2.cap, 32, sb); p.z = ws_ld(row, ws2.cap, 40, sb); U = g1j_add(U, p);
+        p.x = ws_ld(row, ws2.cap, 48, sb); p.y = ws_ld(row, ws2.cap, 56, sb); p.z = ws_ld(row, ws2.cap, 64, sb); W = g1j_add(W, p);
+    }
+    ws2.g2bad[j] = 0;
+    if (cnt == 0) { ws2.flags[j] = 0; status2[j] = ST_OK; return; }
+    if (tab && blocks > 1u) {
+        const uint32_t extra = blocks - 1u;                     // 1 .. 3
+        if (extra & 1u) { const G1A a = tab->alpha_pow[0]; E = g1j_add_affine(E, a.x, a.y); }
+        if (extra & 2u) { const G1A a = tab->alpha_pow[1]; E = g1j_add_affine(E, a.x, a.y); }
+    }
+    uint32_t flags = FL_ALIVE;
+    G1Norm o;
+    agg_normalize3(E, U, W, flags, o);
+    ws_st(ws2.norm, ws2.cap, 0, j, o.axs); ws_st(ws2.norm, ws2.cap, 8, j, o.ays);
+    ws_st(ws2.norm, ws2.cap, 16, j, o.lxs); ws_st(ws2.norm, ws2.cap, 24, j, o.lys);
+    ws_st(ws2.norm, ws2.cap, 32, j, o.cxs); ws_st(ws2.norm, ws2.cap, 40, j, o.cys);
+    if (tab) {
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) ws_st(ws2.prep, ws2.cap, 32 + 8 * k, j, tab->beta[k]);
+    } else flags |= FL_B_INF;
+    ws2.flags[j] = flags;
+    status2[j] = ST_VERIFICATION_FAILED;
+}
+void launch_agg_combine(size_t n64, size_t n2, uint32_t wide, const AggTables* tab, const Workspace& ws2, uint8_t* status2, hipStream_t s) {
+    if (!n2) return;
+    hipLaunchKernelGGL(k_agg_combine, dim3((unsigned)((n2 + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n64, n2, wide, tab, ws2, status2);
+}
+
 // Verdicts: a proof that was in a sub-batch whose check passed is accepted; one in a failed sub-batch is queued for the ordinary
 // kernels: its index goes into a dense list (slots reserved per wavefront with one atomic add -- the order does not matter), so that
 // those kernels run on full wavefronts spread over the whole chip however the failures are placed in the batch (with the proofs left
@@ -199,9 +254,9 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_agg_mark(size_t n, uint32_t sub, 
     const size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     bool again = false;
     if (i < n) {
-        const uint32_t L = 64u / g, w = sub / g;
-        const size_t sb = (size_t)blockIdx.x * (64u / sub) + (threadIdx.x & (L - 1u)) / w;      // as in k_agg_reduce
-        const bool first = threadIdx.x < L && (threadIdx.x & (w - 1u)) == 0;
+        const uint32_t L = 64u / g, w = (sub < 64u ? sub : 64u) / g;
+        const size_t sb = sub > 64u ? i / sub : (size_t)blockIdx.x * (64u / sub) + (threadIdx.x & (L - 1u)) / w;      // as in k_agg_reduce / k_agg_combine
+        const bool first = sub > 64u ? (i % sub) == 0 : (threadIdx.x < L && (threadIdx.x & (w - 1u)) == 0);
         const bool passed = status2[sb] == ST_OK;
         if (first) { atomicAdd(&counters[0], 1ull); if (!passed) atomicAdd(&counters[1], 1ull); }
         const uint32_t flags0 = agg[(size_t)AGG_W_FLAGS * ws.cap + i];
@@ -292,10 +347,10 @@ void launch_agg_g1(size_t n, const VkTables* d_tab, const InstTab* inst_tab, con
     hipLaunchKernelGGL(k_agg_g1, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, d_tab, inst_tab, ws, agg, seed, sums ? 1u : 0u);
 }
 void launch_agg_reduce(size_t n, uint32_t sub, bool sums, uint32_t g, const VkTables* d_tab, const Workspace& ws, const uint32_t* agg, const AggTables* tab,
-                       const Workspace& ws2, uint8_t* status2, hipStream_t s) {
+                       const Workspace& ws2, uint8_t* status2, bool park, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_agg_reduce, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, sub, sums ? 1u : 0u, g, d_tab, ws, agg,
-                       tab, ws2, status2);
+                       tab, ws2, status2, park ? 1u : 0u);
 }
 void launch_agg_mark(size_t n, uint32_t sub, uint32_t g, const Workspace& ws, const uint32_t* agg, const uint8_t* status2, uint8_t* status, unsigned long long* counters,
                      uint32_t* idx, hipStream_t s) {

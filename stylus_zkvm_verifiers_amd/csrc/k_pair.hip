@@ -273,19 +273,23 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_agg_fprod(size_t n, size_t n2,
     LRef acc = l_ref(lds + threadIdx.x);
     MRef P2 = m_ref(ws2.f + (size_t)(8 * par) * ws2.cap + sb, (uint32_t)ws2.cap, 16);
     f12m_copy(acc, P2);
-    const uint32_t per = 64u / sub, L = 64u / g, w = sub / g;   // sub-batches per block, groups per block, groups per sub-batch
-    const size_t i0 = (sb / per) * 64 + (sb % per) * w;
+    // sub <= 64: sub / g consecutive groups of one 64-proof block; sub = 128, 256: all 64 / g groups of 2 / 4 consecutive blocks
+    const uint32_t L = 64u / g, w = (sub < 64u ? sub : 64u) / g, nblk = sub > 64u ? sub / 64u : 1u, per = sub > 64u ? 1u : 64u / sub;
 #pragma unroll 1
-    for (uint32_t k = 0; k < w; k++) {
-        bool in = false;                                        // both lanes of the pair read the same words
+    for (uint32_t b = 0; b < nblk; b++) {
+        const size_t i0 = sub > 64u ? sb * sub + (size_t)b * 64 : (sb / per) * 64 + (sb % per) * w;
 #pragma unroll 1
-        for (uint32_t p = 0; p < g && !in; p++) {
-            const size_t i = i0 + k + p * L;
-            if (i < n) in = (agg[(size_t)AGG_W_FLAGS * ws.cap + i] & FL_ALIVE) && !ws.g2bad[i];
+        for (uint32_t k = 0; k < w; k++) {
+            bool in = false;                                    // both lanes of the pair read the same words
+#pragma unroll 1
+            for (uint32_t p = 0; p < g && !in; p++) {
+                const size_t i = i0 + k + p * L;
+                if (i < n) in = (agg[(size_t)AGG_W_FLAGS * ws.cap + i] & FL_ALIVE) && !ws.g2bad[i];
+            }
+            if (!in) continue;
+            MRef Pi = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i0 + k, (uint32_t)ws.cap, 16);
+            f12m_mul(acc, acc, Pi);
         }
-        if (!in) continue;
-        MRef Pi = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i0 + k, (uint32_t)ws.cap, 16);
-        f12m_mul(acc, acc, Pi);
     }
     f12m_copy(P2, acc);
 }

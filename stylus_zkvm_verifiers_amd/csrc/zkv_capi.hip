@@ -70,7 +70,7 @@ struct zkv_ctx {
     // Aggregate check (zkv_agg.h, zkv_ctx_set_aggregate_check): key tables, per-proof rows, the pseudo-proofs' workspace (one per
     // sub-batch), their statuses and the counters {sub-batches checked, sub-batches failed}
     bool agg_on = false, agg_key_ok = false;
-    uint32_t agg_sub = 32;                                     // proofs per sub-batch: 16, 32 or 64
+    uint32_t agg_sub = 32;                                     // proofs per sub-batch: 16, 32, 64, 128 or 256
     AggTables* d_agg_tab = nullptr;
     uint32_t* d_agg = nullptr;
     Workspace ws2 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
@@ -413,10 +413,11 @@ static void launch_finalexp_by_size(size_t n, const Workspace& ws, uint8_t* stat
 // proofs of sub-batches that failed, gathered into a dense workspace (the launches cover the whole chunk -- the host does not know how
 // many there are -- and wavefronts past the end of the list leave at once).
 static void enqueue_agg(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed) {
-    const uint32_t sub = c->agg_sub;
-    const size_t n2 = ((a.n + 63) / 64) * (64 / sub);         // sub-batches, the last 64-proof block counted in full (empty ones switch themselves off)
+    const uint32_t sub = c->agg_sub, sub64 = sub < 64 ? sub : 64;        // sub-batches of 128 / 256 proofs are summed per 64-proof block first
+    const size_t n64 = (a.n + 63) / 64;
+    const size_t n2 = sub > 64 ? (a.n + sub - 1) / sub : n64 * (64 / sub);      // the last block counted in full (empty sub-batches switch themselves off)
     // proofs per Miller accumulator: ZKV_AGG_GROUP = 1 (k_miller2), 2, 4 or 8 (k_agg_miller); at most the sub-batch's eighth... see agg_group()
-    const uint32_t grp = agg_group(sub);
+    const uint32_t grp = agg_group(sub64);
     const InstTab* inst = a.inst ? c->d_inst : nullptr;
     c->agg_seed.call++;                                       // fresh coefficients for every chunk
     // vk_x through summed scalars: one key (no per-proof base) and at most two per-proof signals
@@ -425,7 +426,8 @@ static void enqueue_agg(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed
     if (timed) { (void)hipEventRecord(c->ev[2], s); (void)hipEventRecord(c->ev[3], s); }
     if (grp > 1) launch_agg_miller(a.n, grp, c->d_tab, c->ws, a.status, s);
     else launch_miller2(a.n, c->d_tab, c->ws, a.status, s);
-    launch_agg_reduce(a.n, sub, sums, grp, c->d_tab, c->ws, c->d_agg, c->d_agg_tab, c->ws2, c->d_status2, s);
+    launch_agg_reduce(a.n, sub64, sums, grp, c->d_tab, c->ws, c->d_agg, c->d_agg_tab, c->ws2, c->d_status2, sub > 64, s);
+    if (sub > 64) launch_agg_combine(n64, n2, sub / 64, c->d_agg_tab, c->ws2, c->d_status2, s);
     launch_miller_by_size(c, n2, c->ws2, c->d_status2, s);
     if (timed) (void)hipEventRecord(c->ev[4], s);
     launch_agg_fprod(a.n, n2, sub, grp, c->ws, c->d_agg, c->ws2, s);
@@ -441,12 +443,14 @@ static void enqueue_agg(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed
 
 // The aggregate check of a PLONK chunk, after the unchanged PREP stage (k_agg_plonk_g1 explains why there is no per-proof Miller loop).
 static void enqueue_agg_plonk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed) {
-    const uint32_t sub = c->agg_sub;
-    const size_t n2 = ((a.n + 63) / 64) * (64 / sub);
+    const uint32_t sub = c->agg_sub, sub64 = sub < 64 ? sub : 64;
+    const size_t n64 = (a.n + 63) / 64;
+    const size_t n2 = sub > 64 ? (a.n + sub - 1) / sub : n64 * (64 / sub);
     c->agg_seed.call++;
     launch_agg_plonk_g1(a.n, c->ws, c->d_agg, c->agg_seed, s);
     if (timed) { (void)hipEventRecord(c->ev[2], s); (void)hipEventRecord(c->ev[3], s); }
-    launch_agg_reduce(a.n, sub, false, 1, c->d_tab, c->ws, c->d_agg, nullptr, c->ws2, c->d_status2, s);
+    launch_agg_reduce(a.n, sub64, false, 1, c->d_tab, c->ws, c->d_agg, nullptr, c->ws2, c->d_status2, sub > 64, s);
+    if (sub > 64) launch_agg_combine(n64, n2, sub / 64, nullptr, c->ws2, c->d_status2, s);
     launch_miller_by_size(c, n2, c->ws2, c->d_status2, s);
     if (timed) (void)hipEventRecord(c->ev[4], s);
     launch_finalexp_by_size(n2, c->ws2, c->d_status2, s);
@@ -1732,7 +1736,7 @@ ZKV_EXPORT int zkv_ctx_set_lanes_per_proof(zkv_ctx* c, int lanes) {
 }
 // Aggregate check on / off (zkv_agg.h).  seed32 = nullptr draws the 32 secret bytes from the operating system.
 ZKV_EXPORT int zkv_ctx_set_aggregate_check(zkv_ctx* c, int enable, const uint8_t* seed32) {
-    if (!c || (enable != 0 && enable != 1 && enable != 16 && enable != 32 && enable != 64)) return ZKV_ERR_INVALID_ARG;
+    if (!c || (enable != 0 && enable != 1 && enable != 16 && enable != 32 && enable != 64 && enable != 128 && enable != 256)) return ZKV_ERR_INVALID_ARG;
     uint8_t seed[32];
     if (enable) {
         if (seed32) memcpy(seed, seed32, 32);

@@ -126,7 +126,8 @@ struct AggTables; struct AggSeed;
 void launch_setup_agg(const VkRaw* d_raw, const VkTables* d_tab, AggTables* d_agg, hipStream_t s);
 void launch_agg_g1(size_t n, const VkTables* d_tab, const InstTab* inst_tab, const Workspace& ws, uint32_t* agg, const AggSeed& seed, bool sums, hipStream_t s);
 void launch_agg_reduce(size_t n, uint32_t sub, bool sums, uint32_t g, const VkTables* d_tab, const Workspace& ws, const uint32_t* agg, const AggTables* tab,
-                       const Workspace& ws2, uint8_t* status2, hipStream_t s);
+                       const Workspace& ws2, uint8_t* status2, bool park, hipStream_t s);
+void launch_agg_combine(size_t n64, size_t n2, uint32_t wide, const AggTables* tab, const Workspace& ws2, uint8_t* status2, hipStream_t s);
 void launch_agg_miller(size_t n, uint32_t g, const VkTables* d_tab, const Workspace& ws, uint8_t* status, hipStream_t s);
 void launch_agg_fprod(size_t n, size_t n2, uint32_t sub, uint32_t g, const Workspace& ws, const uint32_t* agg, const Workspace& ws2, hipStream_t s);
 void launch_agg_mark(size_t n, uint32_t sub, uint32_t g, const Workspace& ws, const uint32_t* agg, const uint8_t* status2, uint8_t* status, unsigned long long* counters,

@@ -216,6 +216,7 @@ def _risc0_inputs(real_proofs, n, seed, mutate_every, classes=None):
 def _sub_batches(n, sub, g=4):
     """Sub-batches counted for a chunk of n proofs.  g proofs share a Miller accumulator (default 4; members l, l + 64/g, ... of a 64-proof
     block): a sub-batch is sub / g consecutive proofs of the block's first 64 / g and their partners; g = 1: `sub` consecutive proofs."""
+    if sub > 64: return (n + sub - 1) // sub                     # 2 or 4 whole 64-proof blocks
     full, rem = divmod(n, 64)
     return full * (64 // sub) + (min(rem, 64 // g) + sub // g - 1) // (sub // g)
 
@@ -249,7 +250,7 @@ def test_aggregate_check_gives_the_deterministic_statuses(real_proofs, monkeypat
     total = 0
     for g in (4, 1, 2, 8):
         monkeypatch.setenv('ZKV_AGG_GROUP', str(g))
-        for sub in (16, 32, 64):
+        for sub in (16, 32, 64, 128, 256):
             v.set_aggregate_check(True, seed=bytes(range(32)), sub_batch=sub)
             agg = _run_risc0_dev(v, seals, ids, jds)
             checked, failed = v.aggregate_counters()
@@ -284,17 +285,21 @@ def test_aggregate_check_all_valid_and_only_early_rejects(real_proofs, monkeypat
     seals, ids, jds, mut, _ = _risc0_inputs(real_proofs, n, 0x5A4B56A2, 0)
     st = _run_risc0_dev(v, seals, ids, jds)
     assert (st == 0).all() and v.aggregate_counters() == (32, 0)
+    v.set_aggregate_check(True, seed=b'\x08' * 32, sub_batch=256)
+    st = _run_risc0_dev(v, seals, ids, jds)
+    assert (st == 0).all() and v.aggregate_counters() == (32 + 8, 0)
+    v.set_aggregate_check(True, seed=b'\x07' * 32, sub_batch=64)
     early = tuple(c for c in synth.MUTATION_CLASSES if c != 'flip_input')
     seals, ids, jds, mut, _ = _risc0_inputs(real_proofs, n, 0x5A4B56A3, 5, classes=early)
     st = _run_risc0_dev(v, seals, ids, jds)
     assert ((st == 0) == ~mut).all() and mut.sum() > 300
-    assert v.aggregate_counters() == (64, 0)
+    assert v.aggregate_counters() == (64 + 8, 0)
     # one wrong public input in the whole batch: exactly one sub-batch is verified again, and only that proof is rejected
     seals, ids, jds, mut, _ = _risc0_inputs(real_proofs, n, 0x5A4B56A4, 0)
     jds[777, 3] ^= 0x10
     st = _run_risc0_dev(v, seals, ids, jds)
     assert st[777] == 1 and (st == 0).sum() == n - 1
-    assert v.aggregate_counters() == (96, 1)
+    assert v.aggregate_counters() == (96 + 8, 1)
     v.close()
 
 
@@ -488,9 +493,9 @@ def test_aggregate_check_on_the_golden_corpus(real_proofs, verify_corpus, monkey
     st, rv1 = sp.verify_batch(*a1); assert [int(x) for x in st] == want1
     for g in (4, 1, 2, 8):
         monkeypatch.setenv('ZKV_AGG_GROUP', str(g))
-        for sub in (16, 32, 64):
-            v.set_aggregate_check(True, seed=bytes([sub + g]) * 32, sub_batch=sub)
-            sp.set_aggregate_check(True, seed=bytes([sub + g + 1]) * 32, sub_batch=sub)
+        for sub in (16, 32, 64, 128, 256):
+            v.set_aggregate_check(True, seed=bytes([sub % 251 + g]) * 32, sub_batch=sub)
+            sp.set_aggregate_check(True, seed=bytes([sub % 251 + g + 1]) * 32, sub_batch=sub)
             st, rv_ = v.verify_batch(*a0)
             assert [int(x) for x in st] == want0 and (np.asarray(rv_) == np.asarray(rv)).all(), (g, sub)
             st, rv_ = sp.verify_batch(*a1)

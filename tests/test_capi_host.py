@@ -220,10 +220,10 @@ def test_aggregate_check_switch_host_side(z, real_proofs):
     sp = z.Sp1Verifier()
     mx = z.MixedVerifier(H(r['control_root']), H(r['bn254_control_id']))
     for ctx in (v, sp, mx):
-        for en in (1, 16, 32, 64, 0):
+        for en in (1, 16, 32, 64, 128, 256, 0):
             assert L.zkv_ctx_set_aggregate_check(ctx._h, en, None) == 0
             assert L.zkv_ctx_set_aggregate_check(ctx._h, en, bytes(32)) == 0
-        for en in (2, 8, 48, 128, -1):
+        for en in (2, 8, 48, 512, -1):
             assert L.zkv_ctx_set_aggregate_check(ctx._h, en, None) != 0
         assert ctx.aggregate_counters() == (0, 0)
     assert L.zkv_ctx_set_aggregate_check(None, 1, None) != 0

@@ -358,14 +358,15 @@ def test_plonk_aggregate_check_gives_the_per_proof_statuses(zkv, pool, monkeypat
     ost, _ = ol.sp1_plonk_verify_batch(vk, vh, [x.tobytes() for x in V[:256]], [x.tobytes() for x in W[:256]], [x.tobytes() for x in P[:256]], threads=8)
     assert (st0[:256] == ost).all() and ((st0 == 0) == ~mut).all()
     total = 0
-    for sub in (16, 32, 64):
+    for sub in (16, 32, 64, 128, 256):
         v.set_aggregate_check(True, seed=bytes(range(32)), sub_batch=sub)
         st1, rv1 = run(P, V, W)
         assert (st1 == st0).all() and (rv1 == rv0).all(), sub
         checked, failed = v.aggregate_counters()
-        total += (n // 64) * (64 // sub) + (n % 64 + sub - 1) // sub
+        total += (n + sub - 1) // sub if sub > 64 else (n // 64) * (64 // sub) + (n % 64 + sub - 1) // sub
         assert checked == total and 0 < failed <= checked
     P, V, W, mut, _ = _pool_batch(pool, 1024, 0x5A4B56AD, 0)
+    v.set_aggregate_check(True, seed=bytes(range(32)), sub_batch=64)
     c0 = v.aggregate_counters()
     st, _ = run(P, V, W)
     assert (st == 0).all() and v.aggregate_counters() == (c0[0] + 16, c0[1])
