@@ -55,7 +55,7 @@ def main():
         v.set_aggregate_check(False)
         plain = run()
         os.environ['ZKV_AGG_GROUP'] = str(rng.choice((1, 2, 4, 8)))
-        v.set_aggregate_check(True, seed=rng.randbytes(32) if rng.random() < 0.5 else None, sub_batch=rng.choice((16, 32, 64)))
+        v.set_aggregate_check(True, seed=rng.randbytes(32) if rng.random() < 0.5 else None, sub_batch=rng.choice((16, 32, 64, 128, 256)))
         c0 = v.aggregate_counters()
         agg = run()
         c1 = v.aggregate_counters()

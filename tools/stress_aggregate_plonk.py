@@ -41,7 +41,7 @@ def main():
             return st.cpu().numpy()
         v.set_aggregate_check(False)
         plain = run()
-        v.set_aggregate_check(True, seed=rng.randbytes(32) if rng.random() < 0.5 else None, sub_batch=rng.choice((16, 32, 64)))
+        v.set_aggregate_check(True, seed=rng.randbytes(32) if rng.random() < 0.5 else None, sub_batch=rng.choice((16, 32, 64, 128, 256)))
         c0 = v.aggregate_counters(); agg = run(); c1 = v.aggregate_counters()
         bad = int((agg != plain).sum()) + int(((plain == 0) != ~mut).sum())
         stats['batches'] += 1; stats['proofs'] += n; stats['damaged'] += int(mut.sum()); stats['sub_batches_failed'] += c1[1] - c0[1]; stats['mismatches'] += bad
