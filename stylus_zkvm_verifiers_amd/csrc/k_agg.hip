@@ -96,7 +96,7 @@ __device__ __forceinline__ G1J g1j_xor(const G1J& p, int mask) {
     }
     return r;
 }
-// One wavefront per 64 proofs = 64 / sub sub-batches (sub = 16, 32 or 64).  Lane l holds proof 64 blockIdx + l: its U, W and coefficient
+// One wavefront per 64 proofs = 64 / sub sub-batches (sub = 16, 32 or 64; larger sub-batches are parked per block for k_agg_combine).  Lane l holds proof 64 blockIdx + l: its U, W and coefficient
 // words if the proof is still in the check (alive after PREP, B in the subgroup), nothing otherwise.  Butterflies inside each group of `sub`
 // lanes give every lane its sub-batch's sums; E = (S1 - cnt - 1) alpha + S2 phi(alpha) comes from the lanes' table look-ups (bits lane,
 // lane + sub, ... of S1 and S2) and a third butterfly -- every proof's Miller value and the pseudo-proof's carry one factor

@@ -1,7 +1,7 @@
 // Aggregate check of a sub-batch of Groth16 proofs (opt-in: zkv_ctx_set_aggregate_check).
 //
 // The reference verifies one proof per call: e(-A, B) e(alpha, beta) e(vk_x, gamma) e(C, delta) == 1 (common/groth16.rs:60-72,
-// 109-128).  A batch service may instead check a sub-batch of 16, 32 or 64 proofs with ONE final exponentiation: for coefficients r_i unknown to
+// 109-128).  A batch service may instead check a sub-batch of 16 ... 256 proofs with ONE final exponentiation: for coefficients r_i unknown to
 // whoever produced the proofs,
 //     prod_i e(r_i (-A_i), B_i)  *  e(sum_i r_i vk_x_i, gamma)  *  e(sum_i r_i C_i, delta)  *  e((sum_i r_i) alpha, beta)  ==  1
 // holds when every proof of the sub-batch verifies, and with probability 2^-128 over the coefficients otherwise.  Everything before

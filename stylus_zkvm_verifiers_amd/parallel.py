@@ -223,7 +223,7 @@ def broadcast_context(blob, device, src=0):
 
 def make_verifier(blob, device_index=0, aggregate_sub_batch=0):
     """The verifier a context blob describes, bound to HIP device `device_index` (the same object on every rank).  aggregate_sub_batch =
-    16 / 32 / 64 switches the opt-in aggregate check on (include/zkv.h): every rank draws its OWN secret from its operating system -- the
+    16 / 32 / 64 / 128 / 256 switches the opt-in aggregate check on (include/zkv.h): every rank draws its OWN secret from its operating system -- the
     coefficients are never part of the broadcast blob."""
     from . import Groth16Verifier, MixedVerifier, RiscZeroVerifier, Sp1PlonkVerifier, Sp1Verifier
     c = unpack_context(blob)
