@@ -304,9 +304,10 @@ int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_* */
 int zkv_ctx_set_lanes_per_proof(zkv_ctx* ctx, int lanes);
 /* Aggregate check (no reference counterpart; off by default).  The reference answers one proof per call with one pairing check
  * (common/groth16.rs:60-72, 109-128).  A batch may share that check: with enable != 0, chunks of at least ZKV_AGG_MIN proofs
- * (environment, default 131072) are checked in sub-batches of 32 proofs (enable = 1 or 32; enable = 16, 64, 128 or 256 selects
- * smaller or larger sub-batches: more shared checks but fewer proofs verified again when one fails, or the reverse) through ONE
- * product of pairings per sub-batch,
+ * (environment, default 131072) are checked in sub-batches of 16, 32, 64, 128 or 256 proofs (enable = that size: small sub-batches
+ * mean more shared checks but fewer proofs verified again when one fails; enable = 1: automatic -- 32 at first, then, whenever the
+ * context is idle at the start of a chunk, the size that suits the failure rate the counters show) through ONE product of
+ * pairings per sub-batch,
  *     prod_i e(r_i (-A_i), B_i) * e(sum_i r_i vk_x_i, gamma) * e(sum_i r_i C_i, delta) * e((sum_i r_i) alpha, beta) == 1,
  * with 128-bit coefficients r_i derived (SHA-256) from 32 secret bytes and a per-chunk counter.  Every check before the pairing
  * equation stays per proof and deterministic (seal format, selector, signal ranges, curve membership of A and C, curve and subgroup

@@ -53,7 +53,7 @@ class Groth16Verifier:
         _lib.check(self._L.zkv_groth16_verify_batch(self._h, n, pb, sb, out.ctypes.data), 'zkv_groth16_verify_batch')
         return out[:n].astype(bool)
 
-    def set_aggregate_check(self, enable=True, seed=None, sub_batch=32):
+    def set_aggregate_check(self, enable=True, seed=None, sub_batch=None):
         """Opt-in: share the pairing check among sub-batches of a large chunk (include/zkv.h); the answers stay the deterministic ones."""
         _set_aggregate_check(self._L, self._h, enable, seed, sub_batch)
 

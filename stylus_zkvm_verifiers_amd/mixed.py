@@ -55,8 +55,8 @@ class MixedVerifier:
     def reserve(self, n):
         _lib.check(self._L.zkv_ctx_reserve(self._h, n), 'zkv_ctx_reserve')
 
-    def set_aggregate_check(self, enable=True, seed=None, sub_batch=32):
-        """Opt-in: share the pairing check among sub-batches of 32 (or 16, 64, 128, 256) proofs of a large chunk (include/zkv.h, csrc/zkv_agg.h);
+    def set_aggregate_check(self, enable=True, seed=None, sub_batch=None):
+        """Opt-in: share the pairing check among sub-batches of 16 ... 256 proofs (None: chosen by the failure rate seen) of a large chunk (include/zkv.h, csrc/zkv_agg.h);
         statuses stay the deterministic ones (a failed sub-batch is verified again proof by proof)."""
         _set_aggregate_check(self._L, self._h, enable, seed, sub_batch)
 

@@ -32,10 +32,12 @@ def _same_len(n, **lists):
             raise ValueError('%s has %d entries for a batch of %d proofs' % (name, len(v), n))
 
 
-def _set_aggregate_check(L, h, enable, seed, sub_batch=32):
-    """zkv_ctx_set_aggregate_check: seed = None draws the secret from the operating system; 32 bytes make a run reproducible."""
+def _set_aggregate_check(L, h, enable, seed, sub_batch=None):
+    """zkv_ctx_set_aggregate_check: seed = None draws the secret from the operating system; 32 bytes make a run reproducible.
+    sub_batch = None: automatic (32 proofs at first, then what suits the failure rate seen); 16 ... 256: fixed."""
     if seed is not None and len(seed) != 32: raise ValueError('seed must be 32 bytes')
-    _lib.check(L.zkv_ctx_set_aggregate_check(h, int(sub_batch) if enable else 0, bytes(seed) if seed is not None else None), 'zkv_ctx_set_aggregate_check')
+    _lib.check(L.zkv_ctx_set_aggregate_check(h, (1 if sub_batch is None else int(sub_batch)) if enable else 0, bytes(seed) if seed is not None else None),
+               'zkv_ctx_set_aggregate_check')
 
 
 def _aggregate_counters(L, h):
@@ -149,8 +151,8 @@ class RiscZeroVerifier:
         """Device set-up and per-chunk buffers for batches of up to n proofs, ahead of the first batch (optional)."""
         _lib.check(self._L.zkv_ctx_reserve(self._h, n), 'zkv_ctx_reserve')
 
-    def set_aggregate_check(self, enable=True, seed=None, sub_batch=32):
-        """Opt-in: share the pairing check among sub-batches of 32 (or 16, 64, 128, 256) proofs of a large chunk (include/zkv.h, csrc/zkv_agg.h);
+    def set_aggregate_check(self, enable=True, seed=None, sub_batch=None):
+        """Opt-in: share the pairing check among sub-batches of 16 ... 256 proofs (None: chosen by the failure rate seen) of a large chunk (include/zkv.h, csrc/zkv_agg.h);
         statuses stay the deterministic ones (a failed sub-batch is verified again proof by proof)."""
         _set_aggregate_check(self._L, self._h, enable, seed, sub_batch)
 
@@ -218,8 +220,8 @@ class RiscZeroVerifierSet:
         _lib.check(self._L.zkv_risc0_set_vk_x_batch(self._h, n, idx.ctypes.data, blob, out.ctypes.data), 'zkv_risc0_set_vk_x_batch')
         return [out[64 * i:64 * i + 64].tobytes() for i in range(n)]
 
-    def set_aggregate_check(self, enable=True, seed=None, sub_batch=32):
-        """Opt-in: share the pairing check among sub-batches of 32 (or 16, 64, 128, 256) proofs of a large chunk (include/zkv.h, csrc/zkv_agg.h);
+    def set_aggregate_check(self, enable=True, seed=None, sub_batch=None):
+        """Opt-in: share the pairing check among sub-batches of 16 ... 256 proofs (None: chosen by the failure rate seen) of a large chunk (include/zkv.h, csrc/zkv_agg.h);
         statuses stay the deterministic ones (a failed sub-batch is verified again proof by proof)."""
         _set_aggregate_check(self._L, self._h, enable, seed, sub_batch)
 

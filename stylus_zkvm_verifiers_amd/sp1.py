@@ -74,8 +74,8 @@ class Sp1Verifier:
         """Device set-up and per-chunk buffers for batches of up to n proofs, ahead of the first batch (optional)."""
         _lib.check(self._L.zkv_ctx_reserve(self._h, n), 'zkv_ctx_reserve')
 
-    def set_aggregate_check(self, enable=True, seed=None, sub_batch=32):
-        """Opt-in: share the pairing check among sub-batches of 32 (or 16, 64, 128, 256) proofs of a large chunk (include/zkv.h, csrc/zkv_agg.h);
+    def set_aggregate_check(self, enable=True, seed=None, sub_batch=None):
+        """Opt-in: share the pairing check among sub-batches of 16 ... 256 proofs (None: chosen by the failure rate seen) of a large chunk (include/zkv.h, csrc/zkv_agg.h);
         statuses stay the deterministic ones (a failed sub-batch is verified again proof by proof)."""
         _set_aggregate_check(self._L, self._h, enable, seed, sub_batch)
 
@@ -147,7 +147,7 @@ class Sp1PlonkVerifier:
     def reserve(self, n):
         _lib.check(self._L.zkv_ctx_reserve(self._h, n), 'zkv_ctx_reserve')
 
-    def set_aggregate_check(self, enable=True, seed=None, sub_batch=32):
+    def set_aggregate_check(self, enable=True, seed=None, sub_batch=None):
         """Opt-in (include/zkv.h): sub-batches share the two-pair check -- e(sum r D, [1]_2) e(sum r (-Q), [tau]_2) -- so no per-proof Miller
         loop or final exponentiation is left; statuses stay the per-proof ones (failed sub-batches are checked again proof by proof)."""
         _set_aggregate_check(self._L, self._h, enable, seed, sub_batch)

@@ -502,3 +502,28 @@ def test_aggregate_check_on_the_golden_corpus(real_proofs, verify_corpus, monkey
             assert [int(x) for x in st] == want1 and (np.asarray(rv_) == np.asarray(rv1)).all(), (g, sub)
     assert v.aggregate_counters()[0] > 0 and sp.aggregate_counters()[0] > 0
     v.close(); sp.close()
+
+
+@pytest.mark.gpu
+def test_automatic_sub_batch_size_follows_the_failure_rate(real_proofs, monkeypatch):
+    """enable = 1: sub-batches of 32 at first; once the context is idle at the start of a call the counters decide -- one proof in 10 failing
+    at the pairing brings 16, a run of valid batches 128.  Statuses stay the per-proof ones throughout."""
+    import stylus_zkvm_verifiers_amd as zkv
+    monkeypatch.setenv('ZKV_AGG_MIN', '64')
+    monkeypatch.setenv('ZKV_AGG_GROUP', '1')                     # contiguous sub-batches: the counts below are then n / sub exactly
+    r = real_proofs['risc0']
+    v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    v.set_aggregate_check(True)                                  # sub_batch = None: automatic
+    n = 16384
+    seals, ids, jds, mut, _ = _risc0_inputs(real_proofs, n, 0x5A4B56B1, 10, classes=('flip_input',))
+    def run(s_, i_, j_):
+        before = v.aggregate_counters()[0]
+        st = _run_risc0_dev(v, s_, i_, j_)
+        v.synchronize()
+        return st, v.aggregate_counters()[0] - before
+    st, k = run(seals, ids, jds); assert ((st == 0) == ~mut).all() and k == n // 32
+    st, k = run(seals, ids, jds); assert ((st == 0) == ~mut).all() and k == n // 16
+    seals, ids, jds, mut, _ = _risc0_inputs(real_proofs, n, 0x5A4B56B2, 0)
+    st, k = run(seals, ids, jds); assert (st == 0).all() and k == n // 16          # decided on what the last call showed
+    st, k = run(seals, ids, jds); assert (st == 0).all() and k == n // 128
+    v.close()
