@@ -419,8 +419,9 @@ static void launch_finalexp_by_size(size_t n, const Workspace& ws, uint8_t* stat
 // Measured (2^20 SP1 proofs): no failures 128 best (87 ms; 91.5 at 64), one proof in 320 failing 16 best (109 ms; 133 at 64).
 static void agg_adapt(zkv_ctx* c) {
     if (!c->agg_auto || !c->has_done || !c->d_agg_cnt || hipEventQuery(c->ev_done) != hipSuccess) { (void)hipGetLastError(); return; }
-    unsigned long long v[2];                                   // (on the context's own copy stream: never waits for the caller's streams)
-    if (hipMemcpyAsync(v, c->d_agg_cnt, sizeof v, hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess || hipStreamSynchronize(c->copy_stream) != hipSuccess) {
+    unsigned long long v[2];                                   // (on the context's side stream, idle here: waits neither for the caller's streams nor for the
+                                                               // host pipeline's segment copies on copy_stream)
+    if (hipMemcpyAsync(v, c->d_agg_cnt, sizeof v, hipMemcpyDeviceToHost, c->side) != hipSuccess || hipStreamSynchronize(c->side) != hipSuccess) {
         (void)hipGetLastError();
         return;
     }
