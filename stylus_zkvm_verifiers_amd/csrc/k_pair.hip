@@ -58,19 +58,18 @@ __global__ __launch_bounds__(PAIR_BLOCK, 2) void k_miller2(size_t n, const VkTab
 }
 
 __global__ __launch_bounds__(PAIR_BLOCK, 2) void k_finalexp2(size_t n, Workspace ws, uint8_t* __restrict__ status) {
-    __shared__ uint32_t lds[48 * PAIR_BLOCK];
+    __shared__ uint32_t lds[54 * PAIR_BLOCK];             // the accumulator in resident 29-bit limbs: 6 coefficients x 9 words per lane
     size_t i = ((size_t)blockIdx.x * PAIR_BLOCK + threadIdx.x) >> 1;
     if (i >= n) return;
     uint32_t flags = ws.flags[i];
     if (!(flags & FL_ALIVE) || ws.g2bad[i]) return;
     const uint32_t par = threadIdx.x & 1u;
     const uint32_t st = (uint32_t)ws.cap;
-    uint32_t* wl = lds + (threadIdx.x >> 6) * (48 * ZKV_BLOCK) + (threadIdx.x & 63u);
-    LRef acc = l_ref(wl);
+    uint32_t* wl = lds + (threadIdx.x >> 6) * (54 * ZKV_BLOCK) + (threadIdx.x & 63u);
+    L9Ref acc = l9_ref(wl);
     MRef F = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, st, 16);
     MRef E = m_ref(ws.fe + (size_t)(8 * par) * ws.cap + i, st, 16);
-    MRef accm = m_ref(wl, 64, 8);                         // the accumulator's LDS words through a flat pointer, for the rare generic operations
-    bool one = final_exp_prog_p(F, E, acc, accm);
+    bool one = final_exp_prog_p(F, E, acc);
     if (!par) status[i] = one ? ST_OK : ST_VERIFICATION_FAILED;
 }
 
@@ -172,18 +171,17 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_miller(size_t n, Works
 }
 __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_finalexp(size_t n, Workspace ws, const uint8_t* __restrict__ ok, uint8_t* __restrict__ result,
                                                                    uint32_t empty) {
-    __shared__ uint32_t lds[48 * ZKV_BLOCK];
+    __shared__ uint32_t lds[54 * ZKV_BLOCK];
     size_t i = ((size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x) >> 1;
     if (i >= n) return;
     const uint32_t par = threadIdx.x & 1u;
     uint8_t res = empty ? 1 : 0;                                 // k = 0: the empty product is 1
     if (ok[i] && !empty) {
         const uint32_t st = (uint32_t)ws.cap;
-        LRef acc = l_ref(lds + threadIdx.x);
+        L9Ref acc = l9_ref(lds + threadIdx.x);
         MRef P = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, st, 16);
         MRef E = m_ref(ws.fe + (size_t)(8 * par) * ws.cap + i, st, 16);
-        MRef accm = m_ref(lds + threadIdx.x, 64, 8);
-        res = final_exp_prog_p(P, E, acc, accm) ? 1 : 0;
+        res = final_exp_prog_p(P, E, acc) ? 1 : 0;
     }
     if (!par) result[i] = res;
 }

@@ -34,6 +34,14 @@ static thread_local unsigned long long zkv_mad_counter = 0;         // 32 x 32 +
 #define ZKV_TABLE static const
 #endif
 
+// Region marks for tools/asm_hist.py (-DZKV_ASM_MARKS builds of the assembly listing only: comments in the instruction stream,
+// so that the ISA histogram of a kernel can be split by Fp12-level body).
+#if defined(ZKV_ASM_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+#define ZKV_MARK(name) asm volatile("; ZKVMARK " name)
+#else
+#define ZKV_MARK(name) ((void)0)
+#endif
+
 #include "zkv_modinv.h"
 
 namespace zkv {
@@ -194,8 +202,9 @@ ZKV_HD void fp_mac81(COL col[18], const uint32_t x[9], const uint32_t y[9]) {   
 }
 // Montgomery reduction of an 18-column value V >= 0 (V = sum col[k] 2^(29k)): returns V * 2^-261 mod p in the loose range:
 // the result is < V / 2^261 + p, which is < 2p because every caller keeps V < p * 2^261 (about 169 p^2; operands are < 4p).
+// The reduction proper: nine 29-bit limbs of V * 2^-261 (limbs 0..7 below 2^29, limb 8 the rest), not yet packed.
 template <typename COL>                          // int64_t: signed columns (arithmetic carries); uint64_t: all terms >= 0
-ZKV_HD Fp fp_reduce_cols(COL col[18]) {
+ZKV_HD void fp_reduce_cols_limbs(COL col[18], uint32_t (&r)[9]) {
     ZKV_COUNT_MADS(81);
     const uint32_t P29[9] = ZKV_FP_P29_LIMBS;
     const uint32_t M29 = 0x1fffffffu;
@@ -206,16 +215,17 @@ ZKV_HD Fp fp_reduce_cols(COL col[18]) {
         for (int j = 0; j < 9; j++) col[i + j] = (COL)((uint64_t)col[i + j] + (uint64_t)m * P29[j]);
         col[i + 1] += col[i] >> 29;               // low 29 bits of col[i] are now zero; arithmetic shift when signed
     }
-    uint32_t r[9];
 #pragma unroll
     for (int k = 9; k < 17; k++) {
         r[k - 9] = (uint32_t)col[k] & M29;
         col[k + 1] += col[k] >> 29;
     }
     r[8] = (uint32_t)col[17];
+}
+ZKV_HD Fp fp_pack29(const uint32_t (&r)[9]) {    // 9 x 29 -> 8 x 32 (limbs 0..7 below 2^29, value below 2^256)
     Fp o;
 #pragma unroll
-    for (int w = 0; w < 8; w++) {                 // pack 9 x 29 -> 8 x 32 (the value is < 2p < 2^255)
+    for (int w = 0; w < 8; w++) {
         const int bit = 32 * w, k = bit / 29, s = bit - 29 * k, got = 29 - s;
         uint32_t v = r[k] >> s;
         if (k + 1 < 9) v |= r[k + 1] << got;
@@ -223,6 +233,12 @@ ZKV_HD Fp fp_reduce_cols(COL col[18]) {
         o.v[w] = v;
     }
     return o;
+}
+template <typename COL>
+ZKV_HD Fp fp_reduce_cols(COL col[18]) {
+    uint32_t r[9];
+    fp_reduce_cols_limbs(col, r);
+    return fp_pack29(r);                          // the value is < 2p < 2^255
 }
 #if defined(ZKV_FP_MUL_NOINLINE)
 ZKV_HD_NI
@@ -556,6 +572,84 @@ ZKV_HD Fp f2_mul_limbs(const uint32_t (&ao)[9], const uint32_t (&ap)[9], const u
     for (int k = 0; k < 18; k++) col[k] = 0;
     fp_mac81(col, ao, bU); fp_mac81(col, ap, bV);
     return fp_reduce_cols(col);
+}
+// ---------------------------------------------------------------- resident 29-bit limbs (L9), lane-pair kernels
+// The accumulator of the final exponentiation stays UNPACKED between Fp12 operations: a value is nine 29-bit limbs in nine words
+// (limbs 0..7 below 2^29, value below 2p), which is what the column multiplier consumes and produces.  That removes the unpack /
+// pack around every product (54 of the 160 non-multiply instructions of a lane product) and, more importantly, the carry chains: on
+// gfx950 every v_addc / v_subb needs a wait state after the instruction that wrote VCC (the ISA listing of the packed cyclotomic
+// squaring holds 808 carry instructions and 704 s_nop), whereas limb-wise sums have no carries at all.  Linear combinations of
+// several values -- Karatsuba's differences, 3t +- 2z of the cyclotomic squaring, the xi-multiplication 9x -+ x' -- are formed in
+// ONE pass per result (l9_lincomb): per limb one 32 x 32 + 64 multiply-add per term with a small constant, one more with the
+// quotient estimate times p, and a carry step; the result is normalised and below 1.01 p.
+struct L9 { uint32_t l[9]; };
+struct L9X { uint32_t own[9], par[9]; };          // multiplicand form: this lane's limbs and the partner's
+struct L9Y { uint32_t U[9], V[9]; };              // multiplier form: the even lane's limbs in both lanes; the odd lane's (8p - them in the even lane)
+ZKV_HD L9 l9_from_fp(const Fp& a) { L9 r; fp_unpack29(a, r.l); return r; }
+ZKV_HD Fp l9_to_fp(const L9& a) { return fp_pack29(a.l); }      // normalised limbs, value < 2^256
+ZKV_HD L9 l9_partner(const L9& a) {
+    L9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = zkv_partner_u32(a.l[i]);
+    return r;
+}
+ZKV_HD void l9_x(const L9& a, L9X& x) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) { x.own[i] = a.l[i]; x.par[i] = zkv_partner_u32(a.l[i]); }
+}
+// b: normalised limbs (below 2^29), value below 8p
+ZKV_HD void l9_y(const L9& b, L9Y& y) {
+    const uint32_t FAT[9] = ZKV_FP_FAT8P_LIMBS;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { y.U[i] = zkv_pair_even_u32(b.l[i]); y.V[i] = zkv_pair_odd_u32(b.l[i]); }
+    if (zkv_parity() == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) y.V[i] = FAT[i] - y.V[i];
+    }
+}
+// (a0 + a1 u)(b0 + b1 u), this lane's component: what f2_mul_lane computes, on prepared operands and without the pack.  The limbs of
+// the multiplicand may be lazy sums below 2^30, the multiplier's are normalised (a column then holds at most 9 (2 + 4) + 9 = 63 units
+// of 2^58); values: a0 b0 + a1 b1 below 169 p^2.
+ZKV_HD L9 l9_mul(const L9X& a, const L9Y& b) {
+#if defined(ZKV_COUNT_FP_MUL)
+    zkv_fp_mul_counter += 2;
+#endif
+    uint64_t col[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) col[k] = 0;
+    fp_mac81(col, a.own, b.U); fp_mac81(col, a.par, b.V);
+    L9 r; fp_reduce_cols_limbs(col, r.l);
+    return r;
+}
+// sum over j of k_j x_j  (mod p), normalised and below 1.01 p.  x_j: nine signed 32-bit limbs each (normalised values, or lazy limb-wise
+// sums / differences of a few of them: |limb| < 2^31); k_j: small integers, possibly different in the two lanes of a pair.
+// c: any integer >= 1 + sum over the terms that can be negative of |k_j| * (bound of x_j in units of p): it keeps the quotient
+// estimate non-negative.  Let D = floor(p / 2^232) + 1.  The sum X satisfies (T - G) 2^232 < X < (T + G) 2^232 for T = sum k_j x_j[8]
+// (every x_j is its top limb times 2^232 plus a lower part below rho_j 2^232, and G = 256 exceeds sum |k_j| rho_j + c by construction), so
+// with q = floor((T + c D - c - G) / D) - c:  0 <= X - q p < p + (2 G + c + q + 2) 2^232 < 1.01 p.  The division is one v_mul_hi: with
+// M = ceil(2^53 / D) the product (t M) >> 53 equals floor(t / D) for every t < 2^31 (the excess t / 2^53 stays below 1 / D).
+struct LTerm { const uint32_t* x; int32_t k; };
+#define ZKV_L9_G 256
+template <int N> ZKV_HD L9 l9_lincomb(const LTerm (&t)[N], const int c) {
+    const uint32_t P29[9] = ZKV_FP_P29_LIMBS;
+    const int32_t D = (int32_t)P29[8] + 1;
+    const uint32_t M = (uint32_t)(((1ull << 53) + (uint64_t)D - 1) / (uint64_t)D);
+    int32_t top = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) top += t[j].k * (int32_t)t[j].x[8];
+    const uint32_t tt = (uint32_t)(top + c * D - c - ZKV_L9_G);
+    const int32_t nq = c - (int32_t)(uint32_t)(((uint64_t)tt * M) >> 53);          // -q
+    L9 y; int64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        int64_t s = carry;
+#pragma unroll
+        for (int j = 0; j < N; j++) s += (int64_t)t[j].k * (int64_t)(int32_t)t[j].x[i];
+        s += (int64_t)nq * (int64_t)(int32_t)P29[i];
+        if (i < 8) { y.l[i] = (uint32_t)s & 0x1fffffffu; carry = s >> 29; }
+        else y.l[i] = (uint32_t)s;
+    }
+    return y;
 }
 ZKV_HD Fp2 f2_sqr(const Fp2& a) {           // reduced (< 2p) input: even lane (a0+a1)(a0-a1), odd lane (2 a1) a0
     const bool odd = zkv_parity() != 0;

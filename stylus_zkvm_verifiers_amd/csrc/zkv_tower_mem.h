@@ -119,6 +119,94 @@ template <class RF> ZKV_HD void f12m_cyclo_sqr_body(RF f) {
     m_st_f2(f, 3, z2); m_st_f2(f, 2, z3); m_st_f2(f, 1, z4); m_st_f2(f, 5, z5);
 }
 template <class RF> ZKV_HD_NI void f12m_cyclo_sqr(RF f) { f12m_cyclo_sqr_body(f); }
+#if defined(ZKV_PAIRED)
+// ---------------------------------------------------------------- the accumulator in resident 29-bit limbs (zkv_field.h, L9)
+// L9Ref: lane-interleaved LDS slot of six Fp2 coefficients, nine words each: limb k of coefficient idx at p[(9 idx + k) * 64].
+// Through m_ld_fp / m_st_fp (which pack / unpack) the slot also serves the generic Fp12 routines above and below.
+struct L9Ref {
+    zkv_lds_u32* p;
+    ZKV_HD int fw() const { return 8; }
+};
+ZKV_HD L9Ref l9_ref(uint32_t* lds_base_plus_lane) { L9Ref r; r.p = (zkv_lds_u32*)lds_base_plus_lane; return r; }
+ZKV_HD L9 l9_ld(L9Ref m, int idx) {
+    L9 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.l[k] = m.p[(9 * idx + k) * 64];
+    return r;
+}
+ZKV_HD void l9_st(L9Ref m, int idx, const L9& a) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) m.p[(9 * idx + k) * 64] = a.l[k];
+}
+ZKV_HD Fp m_ld_fp(L9Ref m, int word0) { return l9_to_fp(l9_ld(m, word0 >> 3)); }
+ZKV_HD void m_st_fp(L9Ref m, int word0, const Fp& a) { l9_st(m, word0 >> 3, l9_from_fp(a)); }
+
+// (t0, t1) = (a + b y)^2 with y^2 = xi (Granger-Scott's Fp4 squaring) and the cyclotomic update in one go:
+//   o0 = 3 t0 - 2 za,   o1 = 3 t1 + 2 zb   (xi_t1: o1 = 3 xi t1 + 2 zb),   t0 = a^2 + xi b^2 = (a + b)(a + xi b) - (1 + xi) a b,  t1 = 2 a b.
+// Two lane products (tmp = a b, S = (a + b)(a + xi b)) and three one-pass linear combinations: a + xi b for the multiplier of S,
+//   o0 = 3 S - 30 tmp -+ 3 tmp' - 2 za  (1 + xi = 10 + u: the even lane needs -(10 tmp.re - tmp.im), the odd lane -(10 tmp.im + tmp.re)),
+//   o1 = 6 tmp + 2 zb, or 54 tmp -+ 6 tmp' + 2 zb.
+// All inputs normalised and below 2p.
+ZKV_HD void l9_fp4_sqr_update(const L9& a, const L9& b, const L9& za, const L9& zb, const bool xi_t1, L9& o0, L9& o1) {
+    const bool odd = zkv_parity() != 0;
+    L9X ax; L9Y by;
+    l9_x(a, ax); l9_y(b, by);
+    const L9 tmp = l9_mul(ax, by);
+    L9X s1;
+#pragma unroll
+    for (int i = 0; i < 9; i++) s1.own[i] = a.l[i] + b.l[i];                     // lazy limbs below 2^30: multiplicand only
+#pragma unroll
+    for (int i = 0; i < 9; i++) s1.par[i] = zkv_partner_u32(s1.own[i]);
+    L9 s2;
+    {
+        // this lane's component of a + xi b = mine(a) + 9 mine(b) -+ other(b): the even lane takes 8p - b1 (by.V), the odd lane b0 (by.U)
+        uint32_t ob[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) ob[i] = odd ? by.U[i] : by.V[i];
+        const LTerm t[3] = {{a.l, 1}, {b.l, 9}, {ob, 1}};
+        s2 = l9_lincomb(t, 1);
+    }
+    L9Y s2y; l9_y(s2, s2y);
+    const L9 S = l9_mul(s1, s2y);
+    const L9 tp = l9_partner(tmp);
+    const int32_t k3 = odd ? -3 : 3;
+    {
+        const LTerm t[4] = {{S.l, 3}, {tmp.l, -30}, {tp.l, k3}, {za.l, -2}};
+        o0 = l9_lincomb(t, 72);                                                    // 1 + (30 + 3 + 2) * 2
+    }
+    if (!xi_t1) {
+        const LTerm t[2] = {{tmp.l, 6}, {zb.l, 2}};
+        o1 = l9_lincomb(t, 1);
+    } else {
+        const LTerm t[3] = {{tmp.l, 54}, {tp.l, -2 * k3}, {zb.l, 2}};
+        o1 = l9_lincomb(t, 14);                                                    // 1 + 6 * 2
+    }
+}
+// f <- f^2 for f in the cyclotomic subgroup, accumulator in resident limbs.  Memory order g0 g1 g2 h0 h1 h2; pairs (g0,h1), (h0,g2), (g1,h2):
+//   g0' = 3 t0 - 2 g0, h1' = 3 t1 + 2 h1;   g1' = 3 t2 - 2 g1, h2' = 3 t3 + 2 h2 with (t2, t3) from (h0, g2);
+//   g2' = 3 t4 - 2 g2, h0' = 3 xi t5 + 2 h0 with (t4, t5) from (g1, h2).
+ZKV_HD void f12l9_cyclo_sqr(L9Ref f) {
+    {
+        const L9 a = l9_ld(f, 0), b = l9_ld(f, 4);
+        L9 o0, o1;
+        l9_fp4_sqr_update(a, b, a, b, false, o0, o1);
+        l9_st(f, 0, o0); l9_st(f, 4, o1);
+    }
+    L9 n1, n5;
+    {
+        const L9 a = l9_ld(f, 3), b = l9_ld(f, 2), za = l9_ld(f, 1), zb = l9_ld(f, 5);
+        l9_fp4_sqr_update(a, b, za, zb, false, n1, n5);
+    }
+    {
+        const L9 a = l9_ld(f, 1), b = l9_ld(f, 5), za = l9_ld(f, 2), zb = l9_ld(f, 3);
+        L9 o0, o1;
+        l9_fp4_sqr_update(a, b, za, zb, true, o0, o1);
+        l9_st(f, 2, o0); l9_st(f, 3, o1);
+    }
+    l9_st(f, 1, n1); l9_st(f, 5, n5);
+}
+#endif  // ZKV_PAIRED
+
 // d <- a * b, or a * conj(b) (conj(b) = b^-1 for b in the cyclotomic subgroup); d may alias a or b
 template <class RD, class RA, class RB> ZKV_HD void f12m_mul_body(RD d, RA a, RB b, bool conj_b) {
     Fp6 ag = m_ld_f6(a, 0), bg = m_ld_f6(b, 0);

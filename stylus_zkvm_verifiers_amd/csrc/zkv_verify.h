@@ -488,24 +488,29 @@ template <class RA> ZKV_HD bool final_exp_is_one_m(MRef F, MRef E, MRef Y1, MRef
 
 #if defined(ZKV_PAIRED)
 // The same final exponentiation for the lane-pair kernel as a PROGRAM of Fp12-level operations (ZKV_FE_PROG, generated from the chain
-// above by gen_constants.py, with x^u on the signed digit set {1, 17, 35}: 264 entries) run by one loop in which every operation body is inlined exactly once -- no Fp12-level calls,
-// hence no callee-saved-register frames (see miller_loop_p).  The two hot operations keep the typed-LDS accumulator: the cyclotomic
-// squaring of ACC (189 entries) and ACC <- ACC * S / ACC * conj(S) with S in an HBM slot (48 entries); everything else (32 entries)
-// goes through one generic body in which ACC is addressed through `accm`, a flat view of the same LDS words.
-// slots: 0 ACC, 1 F, 2.. = E, Y1, Y3, Y4, X17, X35, (free) (consecutive 96-word slots from E).
-ZKV_HD MRef fe_slot(int s, MRef accm, MRef F, MRef E) { return s == 0 ? accm : s == 1 ? F : m_off(E, 96 * (s - 2)); }
-template <class RA> ZKV_HD bool final_exp_prog_p(MRef F, MRef E, RA acc, MRef accm) {
+// above by gen_constants.py, with x^u on the signed digit set {1, 17, 35}) run by one loop in which every operation body is inlined
+// exactly once -- no Fp12-level calls, hence no callee-saved-register frames (see miller_loop_p).
+// The accumulator ACC lives in LDS in RESIDENT 29-BIT LIMBS (L9Ref; zkv_field.h "L9", zkv_tower_mem.h): the cyclotomic squaring of ACC
+// (189 entries) runs on limbs throughout; ACC <- ACC * S / ACC * conj(S) with S in an HBM slot (48 entries) reads and writes ACC through
+// the packing accessors; COPY to / from ACC and CONJ ACC likewise.  Every other entry works on the packed HBM slots only (the generator
+// routes the few that need ACC's value through the slot TMP), in one generic body.
+// slots: 0 ACC, 1 F, 2.. = E, Y1, Y3, Y4, X17, X35, TMP (consecutive 96-word slots from E).
+ZKV_HD MRef fe_slot(int s, MRef F, MRef E) { return s == 1 ? F : m_off(E, 96 * (s - 2)); }
+ZKV_HD bool final_exp_prog_p(MRef F, MRef E, L9Ref acc) {
     const uint32_t PROG[ZKV_FE_PROG_LEN] = ZKV_FE_PROG;
     bool one = false;
 #pragma unroll 1
     for (int pc = 0; pc < ZKV_FE_PROG_LEN; pc++) {
         const uint32_t e = PROG[pc];
         const int op = (int)(e & 255u), d = (int)((e >> 8) & 255u), a = (int)((e >> 16) & 255u), b = (int)(e >> 24);
-        if (op == 6) f12m_cyclo_sqr_body(acc);
-        else if ((op == 3 || op == 4) && d == 0 && a == 0 && b != 0) f12m_mul_body(acc, acc, fe_slot(b, accm, F, E), op == 4);
+        if (op == 6) { ZKV_MARK("begin cyclo"); f12l9_cyclo_sqr(acc); ZKV_MARK("end cyclo"); }
+        else if ((op == 3 || op == 4) && d == 0) { ZKV_MARK("begin accmul"); f12m_mul_body(acc, acc, fe_slot(b, F, E), op == 4); ZKV_MARK("end accmul"); }
+        else if (op == 0 && d == 0) f12m_copy(acc, fe_slot(a, F, E));
+        else if (op == 0 && a == 0) f12m_copy(fe_slot(d, F, E), acc);
+        else if (op == 1 && d == 0) f12m_conj(acc);
         else {
-            const MRef D = fe_slot(d, accm, F, E), A = fe_slot(a, accm, F, E);
-            if (op == 3 || op == 4) f12m_mul_body(D, A, fe_slot(b, accm, F, E), op == 4);
+            const MRef D = fe_slot(d, F, E), A = fe_slot(a, F, E);
+            if (op == 3 || op == 4) f12m_mul_body(D, A, fe_slot(b, F, E), op == 4);
             else if (op == 0) f12m_copy(D, A);
             else if (op == 1) f12m_conj(D);
             else if (op == 2) f12m_inv_body(D, A);

@@ -52,7 +52,8 @@ static void lane(Job* j, uint32_t par) {
     MRef F = m_ref(full + 8 * par, 1, 16), E = m_ref(full + 96 + 8 * par, 1, 16);
     f12m_mul(F, fm, ab);
     j->muls[par][1] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter; j->mads[par][1] = zkv_mad_counter - d0; d0 = zkv_mad_counter;
-    j->accept[par] = final_exp_prog_p(F, E, fm, fm) ? 1 : 0;          // the interpreted program k_finalexp2 runs
+    static thread_local uint32_t acc9[54 * 64];     // the accumulator in resident 29-bit limbs, laid out as one lane's column of the LDS slot
+    j->accept[par] = final_exp_prog_p(F, E, l9_ref(acc9)) ? 1 : 0;    // the interpreted program k_finalexp2 runs
     j->muls[par][2] = zkv_fp_mul_counter - c0; j->mads[par][2] = zkv_mad_counter - d0;
 }
 // Fp multiplications (a lane's Fp2 product counts 2, fp_mul 1) spent by BOTH lanes of the pair in g2chk, miller, finalexp
