@@ -64,12 +64,9 @@ __global__ __launch_bounds__(PAIR_BLOCK, 2) void k_finalexp2(size_t n, Workspace
     uint32_t flags = ws.flags[i];
     if (!(flags & FL_ALIVE) || ws.g2bad[i]) return;
     const uint32_t par = threadIdx.x & 1u;
-    const uint32_t st = (uint32_t)ws.cap;
     uint32_t* wl = lds + (threadIdx.x >> 6) * (54 * ZKV_BLOCK) + (threadIdx.x & 63u);
     L9Ref acc = l9_ref(wl);
-    MRef F = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, st, 16);
-    MRef E = m_ref(ws.fe + (size_t)(8 * par) * ws.cap + i, st, 16);
-    bool one = final_exp_prog_p(F, E, acc);
+    bool one = final_exp_prog_p(ws.f, ws.fe, ws.cap, (uint32_t)(8 * par * ws.cap + i) * 4u, acc);
     if (!par) status[i] = one ? ST_OK : ST_VERIFICATION_FAILED;
 }
 
@@ -177,11 +174,8 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_finalexp(size_t n, Wor
     const uint32_t par = threadIdx.x & 1u;
     uint8_t res = empty ? 1 : 0;                                 // k = 0: the empty product is 1
     if (ok[i] && !empty) {
-        const uint32_t st = (uint32_t)ws.cap;
         L9Ref acc = l9_ref(lds + threadIdx.x);
-        MRef P = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, st, 16);
-        MRef E = m_ref(ws.fe + (size_t)(8 * par) * ws.cap + i, st, 16);
-        res = final_exp_prog_p(P, E, acc) ? 1 : 0;
+        res = final_exp_prog_p(ws.f, ws.fe, ws.cap, (uint32_t)(8 * par * ws.cap + i) * 4u, acc) ? 1 : 0;
     }
     if (!par) result[i] = res;
 }

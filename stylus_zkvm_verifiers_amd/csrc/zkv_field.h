@@ -583,8 +583,6 @@ ZKV_HD Fp f2_mul_limbs(const uint32_t (&ao)[9], const uint32_t (&ap)[9], const u
 // ONE pass per result (l9_lincomb): per limb one 32 x 32 + 64 multiply-add per term with a small constant, one more with the
 // quotient estimate times p, and a carry step; the result is normalised and below 1.01 p.
 struct L9 { uint32_t l[9]; };
-struct L9X { uint32_t own[9], par[9]; };          // multiplicand form: this lane's limbs and the partner's
-struct L9Y { uint32_t U[9], V[9]; };              // multiplier form: the even lane's limbs in both lanes; the odd lane's (8p - them in the even lane)
 ZKV_HD L9 l9_from_fp(const Fp& a) { L9 r; fp_unpack29(a, r.l); return r; }
 ZKV_HD Fp l9_to_fp(const L9& a) { return fp_pack29(a.l); }      // normalised limbs, value < 2^256
 ZKV_HD L9 l9_partner(const L9& a) {
@@ -593,34 +591,47 @@ ZKV_HD L9 l9_partner(const L9& a) {
     for (int i = 0; i < 9; i++) r.l[i] = zkv_partner_u32(a.l[i]);
     return r;
 }
-ZKV_HD void l9_x(const L9& a, L9X& x) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) { x.own[i] = a.l[i]; x.par[i] = zkv_partner_u32(a.l[i]); }
-}
-// b: normalised limbs (below 2^29), value below 8p
-ZKV_HD void l9_y(const L9& b, L9Y& y) {
-    const uint32_t FAT[9] = ZKV_FP_FAT8P_LIMBS;
-#pragma unroll
-    for (int i = 0; i < 9; i++) { y.U[i] = zkv_pair_even_u32(b.l[i]); y.V[i] = zkv_pair_odd_u32(b.l[i]); }
-    if (zkv_parity() == 0) {
-#pragma unroll
-        for (int i = 0; i < 9; i++) y.V[i] = FAT[i] - y.V[i];
-    }
-}
-// (a0 + a1 u)(b0 + b1 u), this lane's component: what f2_mul_lane computes, on prepared operands and without the pack.  The limbs of
-// the multiplicand may be lazy sums below 2^30, the multiplier's are normalised (a column then holds at most 9 (2 + 4) + 9 = 63 units
-// of 2^58); values: a0 b0 + a1 b1 below 169 p^2.
-ZKV_HD L9 l9_mul(const L9X& a, const L9Y& b) {
+// (a0 + a1 u)(b0 + b1 u), this lane's component: what f2_mul_lane computes, on limbs and without the unpack / pack.  a, b: this lane's
+// components.  The multiplicand's limbs may be a lazy sum below 2^30; the multiplier's are normalised (below 2^29) with a value below 4p
+// (8p - b1 is formed limb-wise).  The limbs travel as in f2_mul_lane: a is swapped; of b both lanes take the even lane's b0 and the odd
+// lane's b1, which the even lane turns into 8p - b1.  A column holds at most 9 (2 + 4) + 9 = 63 units of 2^58; values: a0 b0 + a1 (8p - b1)
+// must stay below 169 p^2.
+ZKV_HD L9 l9_mul_core(const L9& a, const L9& b) {
 #if defined(ZKV_COUNT_FP_MUL)
     zkv_fp_mul_counter += 2;
 #endif
+    const uint32_t FAT[9] = ZKV_FP_FAT8P_LIMBS;
+    uint32_t xo[9], U[9], V[9];
     uint64_t col[18];
 #pragma unroll
     for (int k = 0; k < 18; k++) col[k] = 0;
-    fp_mac81(col, a.own, b.U); fp_mac81(col, a.par, b.V);
+#pragma unroll
+    for (int i = 0; i < 9; i++) U[i] = zkv_pair_even_u32(b.l[i]);
+    fp_mac81(col, a.l, U);
+#pragma unroll
+    for (int i = 0; i < 9; i++) { xo[i] = zkv_partner_u32(a.l[i]); V[i] = zkv_pair_odd_u32(b.l[i]); }
+    if (zkv_parity() == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) V[i] = FAT[i] - V[i];
+    }
+    fp_mac81(col, xo, V);
     L9 r; fp_reduce_cols_limbs(col, r.l);
     return r;
 }
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ZKV_FP_MUL_NOINLINE)
+// Non-inlined leaf with the 18 operand limbs as scalar parameters (v0..v17 in, v0..v8 out: no stack traffic at the call); the callers
+// are the inlined Fp12 bodies of the final exponentiation, which would otherwise hold 18 copies of the product.
+#define ZKV_L9P(p) uint32_t p##0, uint32_t p##1, uint32_t p##2, uint32_t p##3, uint32_t p##4, uint32_t p##5, uint32_t p##6, uint32_t p##7, uint32_t p##8
+#define ZKV_L9A(f) f.l[0], f.l[1], f.l[2], f.l[3], f.l[4], f.l[5], f.l[6], f.l[7], f.l[8]
+#define ZKV_L9MK(f, p) L9 f; f.l[0] = p##0; f.l[1] = p##1; f.l[2] = p##2; f.l[3] = p##3; f.l[4] = p##4; f.l[5] = p##5; f.l[6] = p##6; f.l[7] = p##7; f.l[8] = p##8
+__device__ __noinline__ inline L9 l9_mul_ni(ZKV_L9P(pa), ZKV_L9P(pb)) {
+    ZKV_L9MK(a, pa); ZKV_L9MK(b, pb);
+    return l9_mul_core(a, b);
+}
+ZKV_HD L9 l9_mul(const L9& a, const L9& b) { return l9_mul_ni(ZKV_L9A(a), ZKV_L9A(b)); }
+#else
+ZKV_HD L9 l9_mul(const L9& a, const L9& b) { return l9_mul_core(a, b); }
+#endif
 // sum over j of k_j x_j  (mod p), normalised and below 1.01 p.  x_j: nine signed 32-bit limbs each (normalised values, or lazy limb-wise
 // sums / differences of a few of them: |limb| < 2^31); k_j: small integers, possibly different in the two lanes of a pair.
 // c: any integer >= 1 + sum over the terms that can be negative of |k_j| * (bound of x_j in units of p): it keeps the quotient

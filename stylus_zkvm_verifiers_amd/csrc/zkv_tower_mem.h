@@ -24,6 +24,24 @@ struct MRef {
 ZKV_HD MRef m_ref(uint32_t* p, uint32_t stride, uint32_t f2w = 16) { MRef r; r.p = p; r.stride = stride; r.f2w = f2w; return r; }
 ZKV_HD MRef m_off(MRef m, int words) { MRef r = m; r.p = m.p + (size_t)words * m.stride; return r; }
 
+// Writable rows addressed like SoaRef (wave-uniform base and stride, one 32-bit byte offset per lane); usable wherever an MRef is:
+// Fp2 value k of this lane at words 16 k .. 16 k + 7 (the lane offset already selects the lane's component).
+struct SoaRW {
+    uint32_t* p; size_t stride; uint32_t off;
+    ZKV_HD uint32_t ld(int k) const { return *(const uint32_t*)((const char*)(p + (size_t)k * stride) + off); }
+    ZKV_HD void st(int k, uint32_t v) const { *(uint32_t*)((char*)(p + (size_t)k * stride) + off) = v; }
+    ZKV_HD int fw() const { return 16; }
+};
+// m_fresh(ref): the same reference with its per-lane part made opaque to the compiler (SoaRW only; a no-op for the other kinds).  Placed
+// in front of a group of loads or stores it keeps the compiler from computing their addresses far ahead and parking them in scratch.
+template <class R> ZKV_HD R m_fresh(R r) { return r; }
+ZKV_HD SoaRW m_fresh(SoaRW r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(r.off));
+#endif
+    return r;
+}
+
 // LRef: lane-interleaved LDS slot of a one-wavefront workgroup, word k at p[k * 64].  The pointer is typed as LDS
 // (address space 3) and the stride is a compile-time constant, so every access is a ds_read_b32 / ds_write_b32 with an
 // immediate offset: no address arithmetic, no flat-address lookup, conflict-free banks.
@@ -149,27 +167,19 @@ ZKV_HD void m_st_fp(L9Ref m, int word0, const Fp& a) { l9_st(m, word0 >> 3, l9_f
 // All inputs normalised and below 2p.
 ZKV_HD void l9_fp4_sqr_update(const L9& a, const L9& b, const L9& za, const L9& zb, const bool xi_t1, L9& o0, L9& o1) {
     const bool odd = zkv_parity() != 0;
-    L9X ax; L9Y by;
-    l9_x(a, ax); l9_y(b, by);
-    const L9 tmp = l9_mul(ax, by);
-    L9X s1;
+    const int32_t k1 = odd ? 1 : -1, k3 = odd ? -3 : 3;
+    const L9 tmp = l9_mul(a, b);
+    L9 s1, s2;
 #pragma unroll
-    for (int i = 0; i < 9; i++) s1.own[i] = a.l[i] + b.l[i];                     // lazy limbs below 2^30: multiplicand only
-#pragma unroll
-    for (int i = 0; i < 9; i++) s1.par[i] = zkv_partner_u32(s1.own[i]);
-    L9 s2;
+    for (int i = 0; i < 9; i++) s1.l[i] = a.l[i] + b.l[i];                       // lazy limbs below 2^30: multiplicand only
     {
-        // this lane's component of a + xi b = mine(a) + 9 mine(b) -+ other(b): the even lane takes 8p - b1 (by.V), the odd lane b0 (by.U)
-        uint32_t ob[9];
-#pragma unroll
-        for (int i = 0; i < 9; i++) ob[i] = odd ? by.U[i] : by.V[i];
-        const LTerm t[3] = {{a.l, 1}, {b.l, 9}, {ob, 1}};
-        s2 = l9_lincomb(t, 1);
+        // this lane's component of a + xi b = mine(a) + 9 mine(b) -+ other(b)
+        const L9 pb = l9_partner(b);
+        const LTerm t[3] = {{a.l, 1}, {b.l, 9}, {pb.l, k1}};
+        s2 = l9_lincomb(t, 4);
     }
-    L9Y s2y; l9_y(s2, s2y);
-    const L9 S = l9_mul(s1, s2y);
+    const L9 S = l9_mul(s1, s2);
     const L9 tp = l9_partner(tmp);
-    const int32_t k3 = odd ? -3 : 3;
     {
         const LTerm t[4] = {{S.l, 3}, {tmp.l, -30}, {tp.l, k3}, {za.l, -2}};
         o0 = l9_lincomb(t, 72);                                                    // 1 + (30 + 3 + 2) * 2
@@ -205,6 +215,114 @@ ZKV_HD void f12l9_cyclo_sqr(L9Ref f) {
     }
     l9_st(f, 1, n1); l9_st(f, 5, n5);
 }
+// ---- ACC <- ACC * S (or ACC * conj(S)) on resident limbs, S packed in an HBM slot
+// S is a row reference with a 32-bit lane offset (SoaRW); each group of loads starts from m_fresh(S).
+ZKV_HD void l9_carry(uint32_t (&x)[9]) {            // exact normalisation of lazy non-negative limbs (the value does not change)
+#pragma unroll
+    for (int k = 0; k < 8; k++) { x[k + 1] += x[k] >> 29; x[k] &= 0x1fffffffu; }
+}
+// The six Karatsuba products of an Fp6 multiplication (a0 + a1 v + a2 v^2)(b0 + b1 v + b2 v^2) and the limb-wise (lazy, signed) sums
+// its three result coefficients are made of:   c0 = v0 + xi wa,   c1 = wb + xi v2,   c2 = wc   with
+//   wa = (a1 + a2)(b1 + b2) - v1 - v2,   wb = (a0 + a1)(b0 + b1) - v0 - v1,   wc = (a0 + a2)(b0 + b2) - v0 - v2 + v1.
+// The caller turns them into reduced coefficients (l9_lincomb), together with whatever else it adds to them.
+// lda(i) / ldb(i): this lane's limbs of coefficient i of the multiplicand / multiplier (normalised, values below 2p: the sum of two
+// multiplicands stays lazy, the sum of two multipliers is carried to normalised limbs).
+struct L9F6Raw { L9 v0, v2; int32_t wa[9], wb[9], wc[9]; };
+template <class LDA, class LDB> ZKV_HD void l9_f6_mul_raw(LDA lda, LDB ldb, L9F6Raw& r) {
+    const L9 b0 = ldb(0), b1 = ldb(1), b2 = ldb(2);
+    r.v0 = l9_mul(lda(0), b0);
+    const L9 v1 = l9_mul(lda(1), b1);
+    r.v2 = l9_mul(lda(2), b2);
+    L9 sa, sb, m;
+    // the multiplicands are read again where they are needed (LDS) instead of living in registers across the products
+    { const L9 a1 = lda(1), a2 = lda(2);
+#pragma unroll
+      for (int i = 0; i < 9; i++) { sa.l[i] = a1.l[i] + a2.l[i]; sb.l[i] = b1.l[i] + b2.l[i]; } }
+    l9_carry(sb.l); m = l9_mul(sa, sb);
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.wa[i] = (int32_t)m.l[i] - (int32_t)v1.l[i] - (int32_t)r.v2.l[i];
+    { const L9 a0 = lda(0), a1 = lda(1);
+#pragma unroll
+      for (int i = 0; i < 9; i++) { sa.l[i] = a0.l[i] + a1.l[i]; sb.l[i] = b0.l[i] + b1.l[i]; } }
+    l9_carry(sb.l); m = l9_mul(sa, sb);
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.wb[i] = (int32_t)m.l[i] - (int32_t)r.v0.l[i] - (int32_t)v1.l[i];
+    { const L9 a0 = lda(0), a2 = lda(2);
+#pragma unroll
+      for (int i = 0; i < 9; i++) { sa.l[i] = a0.l[i] + a2.l[i]; sb.l[i] = b0.l[i] + b2.l[i]; } }
+    l9_carry(sb.l); m = l9_mul(sa, sb);
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.wc[i] = (int32_t)m.l[i] - (int32_t)r.v0.l[i] - (int32_t)r.v2.l[i] + (int32_t)v1.l[i];
+}
+ZKV_HD void l9_partner_i32(const int32_t (&a)[9], int32_t (&o)[9]) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) o[i] = (int32_t)zkv_partner_u32((uint32_t)a[i]);
+}
+// Karatsuba over Fp6: X = ag bg, Y = ah bh, Z = (ag + ah)(bg + bh);  g' = X + v Y,  h' = Z - X - Y.  X and Y are reduced coefficient
+// by coefficient (three one-pass combinations each), g' comes from those, and h' is formed in the same passes that reduce Z.
+template <class RB> ZKV_HD void f12l9_mul(L9Ref acc, RB S0, const bool conj_b) {
+    const int32_t k1 = zkv_parity() != 0 ? 1 : -1;                                 // xi q, this lane's component: 9 mine -+ the partner's
+    L9F6Raw raw;
+    int32_t pw[9];
+    L9 xc0, xc1, xc2;
+    {
+        const RB S = m_fresh(S0);
+        l9_f6_mul_raw([&](int i) { return l9_ld(acc, i); }, [&](int i) { return l9_from_fp(m_ld_f2(S, i).h); }, raw);
+        l9_partner_i32(raw.wa, pw);
+        { const LTerm t[3] = {{raw.v0.l, 1}, {(const uint32_t*)raw.wa, 9}, {(const uint32_t*)pw, k1}}; xc0 = l9_lincomb(t, 48); }
+        const L9 pv2 = l9_partner(raw.v2);
+        { const LTerm t[3] = {{(const uint32_t*)raw.wb, 1}, {raw.v2.l, 9}, {pv2.l, k1}}; xc1 = l9_lincomb(t, 8); }
+        { const LTerm t[1] = {{(const uint32_t*)raw.wc, 1}}; xc2 = l9_lincomb(t, 8); }
+    }
+    uint32_t xy0[9], xy1[9], xy2[9];
+    {
+        L9 g0, g1, g2;
+        const RB S = m_fresh(S0);
+        l9_f6_mul_raw([&](int i) { return l9_ld(acc, 3 + i); }, [&](int i) {
+            Fp2 b = m_ld_f2(S, 3 + i);
+            if (conj_b) b = f2_neg(b);
+            return l9_from_fp(b.h);
+        }, raw);
+        L9 yc0, yc1, yc2;
+        l9_partner_i32(raw.wa, pw);
+        { const LTerm t[3] = {{raw.v0.l, 1}, {(const uint32_t*)raw.wa, 9}, {(const uint32_t*)pw, k1}}; yc0 = l9_lincomb(t, 48); }
+        const L9 pv2 = l9_partner(raw.v2);
+        { const LTerm t[3] = {{(const uint32_t*)raw.wb, 1}, {raw.v2.l, 9}, {pv2.l, k1}}; yc1 = l9_lincomb(t, 8); }
+        { const LTerm t[1] = {{(const uint32_t*)raw.wc, 1}}; yc2 = l9_lincomb(t, 8); }
+        const L9 pyc2 = l9_partner(yc2);
+        { const LTerm t[3] = {{xc0.l, 1}, {yc2.l, 9}, {pyc2.l, k1}}; g0 = l9_lincomb(t, 4); }
+        { const LTerm t[2] = {{xc1.l, 1}, {yc0.l, 1}}; g1 = l9_lincomb(t, 1); }
+        { const LTerm t[2] = {{xc2.l, 1}, {yc1.l, 1}}; g2 = l9_lincomb(t, 1); }
+#pragma unroll
+        for (int i = 0; i < 9; i++) { xy0[i] = xc0.l[i] + yc0.l[i]; xy1[i] = xc1.l[i] + yc1.l[i]; xy2[i] = xc2.l[i] + yc2.l[i]; }
+        // g' is final; the slots of h take the multiplicands of Z, ag + ah carried to normalised limbs (values below 4p), until h' replaces them
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const L9 g = l9_ld(acc, i), h = l9_ld(acc, 3 + i);
+            L9 sum;
+#pragma unroll
+            for (int k = 0; k < 9; k++) sum.l[k] = g.l[k] + h.l[k];
+            l9_carry(sum.l);
+            l9_st(acc, 3 + i, sum);
+        }
+        l9_st(acc, 0, g0); l9_st(acc, 1, g1); l9_st(acc, 2, g2);
+    }
+    L9 h0, h1, h2;
+    {
+        const RB S = m_fresh(S0);
+        l9_f6_mul_raw([&](int i) { return l9_ld(acc, 3 + i); }, [&](int i) {
+            Fp2 b = m_ld_f2(S, 3 + i);
+            if (conj_b) b = f2_neg(b);
+            return l9_from_fp(f2_add(m_ld_f2(S, i), b).h);
+        }, raw);
+        l9_partner_i32(raw.wa, pw);
+        { const LTerm t[4] = {{raw.v0.l, 1}, {(const uint32_t*)raw.wa, 9}, {(const uint32_t*)pw, k1}, {xy0, -1}}; h0 = l9_lincomb(t, 52); }
+        const L9 pv2 = l9_partner(raw.v2);
+        { const LTerm t[4] = {{(const uint32_t*)raw.wb, 1}, {raw.v2.l, 9}, {pv2.l, k1}, {xy1, -1}}; h1 = l9_lincomb(t, 12); }
+        { const LTerm t[2] = {{(const uint32_t*)raw.wc, 1}, {xy2, -1}}; h2 = l9_lincomb(t, 12); }
+    }
+    l9_st(acc, 3, h0); l9_st(acc, 4, h1); l9_st(acc, 5, h2);
+}
 #endif  // ZKV_PAIRED
 
 // d <- a * b, or a * conj(b) (conj(b) = b^-1 for b in the cyclotomic subgroup); d may alias a or b
@@ -215,6 +333,7 @@ template <class RD, class RA, class RB> ZKV_HD void f12m_mul_body(RD d, RA a, RB
     if (conj_b) bh = f6_neg(bh);
     Fp6 t1 = f6_mul(ah, bh);
     Fp6 m = f6_mul(f6_add(ag, ah), f6_add(bg, bh));
+    d = m_fresh(d);
     m_st_f6(d, 3, f6_sub(f6_sub(m, t0), t1));
     m_st_f6(d, 0, f6_add(t0, f6_mul_v(t1)));
 }
@@ -323,6 +442,7 @@ template <class RD, class RA> ZKV_HD void f12m_inv_body(RD d, RA a) {
     Fp6 g = m_ld_f6(a, 0), h = m_ld_f6(a, 3);
     Fp6 t = f6_sub(f6_mul(g, g), f6_mul_v(f6_mul(h, h)));
     t = f6_inv(t);
+    d = m_fresh(d);
     m_st_f6(d, 0, f6_mul(g, t));
     m_st_f6(d, 3, f6_neg(f6_mul(h, t)));
 }

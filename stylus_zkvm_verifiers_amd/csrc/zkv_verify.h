@@ -355,14 +355,6 @@ ZKV_HD bool miller_loop_p(const VkTables* vkp, uint32_t flags, SoaRef norm, SoaR
     Fp2 qx, qy; qx.h = bsrc.fp(0); qy.h = bsrc.fp(16);
     return miller_point_closes(tm, qx, qy);
 }
-// Writable rows addressed like SoaRef (wave-uniform base and stride, one 32-bit byte offset per lane); usable wherever an MRef is:
-// Fp2 value k of this lane at words 16 k .. 16 k + 7 (the lane offset already selects the lane's component).
-struct SoaRW {
-    uint32_t* p; size_t stride; uint32_t off;
-    ZKV_HD uint32_t ld(int k) const { return *(const uint32_t*)((const char*)(p + (size_t)k * stride) + off); }
-    ZKV_HD void st(int k, uint32_t v) const { *(uint32_t*)((char*)(p + (size_t)k * stride) + off) = v; }
-    ZKV_HD int fw() const { return 16; }
-};
 // The Miller loop of the aggregate check (zkv_agg.h) for G proofs of one lane pair that share the accumulator: f <- f^2 once per
 // doubling step, then each proof's line -- only the variable pairs (r A'_p, B_p); the fixed pairs are taken once per sub-batch.  The
 // running points live in HBM rows (tq; proof p's rows p * `step` bytes after proof 0's, as in norm and bsrc) and pass through registers
@@ -495,26 +487,36 @@ template <class RA> ZKV_HD bool final_exp_is_one_m(MRef F, MRef E, MRef Y1, MRef
 // the packing accessors; COPY to / from ACC and CONJ ACC likewise.  Every other entry works on the packed HBM slots only (the generator
 // routes the few that need ACC's value through the slot TMP), in one generic body.
 // slots: 0 ACC, 1 F, 2.. = E, Y1, Y3, Y4, X17, X35, TMP (consecutive 96-word slots from E).
-ZKV_HD MRef fe_slot(int s, MRef F, MRef E) { return s == 1 ? F : m_off(E, 96 * (s - 2)); }
-ZKV_HD bool final_exp_prog_p(MRef F, MRef E, L9Ref acc) {
+// The HBM slots are addressed as SoaRW rows: a wave-uniform base (chosen by the program entry) and stride plus ONE 32-bit byte offset per
+// lane, re-read opaquely every entry -- with per-lane 64-bit pointers the compiler computed the 48 load addresses of a multiplication
+// ahead of its products and parked them in a scratch frame.  fbase / ebase: word 0 of proof 0 in the F rows / the E rows (ws.f, ws.fe);
+// off = 4 (8 parity cap + proof index).
+ZKV_HD SoaRW fe_slot(int s, uint32_t* fbase, uint32_t* ebase, size_t cap, uint32_t off) {
+    SoaRW r; r.p = s == 1 ? fbase : ebase + (size_t)(96 * (s - 2)) * cap; r.stride = cap; r.off = off;
+    return r;
+}
+ZKV_HD bool final_exp_prog_p(uint32_t* fbase, uint32_t* ebase, size_t cap, uint32_t off, L9Ref acc) {
     const uint32_t PROG[ZKV_FE_PROG_LEN] = ZKV_FE_PROG;
     bool one = false;
 #pragma unroll 1
     for (int pc = 0; pc < ZKV_FE_PROG_LEN; pc++) {
         const uint32_t e = PROG[pc];
         const int op = (int)(e & 255u), d = (int)((e >> 8) & 255u), a = (int)((e >> 16) & 255u), b = (int)(e >> 24);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(off));
+#endif
         if (op == 6) { ZKV_MARK("begin cyclo"); f12l9_cyclo_sqr(acc); ZKV_MARK("end cyclo"); }
-        else if ((op == 3 || op == 4) && d == 0) { ZKV_MARK("begin accmul"); f12m_mul_body(acc, acc, fe_slot(b, F, E), op == 4); ZKV_MARK("end accmul"); }
-        else if (op == 0 && d == 0) f12m_copy(acc, fe_slot(a, F, E));
-        else if (op == 0 && a == 0) f12m_copy(fe_slot(d, F, E), acc);
+        else if ((op == 3 || op == 4) && d == 0) { ZKV_MARK("begin accmul");  f12l9_mul(acc, fe_slot(b, fbase, ebase, cap, off), op == 4); ZKV_MARK("end accmul"); }
+        else if (op == 0 && d == 0) f12m_copy(acc, fe_slot(a, fbase, ebase, cap, off));
+        else if (op == 0 && a == 0) f12m_copy(fe_slot(d, fbase, ebase, cap, off), acc);
         else if (op == 1 && d == 0) f12m_conj(acc);
         else {
-            const MRef D = fe_slot(d, F, E), A = fe_slot(a, F, E);
-            if (op == 3 || op == 4) f12m_mul_body(D, A, fe_slot(b, F, E), op == 4);
+            const SoaRW D = fe_slot(d, fbase, ebase, cap, off), A = fe_slot(a, fbase, ebase, cap, off);
+            if (op == 3 || op == 4) { ZKV_MARK("begin genmul"); f12m_mul_body(D, A, fe_slot(b, fbase, ebase, cap, off), op == 4); ZKV_MARK("end genmul"); }
             else if (op == 0) f12m_copy(D, A);
             else if (op == 1) f12m_conj(D);
-            else if (op == 2) f12m_inv_body(D, A);
-            else if (op == 5) f12m_frob_body(D, A, b);
+            else if (op == 2) { ZKV_MARK("begin geninv"); f12m_inv_body(D, A); ZKV_MARK("end geninv"); }
+            else if (op == 5) { ZKV_MARK("begin genfrob"); f12m_frob_body(D, A, b); ZKV_MARK("end genfrob"); }
             else one = f12m_is_one(D);
         }
     }

@@ -49,11 +49,11 @@ static void lane(Job* j, uint32_t par) {
     j->sub_ok[par] = sub == sub_classic ? (sub ? 1 : 0) : -1;                        // the two tests must agree
     if (!sub) { j->muls[par][1] = zkv_fp_mul_counter - c0; j->mads[par][1] = zkv_mad_counter - d0; j->accept[par] = 0; return; }
     MRef ab = m_ref((uint32_t*)j->t->f_alpha_beta + 8 * par, 1, 16);
-    MRef F = m_ref(full + 8 * par, 1, 16), E = m_ref(full + 96 + 8 * par, 1, 16);
+    MRef F = m_ref(full + 8 * par, 1, 16);
     f12m_mul(F, fm, ab);
     j->muls[par][1] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter; j->mads[par][1] = zkv_mad_counter - d0; d0 = zkv_mad_counter;
     static thread_local uint32_t acc9[54 * 64];     // the accumulator in resident 29-bit limbs, laid out as one lane's column of the LDS slot
-    j->accept[par] = final_exp_prog_p(F, E, l9_ref(acc9)) ? 1 : 0;    // the interpreted program k_finalexp2 runs
+    j->accept[par] = final_exp_prog_p(full, full + 96, 1, 4u * 8u * par, l9_ref(acc9)) ? 1 : 0;    // the interpreted program k_finalexp2 runs
     j->muls[par][2] = zkv_fp_mul_counter - c0; j->mads[par][2] = zkv_mad_counter - d0;
 }
 // Fp multiplications (a lane's Fp2 product counts 2, fp_mul 1) spent by BOTH lanes of the pair in g2chk, miller, finalexp

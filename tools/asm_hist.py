@@ -55,7 +55,8 @@ def instrs(lines, a, b):
 
 def walk(lines, start, labels, funcs, memo, stop_mark=None, end=None):
     """Instruction stream from line `start` along the executed path: unconditional branches are followed, conditional ones fall
-    through (the marked bodies are straight-line code; their only conditional branches skip lane-masked sections), calls add the
+    through (the marked bodies are straight-line code; their only conditional branches skip lane-masked sections; s_cbranch_execnz is
+    followed), calls add the
     callee.  Stops at `stop_mark` (a '; ZKVMARK end X' comment) or at line `end`."""
     h, mn_h = collections.Counter(), collections.Counter()
     pending, i, steps = None, start, 0
@@ -66,7 +67,8 @@ def walk(lines, start, labels, funcs, memo, stop_mark=None, end=None):
         if stop_mark and stop_mark in l:
             break
         i += 1; steps += 1
-        assert steps < 2000000, 'no end mark on the path'
+        if steps > 400000:
+            raise RuntimeError('no end mark on the path')
         if not l.startswith('\t') or l.strip().startswith(('.', ';')):
             continue
         ins = l.strip()
@@ -81,7 +83,7 @@ def walk(lines, start, labels, funcs, memo, stop_mark=None, end=None):
                 memo[pending] = walk(lines, fa, labels, funcs, memo, end=fb)
             ch, cm = memo[pending]
             h.update(ch); mn_h.update(cm)
-        if mn == 's_branch':
+        if mn in ('s_branch', 's_cbranch_execnz'):      # execnz: taken whenever a lane is active (lane-masked sections placed out of line)
             i = labels[ins.split()[1]]
     return h, mn_h
 
@@ -107,7 +109,11 @@ def main():
     total = collections.Counter()
     for name, spans in regions.items():
         for n, a in enumerate(spans):
-            h, mn_h = walk(lines, a + 1, labels, funcs, memo, stop_mark='; ZKVMARK end ' + name)
+            try:
+                h, mn_h = walk(lines, a + 1, labels, funcs, memo, stop_mark='; ZKVMARK end ' + name)
+            except (RuntimeError, KeyError):
+                print('%-14s (region holds a loop or a two-way branch: not a single path)' % name)
+                continue
             tot = sum(h.values())
             print('%-14s %7d ' % (name if len(spans) == 1 else '%s#%d' % (name, n), tot) + ' '.join('%6d' % h[c] for c in CLASSES))
             top = ', '.join('%s %d' % kv for kv in mn_h.most_common(14))
