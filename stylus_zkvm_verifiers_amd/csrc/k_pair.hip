@@ -34,10 +34,31 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_g2chk2(size_t n, Workspace ws,
     if (!ok && !(threadIdx.x & 1u)) { ws.g2bad[i] = 1; status[i] = ST_VERIFICATION_FAILED; }
 }
 
+#if defined(ZKV_STAMPS)
+// Diagnostic build only (tools/ab_build.py ...:-DZKV_STAMPS, tools/stamp_probe.py): lane 0 of every wavefront of k_miller2 / k_finalexp2 leaves
+// the constant 100 MHz clock at its first and last instruction, the shader clock, and where it ran (HW_ID, XCC_ID) in a side buffer no
+// result depends on: 8 words per wavefront, kernel k at rows [k * n_waves, (k + 1) * n_waves).
+__device__ unsigned long long* g_zkv_stamps = nullptr;
+extern "C" __attribute__((visibility("default"))) int zkv_diag_set_stamps(void* dev_ptr) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_zkv_stamps), &dev_ptr, sizeof(dev_ptr));
+}
+__device__ __forceinline__ void zkv_stamp(unsigned kernel, unsigned slot) {
+    if ((threadIdx.x & 63u) != 0 || !g_zkv_stamps) return;
+    unsigned long long* row = g_zkv_stamps + ((size_t)kernel * gridDim.x * (blockDim.x >> 6) + (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8;
+    row[slot] = __builtin_amdgcn_s_memrealtime();
+    row[4 + slot] = __builtin_amdgcn_s_memtime();
+    if (slot == 0) { row[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); row[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20); }
+}
+#define ZKV_STAMP(k, s) zkv_stamp(k, s)
+#else
+#define ZKV_STAMP(k, s) ((void)0)
+#endif
+
 // The Miller loop is also the subgroup test of B (miller_loop_p, check_b): a proof whose B is outside G2 gets the precompile-failure
 // status here and is skipped by k_finalexp2.  (k_g2chk2 remains for the 16-lane kernels of small chunks.)
 __global__ __launch_bounds__(PAIR_BLOCK, 2) void k_miller2(size_t n, const VkTables* __restrict__ vk, Workspace ws, uint8_t* __restrict__ status) {
     __shared__ uint32_t lds[(48 + 24) * PAIR_BLOCK];      // per wavefront: f: 6 Fp per lane, T: 3 Fp per lane, lane-interleaved
+    ZKV_STAMP(0, 0);
     size_t i = ((size_t)blockIdx.x * PAIR_BLOCK + threadIdx.x) >> 1;
     if (i >= n) return;
     uint32_t flags = ws.flags[i];
@@ -55,10 +76,12 @@ __global__ __launch_bounds__(PAIR_BLOCK, 2) void k_miller2(size_t n, const VkTab
     MRef ab = m_ref((uint32_t*)(vk->f_alpha_beta) + 8 * par, 1, 16);
     MRef out = m_ref(ws.f + (size_t)(8 * par) * ws.cap + i, (uint32_t)ws.cap, 16);
     f12m_mul_body(out, fm, ab, false);
+    ZKV_STAMP(0, 1);
 }
 
 __global__ __launch_bounds__(PAIR_BLOCK, 2) void k_finalexp2(size_t n, Workspace ws, uint8_t* __restrict__ status) {
     __shared__ uint32_t lds[54 * PAIR_BLOCK];             // the accumulator in resident 29-bit limbs: 6 coefficients x 9 words per lane
+    ZKV_STAMP(1, 0);
     size_t i = ((size_t)blockIdx.x * PAIR_BLOCK + threadIdx.x) >> 1;
     if (i >= n) return;
     uint32_t flags = ws.flags[i];
@@ -68,6 +91,7 @@ __global__ __launch_bounds__(PAIR_BLOCK, 2) void k_finalexp2(size_t n, Workspace
     L9Ref acc = l9_ref(wl);
     bool one = final_exp_prog_p(ws.f, ws.fe, ws.cap, (uint32_t)(8 * par * ws.cap + i) * 4u, acc);
     if (!par) status[i] = one ? ST_OK : ST_VERIFICATION_FAILED;
+    ZKV_STAMP(1, 1);
 }
 
 // The ecPairing precompile as a batch (the inner seam of the reference: common/groth16.rs:109-128 builds k x 192 bytes of

@@ -42,6 +42,35 @@ static thread_local unsigned long long zkv_mad_counter = 0;         // 32 x 32 +
 #define ZKV_MARK(name) ((void)0)
 #endif
 
+// Two wavefronts share a SIMD in the big kernels, and the hardware arbitrates VALU issue between them by priority, then AGE: at equal
+// priority the older wavefront runs nearly unimpeded and the younger one gets the leftover slots (measured with per-wavefront clock stamps,
+// profiles/round4_*stamps*: in a one-round launch of k_miller2 the wavefronts' own durations spread from 4.8 to 8.1 ms although all do the
+// same work).  Once the older one has finished, the younger runs alone -- and a lone wavefront issues at little more than half the rate of two
+// -- so every launch ended with a tail of half-idle SIMDs: about 1.3 ms for k_miller2, the "fixed cost per launch" that held a 2^16-proof
+// batch 12 % below the 2^20 rate.  zkv_fair_share() makes the two take turns: time is cut into slices of the constant 100 MHz clock, and
+// in each slice the wavefront whose slot parity matches takes priority 1 while the other drops to 0; both then finish nearly together
+// (2^16 RISC Zero proofs: k_miller2 7.86 -> 7.20 ms, k_finalexp2 4.06 -> 3.64 ms; nothing changes for a 2^20-proof launch, whose SIMDs are
+// refilled as wavefronts retire).
+#ifndef ZKV_FAIR_SLICE_SHIFT
+#define ZKV_FAIR_SLICE_SHIFT 17        /* 2^17 ticks of 10 ns = 1.3 ms: measured best of 2^10 ... 2^20 (profiles/round4_fair_share_slices.txt) */
+#endif
+ZKV_HD uint32_t zkv_wave_slot_parity() {           // HW_ID.wave_id[0]: the two resident wavefronts of a SIMD sit in slots 0 and 1
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKV_NO_FAIR_SHARE)
+    return __builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u;
+#else
+    return 0;
+#endif
+}
+ZKV_HD void zkv_fair_share(uint32_t slot_parity) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKV_NO_FAIR_SHARE)
+    const uint32_t t = (uint32_t)(__builtin_amdgcn_s_memrealtime() >> ZKV_FAIR_SLICE_SHIFT);
+    if ((t ^ slot_parity) & 1u) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+#else
+    (void)slot_parity;
+#endif
+}
+
 #include "zkv_modinv.h"
 
 namespace zkv {

@@ -314,30 +314,34 @@ ZKV_HD bool miller_loop_p(const VkTables* vkp, uint32_t flags, SoaRef norm, SoaR
     const bool do_l = with_fixed && !(flags & FL_L_INF) && !vkp->skip_fixed[0], do_c = with_fixed && !(flags & FL_C_INF) && !vkp->skip_fixed[1];
     f12m_set_one(fm);
     { Fp2 bx, by; bx.h = bsrc.fp(0); by.h = bsrc.fp(16); m_st_f2(tm, 0, bx); m_st_f2(tm, 1, by); m_st_f2(tm, 2, f2_one()); }
+    const uint32_t slot = zkv_wave_slot_parity();
 #pragma unroll 1
     for (int li = 0; li < ZKV_MILLER_STEPS; li++) {
         const int kind = KIND[li];
+        zkv_fair_share(slot);                  // the two wavefronts of a SIMD take turns at priority (zkv_field.h)
 #if defined(__HIP_DEVICE_COMPILE__)
         // the lane offsets are re-read through an opaque move every step: otherwise the 64 per-lane addresses of the step's loads are
         // hoisted out of the loop as invariants, and ten of them end up in a scratch frame (5.5 GB of reloads per 2^20-proof launch)
         asm volatile("" : "+v"(norm.off), "+v"(bsrc.off));
 #endif
-        if (kind == 0 && li != 0) f12m_sqr_body(fm);
+        if (kind == 0 && li != 0) { ZKV_MARK("begin sqr"); f12m_sqr_body(fm); ZKV_MARK("end sqr"); }
         if (do_t) {
             Fp2 l0, l1, l3;
             G2H T; T.x = m_ld_f2(tm, 0); T.y = m_ld_f2(tm, 1); T.z = m_ld_f2(tm, 2);
-            if (kind == 0) line_dbl(T, l0, l1, l3);
+            if (kind == 0) { ZKV_MARK("begin linedbl"); line_dbl(T, l0, l1, l3); ZKV_MARK("end linedbl"); }
             else {
                 Fp2 qx, qy; qx.h = bsrc.fp(0); qy.h = bsrc.fp(16);
                 if (kind == 2) qy = f2_neg(qy);
                 else if (kind == 3) { Fp2 x, y; g2_frob_affine(x, y, qx, qy); qx = x; qy = y; }
                 else if (kind == 4) { Fp2 x, y; g2_frob2_affine(x, y, qx, qy); qx = x; qy = f2_neg(y); }
-                line_add(T, qx, qy, l0, l1, l3);
+                ZKV_MARK("begin lineadd"); line_add(T, qx, qy, l0, l1, l3); ZKV_MARK("end lineadd");
             }
             m_st_f2(tm, 0, T.x); m_st_f2(tm, 1, T.y); m_st_f2(tm, 2, T.z);
             if (do_ab) {
+                ZKV_MARK("begin mul034");
                 const Fp2 c3 = f2_mul_fp(l1, norm.fp(0)), c4 = f2_mul_fp(l3, norm.fp(8));
                 f12m_mul_by_034_body(fm, l0, c3, c4);
+                ZKV_MARK("end mul034");
             }
         }
 #pragma unroll 1
@@ -346,9 +350,11 @@ ZKV_HD bool miller_loop_p(const VkTables* vkp, uint32_t flags, SoaRef norm, SoaR
             // the step's line is the same for every lane: 8 vector loads of one broadcast address.  Reading it through the constant
             // address space instead (two s_load_dwordx16 into SGPRs; commit 'Line tables: scalar-load variant built and measured') was
             // slower -- 125.3 against 123.8 ms per 2^20 proofs: 32 more live SGPRs and a scalar wait in front of every line product.
+            ZKV_MARK("begin mul134");
             const LineAffC& L = vkp->lines[j][li];
             const Fp2 c3 = f2_mul_fp(f2_const(L.nl), norm.fp(16 + 16 * j)), c4 = f2_mul_fp(f2_const(L.c), norm.fp(24 + 16 * j));
             f12m_mul_by_134_body(fm, c3, c4);
+            ZKV_MARK("end mul134");
         }
     }
     if (!check_b || !do_t) return true;
@@ -498,10 +504,12 @@ ZKV_HD SoaRW fe_slot(int s, uint32_t* fbase, uint32_t* ebase, size_t cap, uint32
 ZKV_HD bool final_exp_prog_p(uint32_t* fbase, uint32_t* ebase, size_t cap, uint32_t off, L9Ref acc) {
     const uint32_t PROG[ZKV_FE_PROG_LEN] = ZKV_FE_PROG;
     bool one = false;
+    const uint32_t slot = zkv_wave_slot_parity();
 #pragma unroll 1
     for (int pc = 0; pc < ZKV_FE_PROG_LEN; pc++) {
         const uint32_t e = PROG[pc];
         const int op = (int)(e & 255u), d = (int)((e >> 8) & 255u), a = (int)((e >> 16) & 255u), b = (int)(e >> 24);
+        if ((pc & 3) == 0) zkv_fair_share(slot);          // the two wavefronts of a SIMD take turns at priority (zkv_field.h)
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : "+v"(off));
 #endif
