@@ -314,8 +314,11 @@ int zkv_ctx_set_lanes_per_proof(zkv_ctx* ctx, int lanes);
  * membership of B).  A sub-batch whose aggregate check fails is verified again proof by proof by the ordinary kernels, so the
  * statuses are the deterministic ones unless invalid proofs pass an aggregate check, which happens with probability 2^-128 per
  * sub-batch over the coefficients -- provided the proofs were fixed before the secret was drawn.  seed32 = NULL draws the secret from
- * the operating system (getrandom) -- the setting for production; a caller-supplied seed makes runs reproducible (tests) and must
- * not be known to whoever supplies proofs.  Applies to RISC Zero, SP1 (Groth16), verifier-set, generic-key, mixed and sharded
+ * the operating system (getrandom) -- the setting for production: the secret is then drawn afresh every 1,024 chunks; a
+ * caller-supplied seed makes runs reproducible (tests), must not be known to whoever supplies proofs and must never be used for a
+ * second context or process (the per-chunk counter restarts at zero: the same seed replays the same coefficients).  In the automatic
+ * mode the check also switches itself OFF for a while -- 8, then 16 ... 64 chunks, probing again in between -- while more than one
+ * sub-batch of 16 in three fails, where it would cost more than it saves.  Applies to RISC Zero, SP1 (Groth16), verifier-set, generic-key, mixed and sharded
  * contexts, and to SP1 PLONK contexts (both pairs of a PLONK check are fixed: prod_i (e(D_i, [1]_2) e(-Q_i, [tau]_2))^{r_i} needs two
  * scalar multiplications per proof and one pairing product per sub-batch -- no per-proof Miller loop is left); ZKV_ERR_INVALID_ARG on
  * a precompile context.  Keys with alpha or beta at infinity fall back to the ordinary path, and so does a context whose extra buffers
@@ -332,6 +335,20 @@ int zkv_ctx_aggregate_counters(zkv_ctx* ctx, uint64_t out[2]);
  * batch call.  Optional: every batch entry point does this on demand; the buffers (about 3.7 KB per proof in flight) grow to the
  * largest batch seen, at most ZKV_CHUNK proofs (environment, default 2^20; larger batches run chunk by chunk). */
 int zkv_ctx_reserve(zkv_ctx* ctx, size_t n);
+/* Sharded context, device-resident batches: how shard `shard` reaches the GPU that held the rows of the last batch it staged --
+ * 1: peer access granted (hipDeviceEnablePeerAccess: the range travels as direct xGMI copies), 0: refused (the runtime bounces the
+ * copies through the host), 2: not applicable so far (the shard sits on the source GPU, or it has staged nothing yet).
+ * ZKV_ERR_INVALID_ARG (negative) for a context that is not sharded or an index past its shards.  A scaling run reads this to tell direct copies
+ * from bounced ones. */
+int zkv_ctx_shard_peer_access(zkv_ctx* ctx, size_t shard);
+/* Host buffers that a caller hands to the batch entry points again and again (a server's receive ring: seals, public inputs, the
+ * status array) can be pinned once: the H2D staging of a host-buffer batch then runs as direct DMA from them instead of going through
+ * the runtime's pageable-copy path, and the first segment's copy -- the only one the kernels do not hide -- shrinks accordingly
+ * (SURVEY 8(d) measures the metric at this boundary: "wall-clock over the batch call at the C ABI, H2D staging included").
+ * Thin wrappers of hipHostRegister / hipHostUnregister (portable across devices); the memory stays the caller's.  Optional: every entry
+ * point accepts pageable memory.  Without a usable device both return ZKV_ERR_NO_DEVICE; what the runtime refuses is ZKV_ERR_HIP. */
+int zkv_host_register(void* ptr, size_t bytes);
+int zkv_host_unregister(void* ptr);
 /* The chunk size in force: ZKV_CHUNK rounded up to a multiple of 64 and clamped to [64, 2^26] (the kernels address a chunk's
  * workspace rows through 32-bit lane offsets, which a larger chunk would wrap). */
 size_t zkv_chunk_capacity(void);

@@ -72,6 +72,9 @@ SYMBOLS = {
     'zkv_ctx_set_aggregate_check': (_i, [_vp, _i, _cp]),
     'zkv_ctx_aggregate_counters': (_i, [_vp, C.POINTER(C.c_uint64)]),
     'zkv_ctx_reserve': (_i, [_vp, _sz]),
+    'zkv_ctx_shard_peer_access': (_i, [_vp, _sz]),
+    'zkv_host_register': (_i, [_vp, _sz]),
+    'zkv_host_unregister': (_i, [_vp]),
     'zkv_chunk_capacity': (_sz, []),
     'zkv_ctx_synchronize': (_i, [_vp]),
     'zkv_ctx_last_stage_ms': (_i, [_vp, C.POINTER(C.c_float)]),

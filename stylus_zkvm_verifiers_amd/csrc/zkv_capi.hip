@@ -2,6 +2,9 @@
 // Host code here only marshals bytes, runs the once-per-context SHA-256 chain (initialize) and enqueues
 // kernels; every field/curve/pairing operation runs in the HIP kernels.  No CPU fallback exists.
 #include <hip/hip_runtime.h>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <math.h>
@@ -75,6 +78,11 @@ struct zkv_ctx {
     bool agg_auto = false;                                     // enable = 1: the size follows the failure rate seen so far (agg_adapt)
     unsigned long long agg_seen[2] = {0, 0};                   // counters at the last adaptation
     bool agg_resnap = false;                                   // just switched on: the next look only takes the counters as they are
+    bool agg_look = false;                                     // one look at the counters per CALL (order_after_previous arms it): a later chunk of the same call
+                                                               // could find the previous chunk's k_agg_mark half-way through its two counters
+    uint32_t agg_pause = 0, agg_pause_len = 0;                 // automatic mode: chunks still to run WITHOUT the check (too many sub-batches fail), and the length of that pause
+    bool agg_os_seed = false;                                  // the secret came from the operating system: it is drawn afresh every AGG_REKEY_CHUNKS chunks
+    uint32_t agg_key_age = 0;
     AggTables* d_agg_tab = nullptr;
     uint32_t* d_agg = nullptr;
     Workspace ws2 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
@@ -96,7 +104,30 @@ struct zkv_ctx {
         uint8_t *st = nullptr, *rv = nullptr; size_t st_cap = 0, rv_cap = 0;
         hipStream_t copy = nullptr, run = nullptr;
         hipEvent_t ev_piece[2] = {nullptr, nullptr}, ev_done = nullptr;
+        bool has_done = false;                                 // ev_done has been recorded: the next call's copies into row[] wait for it
+        int peer = 2;                                          // peer access to the source GPU of the last staged batch: 1 granted (direct xGMI copies), 0 refused
+                                                               // (the runtime bounces the copies), 2 never needed (same device, or nothing staged yet)
     };
+    // One persistent host thread per shard beyond the first (shard 0 runs on the calling thread): created on first use, parked on a
+    // condition variable between calls.
+    struct ShardWorker {
+        std::thread th; std::mutex m; std::condition_variable cv;
+        std::function<void()> job; bool busy = false, quit = false;
+        void loop() {
+            std::unique_lock<std::mutex> lk(m);
+            for (;;) {
+                cv.wait(lk, [&] { return busy || quit; });
+                if (quit) return;
+                std::function<void()> j = std::move(job);
+                lk.unlock(); j(); lk.lock();
+                busy = false; cv.notify_all();
+            }
+        }
+        void submit(std::function<void()> j) { { std::lock_guard<std::mutex> lk(m); job = std::move(j); busy = true; } cv.notify_all(); }
+        void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !busy; }); }
+    };
+    std::vector<std::unique_ptr<ShardWorker>> workers;
+    std::mutex pool_mu;                                        // one batch call at a time hands work to the pool
     std::vector<zkv_ctx*> shards;
     std::vector<ShardDev> sh;
     std::vector<hipEvent_t> ev_in;                       // per source device: "the caller's stream has produced the inputs"
@@ -373,6 +404,7 @@ static int grow(uint8_t** p, size_t* cap, size_t need) {
 // Cross-stream ordering of consecutive calls on one context (see zkv_ctx::ev_done).
 static int order_after_previous(zkv_ctx* c, hipStream_t s) {
     if (c->has_done) HIP_TRY(hipStreamWaitEvent(s, c->ev_done, 0));
+    c->agg_look = true;
     return ZKV_OK;
 }
 static int mark_done(zkv_ctx* c, hipStream_t s) {
@@ -417,7 +449,18 @@ static void launch_finalexp_by_size(size_t n, const Workspace& ws, uint8_t* stat
 // fail at the pairing, and from p the size for the coming chunks: a failed sub-batch costs its `sub` proofs a second, ordinary
 // verification, a sub-batch costs one pseudo-proof: per proof 1 / sub + sub p in units of one verification, least near sub = 1 / sqrt(p).
 // Measured (2^20 SP1 proofs): no failures 128 best (87 ms; 91.5 at 64), one proof in 320 failing 16 best (109 ms; 133 at 64).
+//
+// Switching OFF: at the smallest size a sub-batch that fails costs its 16 proofs the aggregate pass AND the ordinary pass; from about one
+// failing sub-batch in three on the check is a net loss (measured: the aggregate pass is ~0.6 of an ordinary one at size 16), and a
+// stream of bad proofs would make it a slow-down knob.  Above that rate the following AGG_PAUSE_MIN (then twice as many, up to
+// AGG_PAUSE_MAX) chunks run without the check; the chunk after a pause probes again with size 16, and the check stays on once the
+// rate has fallen.  Only the automatic mode (enable = 1) does any of this: a caller that fixes the size keeps it.
+constexpr uint32_t AGG_PAUSE_MIN = 8, AGG_PAUSE_MAX = 64;
+// One look per call, at its start: ev_done is recorded once per call, so a later chunk of the same call could see the event of the
+// PREVIOUS call complete while its own earlier chunk is still adding to the two counters.
 static void agg_adapt(zkv_ctx* c) {
+    if (!c->agg_look) return;
+    c->agg_look = false;
     if (!c->agg_auto || !c->has_done || !c->d_agg_cnt || hipEventQuery(c->ev_done) != hipSuccess) { (void)hipGetLastError(); return; }
     unsigned long long v[2];                                   // (on the context's side stream, idle here: waits neither for the caller's streams nor for the
                                                                // host pipeline's segment copies on copy_stream)
@@ -431,7 +474,42 @@ static void agg_adapt(zkv_ctx* c) {
     c->agg_seen[0] = v[0]; c->agg_seen[1] = v[1];
     const double f = (double)failed / (double)checked;         // P(a sub-batch of agg_sub proofs holds a failing proof) = 1 - (1 - p)^sub
     const double p = f >= 1.0 ? 1.0 : 1.0 - pow(1.0 - f, 1.0 / (double)c->agg_sub);
+    const uint32_t was = c->agg_sub;
     c->agg_sub = p < 1.0 / 32768 ? 128u : p < 1.0 / 4096 ? 64u : p < 1.0 / 1024 ? 32u : 16u;
+    // what size 16 would see with this p: 1 - (1 - p)^16
+    const double f16 = was == 16u ? f : 1.0 - pow(1.0 - p, 16.0);
+    if (f16 > 1.0 / 3.0) {
+        c->agg_pause_len = c->agg_pause_len ? (2 * c->agg_pause_len > AGG_PAUSE_MAX ? AGG_PAUSE_MAX : 2 * c->agg_pause_len) : AGG_PAUSE_MIN;
+        c->agg_pause = c->agg_pause_len;
+        c->agg_sub = 16u;                                     // the probe after the pause
+    } else c->agg_pause_len = 0;
+}
+// Whether this chunk takes the aggregate check (automatic mode: not during a pause).
+static bool agg_wanted(zkv_ctx* c) {
+    agg_adapt(c);                                             // (once per call: the decision covers this chunk already)
+    if (c->agg_auto && c->agg_pause) { c->agg_pause--; return false; }
+    return true;
+}
+// Fresh coefficients for every chunk (the counter), and a fresh SECRET every AGG_REKEY_CHUNKS chunks when the operating system supplied it
+// (zkv_ctx_set_aggregate_check with seed32 = NULL): nothing a long-running service has revealed about old coefficients -- timing, say --
+// carries over.  A caller-supplied seed is the caller's responsibility (include/zkv.h).
+constexpr uint32_t AGG_REKEY_CHUNKS = 1024;
+static uint32_t agg_rekey_chunks() {
+    const char* e = getenv("ZKV_AGG_REKEY");                    // tests shorten the interval
+    const unsigned long v = e ? strtoul(e, nullptr, 10) : 0;
+    return v ? (uint32_t)v : AGG_REKEY_CHUNKS;
+}
+static void agg_next_coefficients(zkv_ctx* c) {
+    if (c->agg_os_seed && ++c->agg_key_age >= agg_rekey_chunks()) {
+        uint8_t seed[32];
+        if (getrandom(seed, 32, 0) == 32) {
+            for (int i = 0; i < 8; i++) c->agg_seed.w[i] = ((uint32_t)seed[4 * i] << 24) | ((uint32_t)seed[4 * i + 1] << 16) | ((uint32_t)seed[4 * i + 2] << 8) | seed[4 * i + 3];
+            c->agg_key_age = 0;
+        }
+        volatile uint8_t* wipe = seed;
+        for (int i = 0; i < 32; i++) wipe[i] = 0;
+    }
+    c->agg_seed.call++;
 }
 // The aggregate check of one chunk (zkv_agg.h), after PREP: per-proof G1 stage and Miller loop of the variable pair only, one
 // pseudo-proof per sub-batch through the ordinary Miller loop and final exponentiation, then the ordinary stages once more for the
@@ -445,7 +523,7 @@ static void enqueue_agg(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed
     // proofs per Miller accumulator: ZKV_AGG_GROUP = 1 (k_miller2), 2, 4 or 8 (k_agg_miller); at most the sub-batch's eighth... see agg_group()
     const uint32_t grp = agg_group(sub64);
     const InstTab* inst = a.inst ? c->d_inst : nullptr;
-    c->agg_seed.call++;                                       // fresh coefficients for every chunk
+    agg_next_coefficients(c);
     // vk_x through summed scalars: one key (no per-proof base) and at most two per-proof signals
     const bool sums = !inst && (c->vm == ZKV_VM_RISC0 || c->vm == ZKV_VM_SP1 || (c->vm == ZKV_VM_GROTH16 && c->g_n_ic >= 1 && c->g_n_ic - 1 <= (uint32_t)AGG_SUM_VARS));
     launch_agg_g1(a.n, c->d_tab, inst, c->ws, c->d_agg, c->agg_seed, sums, s);
@@ -473,7 +551,7 @@ static void enqueue_agg_plonk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool
     const uint32_t sub = c->agg_sub, sub64 = sub < 64 ? sub : 64;
     const size_t n64 = (a.n + 63) / 64;
     const size_t n2 = sub > 64 ? (a.n + sub - 1) / sub : n64 * (64 / sub);
-    c->agg_seed.call++;
+    agg_next_coefficients(c);
     launch_agg_plonk_g1(a.n, c->ws, c->d_agg, c->agg_seed, s);
     if (timed) { (void)hipEventRecord(c->ev[2], s); (void)hipEventRecord(c->ev[3], s); }
     launch_agg_reduce(a.n, sub64, false, 1, c->d_tab, c->ws, c->d_agg, nullptr, c->ws2, c->d_status2, sub > 64, s);
@@ -498,7 +576,7 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
         PrepArgs ap = a;
         ap.plonk_tab = c->d_plonk_tab;
         launch_plonk_prep(ap, c->d_pkey, c->ws, s);
-        if (c->agg_on && c->agg_key_ok && c->agg_cap >= c->ws.cap && c->lanes == 0 && a.n >= agg_min()) {
+        if (c->agg_on && c->agg_key_ok && c->agg_cap >= c->ws.cap && c->lanes == 0 && a.n >= agg_min() && agg_wanted(c)) {
             if (timed) (void)hipEventRecord(c->ev[1], s);
             enqueue_agg_plonk(c, a, s, timed);
             return;
@@ -517,7 +595,7 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     else if (c->vm == ZKV_VM_GROTH16) launch_prep_groth16(a, c->ws, s);
     else launch_prep_sp1(a, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[1], s);
-    if (c->agg_on && c->agg_key_ok && c->agg_cap >= c->ws.cap && c->lanes == 0 && a.n >= agg_min()) { enqueue_agg(c, a, s, timed); return; }
+    if (c->agg_on && c->agg_key_ok && c->agg_cap >= c->ws.cap && c->lanes == 0 && a.n >= agg_min() && agg_wanted(c)) { enqueue_agg(c, a, s, timed); return; }
     const int lanes = c->lanes ? c->lanes : 2;       // 2 = one proof per lane pair; 16 = one proof per 16 lanes (small chunks); 64 = per wavefront (smallest)
     const bool dual = lanes == 128 || (c->lanes == 0 && a.n <= dual_below());       // 128 = two wavefronts per proof in the Miller loop
     const bool wave = dual || lanes == 64 || (c->lanes == 0 && a.n <= wave_below());
@@ -735,16 +813,32 @@ static inline void shard_range(size_t n, size_t used, size_t k, size_t* lo, size
     *hi = *lo + q + (k < r ? 1 : 0);
 }
 // per_shard(child, lo, hi) -> ZKV_*; shard 0 runs on the calling thread
+// fn(k) for the shards 1 .. used - 1 on their persistent workers and for shard 0 on the calling thread; returns when all are done.
+template <class F> static void shard_parallel(zkv_ctx* c, size_t used, F fn) {
+    std::lock_guard<std::mutex> pool(c->pool_mu);
+    while (c->workers.size() + 1 < used) {
+        std::unique_ptr<zkv_ctx::ShardWorker> w(new zkv_ctx::ShardWorker());
+        try { w->th = std::thread([p = w.get()] { p->loop(); }); } catch (const std::system_error&) { break; }     // no thread to be had: that shard runs here
+        c->workers.push_back(std::move(w));
+    }
+    const size_t pooled = c->workers.size() + 1 < used ? c->workers.size() + 1 : used;
+    for (size_t k = 1; k < pooled; k++) c->workers[k - 1]->submit([&fn, k] { fn(k); });
+    fn(0);
+    for (size_t k = pooled; k < used; k++) fn(k);
+    for (size_t k = 1; k < pooled; k++) c->workers[k - 1]->wait();
+}
+static void shard_workers_stop(zkv_ctx* c) {
+    for (auto& w : c->workers) {
+        { std::lock_guard<std::mutex> lk(w->m); w->quit = true; }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+    }
+    c->workers.clear();
+}
 template <class F> static int run_sharded(zkv_ctx* c, size_t n, F per_shard) {
     const size_t used = shards_used(c, n);
     std::vector<int> rc(used, ZKV_OK);
-    std::vector<std::thread> th;
-    auto one = [&](size_t k) { size_t lo, hi; shard_range(n, used, k, &lo, &hi); rc[k] = per_shard(c->shards[k], lo, hi); };
-    for (size_t k = 1; k < used; k++) {
-        try { th.emplace_back(one, k); } catch (const std::system_error&) { one(k); }          // no thread to be had: run it here
-    }
-    one(0);
-    for (auto& t : th) t.join();
+    shard_parallel(c, used, [&](size_t k) { size_t lo, hi; shard_range(n, used, k, &lo, &hi); rc[k] = per_shard(c->shards[k], lo, hi); });
     for (int r : rc) if (r != ZKV_OK) return r;
     return ZKV_OK;
 }
@@ -794,7 +888,14 @@ static int run_sharded_dev(zkv_ctx* c, size_t n, const DevRow* rows, int n_rows,
         const bool staged = force || kid->device != sdev;
         if (caller) { HIP_TRY(hipStreamWaitEvent(d.run, c->ev_in[sdev], 0)); HIP_TRY(hipStreamWaitEvent(d.copy, c->ev_in[sdev], 0)); }
         if (staged) {
-            if (kid->device != sdev) { (void)hipDeviceEnablePeerAccess(sdev, 0); (void)hipGetLastError(); }     // direct xGMI copies where the platform allows
+            if (kid->device != sdev) {                             // direct xGMI copies where the platform allows; the verdict is kept for zkv_ctx_shard_peer_access
+                const hipError_t pe = hipDeviceEnablePeerAccess(sdev, 0);
+                (void)hipGetLastError();
+                d.peer = (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) ? 1 : 0;
+            }
+            // the staging rows are about to be overwritten: not before the previous call's kernels on this shard have read them (that call may
+            // have been enqueued on another caller stream, or with none, and still be running)
+            if (d.has_done) HIP_TRY(hipStreamWaitEvent(d.copy, d.ev_done, 0));
             for (int j = 0; j < n_rows; j++) if ((r = grow(&d.row[j], &d.row_cap[j], m * rows[j].stride + 8)) != ZKV_OK) return r;
             if ((r = grow(&d.st, &d.st_cap, m)) != ZKV_OK || (d_recv && (r = grow(&d.rv, &d.rv_cap, 4 * m)) != ZKV_OK)) return r;
         }
@@ -825,14 +926,10 @@ static int run_sharded_dev(zkv_ctx* c, size_t n, const DevRow* rows, int n_rows,
             if (d_recv) HIP_TRY(hipMemcpyPeerAsync(d_recv + 4 * lo, sdev, d.rv, kid->device, 4 * m, d.run));
         }
         HIP_TRY(hipEventRecord(d.ev_done, d.run));
+        d.has_done = true;
         return ZKV_OK;
     };
-    std::vector<std::thread> th;
-    for (size_t k = 1; k < used; k++) {
-        try { th.emplace_back([&, k] { rc[k] = one(k); }); } catch (const std::system_error&) { rc[k] = one(k); }
-    }
-    rc[0] = one(0);
-    for (auto& t : th) t.join();
+    shard_parallel(c, used, [&](size_t k) { rc[k] = one(k); });
     for (int r : rc) if (r != ZKV_OK) return r;
     if (caller) {                                     // ... and the caller's stream continues after every shard has delivered its statuses
         HIP_TRY(hipSetDevice(sdev));
@@ -841,6 +938,7 @@ static int run_sharded_dev(zkv_ctx* c, size_t n, const DevRow* rows, int n_rows,
     return ZKV_OK;
 }
 static void shards_free(zkv_ctx* c) {
+    shard_workers_stop(c);
     for (size_t k = 0; k < c->sh.size(); k++) {
         zkv_ctx::ShardDev& d = c->sh[k];
         if (!d.run) continue;
@@ -1774,6 +1872,7 @@ ZKV_EXPORT int zkv_ctx_set_aggregate_check(zkv_ctx* c, int enable, const uint8_t
             uint8_t sk[32];
             if (enable && seed32) { uint8_t buf[36]; memcpy(buf, seed, 32); buf[32] = (uint8_t)(k >> 24); buf[33] = (uint8_t)(k >> 16); buf[34] = (uint8_t)(k >> 8); buf[35] = (uint8_t)k; host::sha256_host(buf, 36, sk); }
             const int rc = zkv_ctx_set_aggregate_check(c->shards[k], enable, enable && seed32 ? sk : nullptr);
+            { volatile uint8_t* w = sk; for (int i = 0; i < 32; i++) w[i] = 0; }
             if (rc != ZKV_OK) return rc;
         }
         return ZKV_OK;
@@ -1783,20 +1882,27 @@ ZKV_EXPORT int zkv_ctx_set_aggregate_check(zkv_ctx* c, int enable, const uint8_t
             uint8_t sk[32];
             if (enable && seed32) { uint8_t buf[33]; memcpy(buf, seed, 32); buf[32] = (uint8_t)k; host::sha256_host(buf, 33, sk); }
             const int rc = zkv_ctx_set_aggregate_check(c->kid[k], enable, enable && seed32 ? sk : nullptr);
+            { volatile uint8_t* w = sk; for (int i = 0; i < 32; i++) w[i] = 0; }
             if (rc != ZKV_OK) return rc;
         }
         return ZKV_OK;
     }
     if (c->vm != ZKV_VM_RISC0 && c->vm != ZKV_VM_RISC0_SET && c->vm != ZKV_VM_SP1 && c->vm != ZKV_VM_GROTH16 && c->vm != ZKV_VM_SP1_PLONK)
         return enable ? ZKV_ERR_INVALID_ARG : ZKV_OK;
-    std::lock_guard<std::mutex> lk(c->mu);
-    c->agg_on = enable != 0;
-    if (enable) {
-        c->agg_auto = enable == 1; c->agg_sub = enable == 1 ? 32u : (uint32_t)enable;
-        c->agg_resnap = c->dev_ready;                           // counters of earlier runs (other sizes) are not this setting's evidence; a fresh context starts from zero
-        if (!c->dev_ready) c->agg_seen[0] = c->agg_seen[1] = 0;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->agg_on = enable != 0;
+        if (enable) {
+            c->agg_auto = enable == 1; c->agg_sub = enable == 1 ? 32u : (uint32_t)enable;
+            c->agg_resnap = c->dev_ready;                       // counters of earlier runs (other sizes) are not this setting's evidence; a fresh context starts from zero
+            if (!c->dev_ready) c->agg_seen[0] = c->agg_seen[1] = 0;
+            c->agg_pause = c->agg_pause_len = 0;
+            c->agg_os_seed = seed32 == nullptr; c->agg_key_age = 0;
+            for (int i = 0; i < 8; i++) c->agg_seed.w[i] = be32_of(seed + 4 * i);
+        }
     }
-    if (enable) for (int i = 0; i < 8; i++) c->agg_seed.w[i] = be32_of(seed + 4 * i);
+    volatile uint8_t* wipe = seed;                              // the secret does not stay on this stack
+    for (int i = 0; i < 32; i++) wipe[i] = 0;
     return ZKV_OK;
 }
 // {sub-batches checked, sub-batches that failed and were verified proof by proof} since the context was set up; the calling thread
@@ -1820,6 +1926,23 @@ ZKV_EXPORT int zkv_ctx_aggregate_counters(zkv_ctx* c, uint64_t out[2]) {
     unsigned long long v[2];
     HIP_TRY(hipMemcpy(v, c->d_agg_cnt, sizeof v, hipMemcpyDeviceToHost));
     out[0] = v[0]; out[1] = v[1];
+    return ZKV_OK;
+}
+ZKV_EXPORT int zkv_ctx_shard_peer_access(zkv_ctx* c, size_t shard) {
+    if (!c || !is_sharded(c) || shard >= c->sh.size()) return ZKV_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return c->sh[shard].peer;
+}
+ZKV_EXPORT int zkv_host_register(void* ptr, size_t bytes) {
+    if (!ptr || !bytes) return ZKV_ERR_INVALID_ARG;
+    if (zkv_device_count() < 1) return ZKV_ERR_NO_DEVICE;
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterPortable));
+    return ZKV_OK;
+}
+ZKV_EXPORT int zkv_host_unregister(void* ptr) {
+    if (!ptr) return ZKV_ERR_INVALID_ARG;
+    if (zkv_device_count() < 1) return ZKV_ERR_NO_DEVICE;
+    HIP_TRY(hipHostUnregister(ptr));
     return ZKV_OK;
 }
 ZKV_EXPORT int zkv_ctx_reserve(zkv_ctx* c, size_t n) {

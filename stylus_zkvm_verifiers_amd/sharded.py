@@ -32,3 +32,10 @@ def shard_count(verifier):
 def shard_devices(verifier):
     L = _lib.lib()
     return [int(L.zkv_ctx_shard_device(verifier._h, k)) for k in range(shard_count(verifier))]
+
+
+def shard_peer_access(verifier):
+    """Per shard: 1 = peer access to the GPU that held the last staged batch's rows was granted (direct xGMI copies), 0 = refused (bounced
+    copies), 2 = not applicable (same GPU, or nothing staged yet).  zkv_ctx_shard_peer_access."""
+    L = _lib.lib()
+    return [int(L.zkv_ctx_shard_peer_access(verifier._h, k)) for k in range(shard_count(verifier))]

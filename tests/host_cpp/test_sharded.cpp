@@ -34,6 +34,9 @@ int main(int argc, char** argv) {
     zkv_ctx* multi = zkv_risc0_ctx_create_multi(cr.data(), cid.data(), 1);
     printf("sharded=%d shards=%zu dev1=%d multi_shards=%zu no_mask=%d plain_shards=%zu ", sh != nullptr, zkv_ctx_shard_count(sh), zkv_ctx_shard_device(sh, 1),
            zkv_ctx_shard_count(multi), zkv_risc0_ctx_create_multi(cr.data(), cid.data(), 0) == nullptr, zkv_ctx_shard_count(other));
+    // peer access of a shard: 2 ("not applicable") until it has staged rows from another GPU; an index past the shards or a plain context is an error
+    printf("peer0=%d peer1=%d peer_bad_index=%d peer_plain=%d ", zkv_ctx_shard_peer_access(sh, 0), zkv_ctx_shard_peer_access(sh, 1),
+           zkv_ctx_shard_peer_access(sh, 2) < 0, zkv_ctx_shard_peer_access(other, 0) < 0);
     uint8_t sel[4] = {0, 0, 0, 0};
     zkv_risc0_get_selector(sh, sel);
     printf("selector=%02x%02x%02x%02x initialized=%d ", sel[0], sel[1], sel[2], sel[3], zkv_risc0_is_initialized(sh));

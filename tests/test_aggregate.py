@@ -506,7 +506,7 @@ def test_aggregate_check_on_the_golden_corpus(real_proofs, verify_corpus, monkey
 
 @pytest.mark.gpu
 def test_automatic_sub_batch_size_follows_the_failure_rate(real_proofs, monkeypatch):
-    """enable = 1: sub-batches of 32 at first; once the context is idle at the start of a call the counters decide -- one proof in 10 failing
+    """enable = 1: sub-batches of 32 at first; once the context is idle at the start of a call the counters decide -- one proof in 100 failing
     at the pairing brings 16, a run of valid batches 128.  Statuses stay the per-proof ones throughout."""
     import stylus_zkvm_verifiers_amd as zkv
     monkeypatch.setenv('ZKV_AGG_MIN', '64')
@@ -515,7 +515,7 @@ def test_automatic_sub_batch_size_follows_the_failure_rate(real_proofs, monkeypa
     v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
     v.set_aggregate_check(True)                                  # sub_batch = None: automatic
     n = 16384
-    seals, ids, jds, mut, _ = _risc0_inputs(real_proofs, n, 0x5A4B56B1, 10, classes=('flip_input',))
+    seals, ids, jds, mut, _ = _risc0_inputs(real_proofs, n, 0x5A4B56B1, 100, classes=('flip_input',))
     def run(s_, i_, j_):
         before = v.aggregate_counters()[0]
         st = _run_risc0_dev(v, s_, i_, j_)
@@ -526,4 +526,99 @@ def test_automatic_sub_batch_size_follows_the_failure_rate(real_proofs, monkeypa
     seals, ids, jds, mut, _ = _risc0_inputs(real_proofs, n, 0x5A4B56B2, 0)
     st, k = run(seals, ids, jds); assert (st == 0).all() and k == n // 16          # decided on what the last call showed
     st, k = run(seals, ids, jds); assert (st == 0).all() and k == n // 128
+    v.close()
+
+
+@pytest.mark.gpu
+def test_automatic_mode_pauses_the_check_while_most_sub_batches_fail(real_proofs, monkeypatch):
+    """enable = 1 under a stream of bad proofs (one in 4 fails at the pairing: 99 % of the sub-batches of 16 would be verified twice): the
+    check switches itself off for 8 chunks, probes once with size 16, stays off for 16 more, ... -- and comes back for good once the
+    proofs are valid again.  Statuses are the per-proof ones in every call."""
+    import stylus_zkvm_verifiers_amd as zkv
+    monkeypatch.setenv('ZKV_AGG_MIN', '64')
+    monkeypatch.setenv('ZKV_AGG_GROUP', '1')
+    r = real_proofs['risc0']
+    v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    v.set_aggregate_check(True)
+    n = 16384
+    bad = _risc0_inputs(real_proofs, n, 0x5A4B56D1, 4, classes=('flip_input',))
+    good = _risc0_inputs(real_proofs, n, 0x5A4B56D2, 0)
+    def run(b):
+        before = v.aggregate_counters()[0]
+        st = _run_risc0_dev(v, b[0], b[1], b[2])
+        v.synchronize()
+        assert ((st == 0) == ~b[3]).all()
+        return v.aggregate_counters()[0] - before
+    assert run(bad) == n // 32                                   # no evidence yet
+    ks = [run(bad) for _ in range(8 + 1 + 16 + 1)]
+    assert ks[:8] == [0] * 8 and ks[8] == n // 16, ks            # eight chunks without the check, then the probe
+    assert ks[9:25] == [0] * 16 and ks[25] == n // 16, ks        # still bad: twice as long a pause
+    ks = [run(good) for _ in range(32 + 1 + 3)]
+    assert ks[:32] == [0] * 32 and ks[32] == n // 16, ks         # the pause that was decided on the bad stream, then the probe on the good one
+    assert all(k > 0 for k in ks[33:]), ks                       # the check is back (and grows its sub-batches: fewer of them per call)
+    v.close()
+
+
+@pytest.mark.gpu
+def test_aggregate_check_rekeys_an_os_drawn_secret(real_proofs, monkeypatch):
+    """seed32 = NULL: the secret comes from getrandom and is drawn afresh every ZKV_AGG_REKEY chunks (default 1,024; 2 here, with 64-proof
+    chunks, so that a 1,000-proof batch passes through eight secrets): statuses as without the check."""
+    import stylus_zkvm_verifiers_amd as zkv
+    monkeypatch.setenv('ZKV_AGG_MIN', '64')
+    monkeypatch.setenv('ZKV_AGG_REKEY', '2')
+    monkeypatch.setenv('ZKV_CHUNK', '64')
+    r = real_proofs['risc0']
+    v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    n = 1000
+    seals, ids, jds, mut, _ = _risc0_inputs(real_proofs, n, 0x5A4B56D3, 9)
+    plain = _run_risc0_dev(v, seals, ids, jds)
+    v.set_aggregate_check(True, sub_batch=16)                    # seed = None: operating system
+    agg = _run_risc0_dev(v, seals, ids, jds)
+    assert (agg == plain).all() and ((agg == 0) == ~mut).all() and v.aggregate_counters()[0] == (n // 64) * 4       # the last, 40-proof chunk is below ZKV_AGG_MIN
+    v.close()
+
+
+@pytest.mark.gpu
+def test_cancelling_pairs_are_rejected_because_every_proof_has_its_own_coefficient(real_proofs, monkeypatch):
+    """What the soundness of the aggregate check rests on: DISTINCT secret coefficients per proof.  Two copies of a valid proof with C + D and
+    C - D in place of C are both invalid, but e(C + D, delta) e(C - D, delta) = e(C, delta)^2: with EQUAL coefficients the pair's errors
+    cancel and any aggregate check passes.  Such pairs are placed in the same sub-batch and in the same Miller group -- members l and
+    l + 32 of a 64-proof block (one group for 2, 4 or 8 proofs per accumulator) and neighbours 2k, 2k + 1 (one sub-batch for contiguous
+    sub-batches) -- for every group size and sub-batch size: all of them must be rejected, the valid proofs between them accepted, and
+    the counters must show failed sub-batches."""
+    import numpy as np
+    import stylus_zkvm_verifiers_amd as zkv
+    from stylus_zkvm_verifiers_amd import synth
+    monkeypatch.setenv('ZKV_AGG_MIN', '64')
+    r = real_proofs['risc0']
+    n = 512
+    seals, ids, jds, mut, _ = _risc0_inputs(real_proofs, n, 0x5A4B56D4, 0)
+    seals = np.ascontiguousarray(seals).copy()
+    rng = synth.SplitMix64(0xD1FF)
+    bad = np.zeros(n, dtype=bool)
+    def twist(i, j):
+        # proofs i and j become copies of proof i with C + D and C - D
+        a, b, c = synth.parse_seal(seals[i].tobytes())
+        d = synth.g1_mul((1, 2), rng.scalar())
+        nd = (d[0], (-d[1]) % synth.P)
+        for row, cc in ((i, synth.g1_add(c, d)), (j, synth.g1_add(c, nd))):
+            synth._write(seals, row, seals[i, :4].tobytes(), synth.seal_words(a, b, cc))
+            bad[row] = True
+    for blk in range(0, n, 64):
+        for l in (1, 5, 12, 30):
+            twist(blk + l, blk + l + 32)
+        for k in (8, 9, 20):
+            twist(blk + 2 * k, blk + 2 * k + 1)
+    v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+    plain = _run_risc0_dev(v, seals, ids, jds)
+    assert ((plain == 0) == ~bad).all() and (plain[bad] == 1).all() and bad.sum() == 8 * 14
+    for g in (1, 2, 4, 8):
+        monkeypatch.setenv('ZKV_AGG_GROUP', str(g))
+        for sub in (16, 32, 64, 128, 256):
+            before = v.aggregate_counters() if g != 1 or sub != 16 else (0, 0)
+            v.set_aggregate_check(True, seed=bytes([g, sub & 255]) * 16, sub_batch=sub)
+            agg = _run_risc0_dev(v, seals, ids, jds)
+            after = v.aggregate_counters()
+            assert (agg == plain).all(), (g, sub, np.flatnonzero(agg != plain)[:8])
+            assert after[1] > before[1], (g, sub)
     v.close()

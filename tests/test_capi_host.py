@@ -89,6 +89,10 @@ def test_no_cpu_fallback(z, real_proofs):
 def test_argument_validation(z):
     from stylus_zkvm_verifiers_amd import _lib
     L = _lib.lib()
+    assert L.zkv_host_register(None, 16) == _lib.ERR_INVALID_ARG and L.zkv_host_unregister(None) == _lib.ERR_INVALID_ARG
+    if z.device_count() == 0:                   # pinning is a device-runtime service: no device, no silent success
+        buf = C.create_string_buffer(4096)
+        assert L.zkv_host_register(C.addressof(buf), 4096) == _lib.ERR_NO_DEVICE
     assert L.zkv_risc0_get_selector(None, C.create_string_buffer(4)) == _lib.ERR_WRONG_CTX
     sp = z.Sp1Verifier()
     assert L.zkv_risc0_get_selector(sp._h, C.create_string_buffer(4)) == _lib.ERR_WRONG_CTX

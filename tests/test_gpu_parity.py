@@ -769,6 +769,36 @@ def test_host_batches_in_several_passes_and_segments(zkv, r0, sp1, real_proofs, 
     assert (want == 0).sum() > 500 and (swant == 0).sum() > 300 and len(set(want)) >= 3
 
 
+def test_pinned_host_buffers_give_the_same_statuses(zkv, r0, real_proofs):
+    """zkv_host_register: a 3,000-proof RISC Zero batch handed over from buffers the caller pinned beforehand (direct DMA staging) returns
+    the bytes the same call returns from pageable memory."""
+    from stylus_zkvm_verifiers_amd import _lib, synth
+    L = _lib.lib()
+    r = real_proofs['risc0']
+    n = 3000
+    seals, mut, _, flip = synth.make_batch('risc0', H(r['seal']), n, 0x5A4B56C1, pool=4, mutate_every=9)
+    seals = np.ascontiguousarray(seals)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(seals.shape[1])
+    ids = np.tile(np.frombuffer(H(r['image_id']), dtype=np.uint8), (n, 1)).copy()
+    jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (n, 1)).copy()
+    jds[flip, 0] ^= 1
+    st_a, st_b = np.full(n, 255, dtype=np.uint8), np.full(n, 255, dtype=np.uint8)
+    rv_a, rv_b = np.zeros(4 * n, dtype=np.uint8), np.zeros(4 * n, dtype=np.uint8)
+    call = lambda st, rv: _lib.check(L.zkv_risc0_verify_batch(r0._h, n, seals.ctypes.data, off.ctypes.data, ids.ctypes.data, jds.ctypes.data,
+                                                              st.ctypes.data, rv.ctypes.data), 'batch')
+    call(st_a, rv_a)
+    bufs = [seals, off, ids, jds, st_b, rv_b]
+    for x in bufs:
+        zkv.host_register(x)
+    try:
+        call(st_b, rv_b)
+    finally:
+        for x in bufs:
+            zkv.host_unregister(x)
+    assert (st_a == st_b).all() and (rv_a == rv_b).all()
+    assert ((st_a == 0) == ~mut).all() and 0 < mut.sum() < n
+
+
 def test_device_calldata_with_corrupt_offsets_is_never_read(zkv, r0, real_proofs):
     """zkv_eth_call_batch_dev takes its offsets from device memory: requests whose offsets run backwards or leave the blob get
     BAD_CALLDATA without being dereferenced; their neighbours are unaffected."""

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 H = bytes.fromhex
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -473,3 +474,24 @@ def test_rccl_backend_initialises_and_a_step_runs_under_it(zkv):
     ok = q.get(timeout=600)
     p.join(timeout=120)
     assert ok is True and p.exitcode == 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsed_on_one_gpu_prints_one_json_line():
+    """`python bench.py --gpus 2 --rehearse-single-gpu` end to end, as the driver would start the N > 1 bench (a fresh process that
+    launches its ranks itself; both ranks on cuda:0, collectives over gloo): exactly ONE JSON line on stdout, n_gpus = 2, config 4
+    (mixed), accept <=> construction on every rank.  (No 8-GPU node is available to this build: this is the whole multi-rank path short
+    of RCCL with more than one real device.)"""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rehearse-single-gpu', '--steps', '1', '--warmup', '1', '--proofs', '8192',
+                        '--no-cpu-baseline', '--no-mulmod'], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['steps'] == 1 and j['config']['workload'] == 'mixed' and j['scaling'] == 'weak'
+    assert j['parity']['accept_reject_matches_construction'] is True
+    assert j['value'] > 0 and j['config']['global_batch'] == 2 * 8192

@@ -30,6 +30,7 @@ def test_sharded_creation_rules_through_the_c_abi(real_proofs):
     for k in ('refuse_mixed_kinds', 'refuse_duplicate', 'refuse_uninitialised', 'refuse_different_params', 'refuse_empty', 'sharded', 'no_mask'):
         assert kv[k] == '1', k
     assert (kv['shards'], kv['dev1'], kv['multi_shards'], kv['plain_shards']) == ('2', '0', '1', '0')
+    assert (kv['peer0'], kv['peer1'], kv['peer_bad_index'], kv['peer_plain']) == ('2', '2', '1', '1')       # zkv_ctx_shard_peer_access
     assert kv['selector'] == real_proofs['risc0']['selector'] and kv['initialized'] == '1'
     if 'rc_no_device' in kv:
         assert kv['rc_no_device'] == '-2'                 # ZKV_ERR_NO_DEVICE from the shards: no CPU fallback
@@ -41,7 +42,7 @@ def test_python_shard_wrapper_host_side(real_proofs):
     mk = lambda: (lambda v: (v.initialize(H(r['control_root']), H(r['bn254_control_id'])), v)[1])(z.RiscZeroVerifier(0))
     a, b = mk(), mk()
     s = z.shard([a, b])
-    assert a._h is None and b._h is None and z.shard_count(s) == 2 and z.shard_devices(s) == [0, 0]
+    assert a._h is None and b._h is None and z.shard_count(s) == 2 and z.shard_devices(s) == [0, 0] and z.shard_peer_access(s) == [2, 2]
     assert s.get_selector().hex() == r['selector'] and s.is_initialized()
     with pytest.raises(ValueError):
         z.shard([mk(), z.Sp1Verifier(0)])
@@ -160,6 +161,46 @@ def test_sharded_device_batches_equal_single_device(zkv, real_proofs, staging):
     finally:
         for k in env:
             del os.environ[k]
+
+
+@pytest.mark.gpu
+def test_back_to_back_staged_batches_do_not_overwrite_each_other(zkv, real_proofs):
+    """Two DIFFERENT HBM-resident batches enqueued back to back on a sharded verifier with no caller stream (NULL: the shards' own
+    streams), both through the staging rows a shard on another GPU uses (ZKV_SHARD_FORCE_STAGING): the second call's copies into those
+    rows must wait for the first call's kernels.  After one zkv_ctx_synchronize both status arrays are the construction's; repeated
+    a few times, and with many small calls in flight."""
+    import torch
+    from stylus_zkvm_verifiers_amd import synth
+    env = {'ZKV_SHARD_MIN': '256', 'ZKV_SHARD_FORCE_STAGING': '1'}
+    os.environ.update(env)
+    try:
+        dev = torch.device('cuda', 0)
+        s = real_proofs['sp1']
+        k = 6000
+        up = lambda *xs: [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in xs]
+        batches = []
+        for seed, every in ((0x5A4B56E1, 3), (0x5A4B56E2, 5), (0x5A4B56E3, 2)):
+            seals, mut, _, flip = synth.make_batch('sp1', H(s['proof']), k, seed, pool=4, mutate_every=every)
+            vk = np.tile(np.frombuffer(H(s['vkey']), dtype=np.uint8), (k, 1))
+            pv = np.tile(np.frombuffer(H(s['public_values']), dtype=np.uint8), (k, 1)); pv[flip, -1] ^= 1
+            batches.append((up(vk, pv, seals), mut, torch.full((k,), 255, dtype=torch.uint8, device=dev)))
+        torch.cuda.synchronize()
+        v = zkv.shard([zkv.Sp1Verifier(0), zkv.Sp1Verifier(0), zkv.Sp1Verifier(0)])
+        for rep in range(3):
+            for d, mut, st in batches:
+                st.fill_(255)
+            torch.cuda.synchronize()
+            for d, mut, st in batches:                              # no synchronisation between the calls
+                v.verify_batch_dev(k, d[0].data_ptr(), d[1].data_ptr(), 96, d[2].data_ptr(), st.data_ptr(), 0, 0)
+            v.synchronize()
+            for j, (d, mut, st) in enumerate(batches):
+                got = st.cpu().numpy()
+                assert ((got == 0) == ~mut).all(), (rep, j, int(((got == 0) != ~mut).sum()))
+        assert zkv.shard_peer_access(v) == [2, 2, 2]             # every shard on the source GPU: no peer access was needed
+        v.close()
+    finally:
+        for kk in env:
+            del os.environ[kk]
 
 
 @pytest.mark.gpu
