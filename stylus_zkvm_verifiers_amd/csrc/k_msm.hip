@@ -9,20 +9,16 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_msm(size_t n, const VkTables* __r
     if (i >= n) return;
     uint32_t flags = ws.flags[i];
     if (!(flags & FL_ALIVE)) return;
+    // the scalars' window digits are read from the proof's workspace row as the walk needs them (L1 / L2 hits: 64 bytes per proof)
+    auto word = [&](uint32_t b, uint32_t k) { return ws.prep[(size_t)(64 + 8 * b + k) * ws.cap + i]; };
+    const G1A* base = &vk->base; uint32_t base_inf = vk->base_inf;
+    if (inst_tab) { const InstTab& t = inst_tab[flags >> 8]; flags &= 0xFFu; base = &t.base; base_inf = t.base_inf; }     // verifier set: the instance index rides in the upper bits of the flags word
+    const G1J acc = msm_accumulate_w(*vk, word, *base, base_inf);
     PrepOut in;
     in.ax = ws_ld(ws.prep, ws.cap, 0, i); in.ay = ws_ld(ws.prep, ws.cap, 8, i);
     in.cx = ws_ld(ws.prep, ws.cap, 16, i); in.cy = ws_ld(ws.prep, ws.cap, 24, i);
-#pragma unroll 1
-    for (uint32_t b = 0; b < vk->n_var; b++) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) in.s[b][k] = ws.prep[(size_t)(64 + 8 * b + k) * ws.cap + i];
-    }
     G1Norm o;
-    if (inst_tab) {                          // verifier set: the instance index rides in the upper bits of the flags word
-        const InstTab& t = inst_tab[flags >> 8];
-        flags &= 0xFFu;
-        msm_normalize(*vk, in, flags, o, t.base, t.base_inf);
-    } else msm_normalize(*vk, in, flags, o);
+    msm_normalize_acc(acc, in, flags, o);
     ws_st(ws.norm, ws.cap, 0, i, o.axs); ws_st(ws.norm, ws.cap, 8, i, o.ays);
     ws_st(ws.norm, ws.cap, 16, i, o.lxs); ws_st(ws.norm, ws.cap, 24, i, o.lys);
     ws_st(ws.norm, ws.cap, 32, i, o.cxs); ws_st(ws.norm, ws.cap, 40, i, o.cys);
@@ -88,14 +84,15 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_vk_x(size_t n, const VkTables* __
                                                      const uint32_t* __restrict__ inst, const uint8_t* __restrict__ sig, uint8_t* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (i >= n) return;
-    PrepOut in;
     const uint32_t nv = vk->n_var;                                  // 2 for the RISC Zero / SP1 keys, n_ic - 1 for a generic key
-#pragma unroll 1
-    for (uint32_t b = 0; b < MAX_VAR; b++) {
-        if (b < nv) load_be256(in.s[b], sig + 32 * ((size_t)nv * i + b));
-        else for (int k = 0; k < 8; k++) in.s[b][k] = 0;
-    }
-    G1J acc = inst_tab ? msm_accumulate(*vk, in, inst_tab[inst[i]].base, inst_tab[inst[i]].base_inf) : msm_accumulate(*vk, in);
+    // limb k (least significant first) of the big-endian 32-byte signal b, read where the window walk needs it
+    auto word = [&](uint32_t b, uint32_t k) {
+        const uint8_t* q = sig + 32 * ((size_t)nv * i + b) + 4 * (7 - k);
+        return ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+    };
+    const G1A* base = &vk->base; uint32_t base_inf = vk->base_inf;
+    if (inst_tab) { const InstTab& t = inst_tab[inst[i]]; base = &t.base; base_inf = t.base_inf; }
+    G1J acc = msm_accumulate_w(*vk, word, *base, base_inf);
     G1A a; uint32_t inf;
     g1j_to_affine(acc, a, inf);
     uint32_t r[8];

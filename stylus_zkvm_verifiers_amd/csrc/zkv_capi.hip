@@ -164,7 +164,28 @@ static size_t msm_wave_below() {
 }
 static size_t wide_below() {
     const char* e = getenv("ZKV_WIDE_BELOW");
-    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)8192;
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)12288;     // round 4 (profiles/round4_batch_sweep.txt): 16 lanes 6.9-7.2 ms against 7.3 for lane pairs up to here, 8.7 beyond
+}
+// One lane-pair wavefront holds 32 proofs and a SIMD holds two wavefronts: a launch of up to 32,768 proofs puts one wavefront on
+// every SIMD (7.4 ms for the Miller loop and the final exponentiation together), the next 32,768 a second one (10.9 ms).  A chunk that
+// only just starts a new layer -- 32,768 k + r proofs with a small r -- would pay a whole wavefront's latency for r proofs; instead the
+// last r proofs run AFTER the others through the mapping their own number selects (one proof per wavefront, 16 lanes per proof: 2-3.5 ms).
+// Worth it up to r = ZKV_TAIL_SPLIT_BELOW (default 3,072: 7.4 + 3.5 against 10.9 ms), for chunks of up to 2^18 proofs (beyond that the
+// last layer is a few per cent of the launch).  0 disables.
+static size_t tail_split_below() {
+    const char* e = getenv("ZKV_TAIL_SPLIT_BELOW");
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)3072;
+}
+static size_t tail_of_chunk(size_t n) {
+    const size_t layer = 32768, r = n % layer;
+    return (n > layer && n <= ((size_t)1 << 18) && r && r <= tail_split_below()) ? r : 0;
+}
+// The workspace rows of proofs [off, off + ...) of a chunk: word k of proof i sits at base[k * cap + i], so the same capacity with every
+// base advanced by `off` elements addresses them as proofs 0, 1, ...
+static Workspace ws_from(const Workspace& ws, size_t off) {
+    Workspace w = ws;
+    w.prep += off; w.norm += off; w.f += off; w.fe += off; w.flags += off; w.g2bad += off;
+    return w;
 }
 // Chunks of at most this many proofs run the Miller loop and the final exponentiation with ONE PROOF PER WAVEFRONT (k_miller_w64 /
 // k_finalexp_w64: four slices of 16 lanes; 1,024 proofs are one wavefront on every SIMD of the chip, 2,048 two).  Measured (RISC Zero,
@@ -596,6 +617,24 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     else launch_prep_sp1(a, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[1], s);
     if (c->agg_on && c->agg_key_ok && c->agg_cap >= c->ws.cap && c->lanes == 0 && a.n >= agg_min() && agg_wanted(c)) { enqueue_agg(c, a, s, timed); return; }
+    const size_t tail = c->lanes == 0 ? tail_of_chunk(a.n) : 0;
+    if (tail) {
+        // all proofs through the vk_x stage, then the Miller loops and final exponentiations of the first a.n - tail proofs on lane pairs and
+        // of the last `tail` through their own small-batch mapping (whose Miller kernels leave the subgroup test of B to k_g2chk2)
+        const size_t head = a.n - tail;
+        const Workspace wt = ws_from(c->ws, head);
+        launch_msm(a.n, c->d_tab, a.inst ? c->d_inst : nullptr, c->ws, s);
+        if (timed) (void)hipEventRecord(c->ev[2], s);
+        launch_g2chk2(tail, wt, a.status + head, s);
+        if (timed) (void)hipEventRecord(c->ev[3], s);
+        launch_miller2(head, c->d_tab, c->ws, a.status, s);
+        launch_miller_by_size(c, tail, wt, a.status + head, s);
+        if (timed) (void)hipEventRecord(c->ev[4], s);
+        launch_finalexp2(head, c->ws, a.status, s);
+        launch_finalexp_by_size(tail, wt, a.status + head, s);
+        if (timed) (void)hipEventRecord(c->ev[5], s);
+        return;
+    }
     const int lanes = c->lanes ? c->lanes : 2;       // 2 = one proof per lane pair; 16 = one proof per 16 lanes (small chunks); 64 = per wavefront (smallest)
     const bool dual = lanes == 128 || (c->lanes == 0 && a.n <= dual_below());       // 128 = two wavefronts per proof in the Miller loop
     const bool wave = dual || lanes == 64 || (c->lanes == 0 && a.n <= wave_below());

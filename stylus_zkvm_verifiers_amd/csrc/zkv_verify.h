@@ -157,7 +157,9 @@ ZKV_HD void risc0_split_digest(const uint32_t h[8], uint32_t lo[8], uint32_t hi[
 // ---------------------------------------------------------------- stage MSM + G1 normalisation
 // vk_x = base + sum_b s_b * IC_var[b] (groth16.rs:51-58), then x/y and 1/y of A', L, C with one inversion.
 // `base` = IC[0] + the per-verifier-instance signals: the context's own (vk.base) or, for a verifier set, the instance's.
-ZKV_HD G1J msm_accumulate(const VkTables& vk, const PrepOut& in, const G1A& base, uint32_t base_inf) {
+// word(b, k): limb k of the per-proof scalar b.  The kernels read it from the proof's workspace row where it is needed (a private copy of
+// the scalars, indexed by the run-time b, was k_msm's 432-byte scratch frame); the host builds and k_vk_x pass their PrepOut.
+template <class WORD> ZKV_HD G1J msm_accumulate_w(const VkTables& vk, WORD word, const G1A& base, uint32_t base_inf) {
     G1J acc;
     if (base_inf) acc = g1j_infinity();
     else { acc.x = base.x; acc.y = base.y; acc.z = fp_one(); }
@@ -165,7 +167,7 @@ ZKV_HD G1J msm_accumulate(const VkTables& vk, const PrepOut& in, const G1A& base
     for (uint32_t b = 0; b < vk.n_var; b++) {
 #pragma unroll 1
         for (uint32_t w = 0; w < vk.var_windows[b]; w++) {
-            uint32_t d = (in.s[b][w >> 2] >> ((w & 3) * 8)) & 255u;
+            uint32_t d = (word(b, w >> 2) >> ((w & 3) * 8)) & 255u;
             if (d) {
                 const G1A& e = vk.msm[b][w][d];
                 acc = g1j_add_affine(acc, e.x, e.y);
@@ -173,6 +175,9 @@ ZKV_HD G1J msm_accumulate(const VkTables& vk, const PrepOut& in, const G1A& base
         }
     }
     return acc;
+}
+ZKV_HD G1J msm_accumulate(const VkTables& vk, const PrepOut& in, const G1A& base, uint32_t base_inf) {
+    return msm_accumulate_w(vk, [&](uint32_t b, uint32_t k) { return in.s[b][k]; }, base, base_inf);
 }
 ZKV_HD G1J msm_accumulate(const VkTables& vk, const PrepOut& in) { return msm_accumulate(vk, in, vk.base, vk.base_inf); }
 ZKV_HD void msm_normalize_acc(const G1J& acc, const PrepOut& in, uint32_t& flags, G1Norm& out);

@@ -159,6 +159,10 @@ def test_hot_kernels_keep_their_resources(z):
         assert int(r['ScratchSize [bytes/lane]']) == 0 and int(r['VGPRs Spill']) == 0, (name, r)
         assert int(r['Occupancy [waves/SIMD]']) >= 2 and int(r['AGPRs']) == 0, (name, r)
         assert int(r['LDS Size [bytes/block]']) <= 18432, (name, r)
+    # round 4: the vk_x stage keeps no private copy of the scalars any more (432 bytes of scratch per lane until then)
+    for name, r in rep.items():
+        if 'k_msmE' in name or 'k_vk_x' in name:
+            assert int(r['ScratchSize [bytes/lane]']) == 0 and int(r['VGPRs Spill']) == 0, (name, r)
     # the small-batch kernels of round 3: the two-wavefront Miller kernels keep everything in registers and LDS, and none of the
     # kernels of that translation unit may push the inversion they share into AGPRs (that cost k_finalexp_w its second wavefront once)
     small = {k: v for k, v in rep.items() if 'w64' in k or 'k_miller_w' in k or 'k_finalexp_w' in k}

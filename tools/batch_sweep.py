@@ -24,15 +24,16 @@ def main():
     args = ap.parse_args()
     import bench
     g = bench.golden()
-    host = bench.synthesize('risc0', args.max, 0x5A4B5601, g, 64)
+    sizes = [int(x) for x in args.sizes.split(',')] if args.sizes else [1, 256, 512, 768] + list(range(args.step, args.max + 1, args.step))
+    host = bench.synthesize('risc0', max(sizes), 0x5A4B5601, g, 64)          # the device rows cover the largest size: never read past them
     import torch
     dev = torch.device('cuda', 0)
     sh = bench.Shard(host, dev, g)
     ts_stream = torch.cuda.Stream()            # a stream of its own: handle 0 (the default stream) would mean "the context's stream" to the library
     torch.cuda.set_stream(ts_stream)
     stream = ts_stream.cuda_stream
-    sizes = [int(x) for x in args.sizes.split(',')] if args.sizes else [1, 256, 512, 768] + list(range(args.step, args.max + 1, args.step))
     lanes = [int(x) for x in args.lanes.split(',')]
+    assert max(sizes) <= sh.n
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     rows = []
     for n in sizes:
