@@ -335,6 +335,11 @@ int zkv_ctx_aggregate_counters(zkv_ctx* ctx, uint64_t out[2]);
  * batch call.  Optional: every batch entry point does this on demand; the buffers (about 3.7 KB per proof in flight) grow to the
  * largest batch seen, at most ZKV_CHUNK proofs (environment, default 2^20; larger batches run chunk by chunk). */
 int zkv_ctx_reserve(zkv_ctx* ctx, size_t n);
+/* The two-wavefront small-batch kernels (chunks of at most ZKV_DUAL_BELOW proofs; ecPairing calls in small batches) let one wavefront wait for
+ * another with a BOUNDED spin (about half a second; nothing can hang).  A wait that runs out -- only a wavefront that died can cause it -- fails
+ * closed: the proof / call is reported as failing, never as accepted.  So that such an event is not mistaken for a verdict, it is counted per device
+ * since the library was loaded; out = that count (0 in every run so far; the tests assert it).  Synchronise first. */
+int zkv_diag_wait_faults(int device, uint64_t* out);
 /* Sharded context, device-resident batches: how shard `shard` reaches the GPU that held the rows of the last batch it staged --
  * 1: peer access granted (hipDeviceEnablePeerAccess: the range travels as direct xGMI copies), 0: refused (the runtime bounces the
  * copies through the host), 2: not applicable so far (the shard sits on the source GPU, or it has staged nothing yet).

@@ -72,6 +72,7 @@ SYMBOLS = {
     'zkv_ctx_set_aggregate_check': (_i, [_vp, _i, _cp]),
     'zkv_ctx_aggregate_counters': (_i, [_vp, C.POINTER(C.c_uint64)]),
     'zkv_ctx_reserve': (_i, [_vp, _sz]),
+    'zkv_diag_wait_faults': (_i, [_i, C.POINTER(C.c_uint64)]),
     'zkv_ctx_shard_peer_access': (_i, [_vp, _sz]),
     'zkv_host_register': (_i, [_vp, _sz]),
     'zkv_host_unregister': (_i, [_vp]),

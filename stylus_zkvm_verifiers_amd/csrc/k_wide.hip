@@ -79,6 +79,17 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_finalexp_w64(size_t n, Workspa
     finalexp_w_body<4>(n, ws, status, lds);
 }
 
+// A consumer wavefront that gave up waiting for its producer (miller_lines_wait's spin bound: about half a second -- only a wavefront that died can
+// cause it) fails CLOSED: the proof is reported as failing, never as accepted.  So that such an event is not mistaken for a verdict on the proof,
+// it is also counted here; zkv_diag_wait_faults (C ABI) reads the counter, and the tests and the bench assert that it stays zero.
+__device__ unsigned int g_zkv_wait_faults = 0;
+int read_wait_faults(unsigned long long* out) {
+    unsigned int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_zkv_wait_faults), sizeof v) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    *out = v;
+    return 0;
+}
+
 // Two wavefronts per proof (workgroup of 128 lanes): wavefront 1 steps the running point and tabulates the line coefficients, wavefront 0
 // accumulates f (miller_lines_producer / miller_loop_consumer, zkv_tower_wide.h).  For chunks of at most ZKV_DUAL_BELOW proofs.
 __global__ __launch_bounds__(128, 2) void k_miller_w64d(size_t n, const VkTables* __restrict__ vk, Workspace ws, uint8_t* __restrict__ status) {
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(128, 2) void k_miller_w64d(size_t n, const VkTables
     uint32_t* base = lds + 8 * half;
     MRef fm = m_ref(base, 1, 16), sc = m_ref(base + 96, 1, 16), red = m_ref(base + 160, 1, 16);
     if (!miller_loop_consumer<4>(vk, flags, nm, fm, sc, lines, ready, w, red)) {
-        if (lane == 0) { ws.g2bad[i] = 1; status[i] = ST_VERIFICATION_FAILED; }     // unreachable unless the producer wavefront died
+        if (lane == 0) { ws.g2bad[i] = 1; status[i] = ST_VERIFICATION_FAILED; atomicAdd(&g_zkv_wait_faults, 1u); }     // unreachable unless the producer wavefront died: fail closed, and count it
         return;
     }
     MRef ab = m_ref((uint32_t*)(vk->f_alpha_beta) + 8 * half, 1, 16);
@@ -195,6 +206,7 @@ __global__ __launch_bounds__(128, 2) void k_pairing_pair_w64d(size_t n, uint32_t
         // for P = infinity only the point is stepped (no line products): the pair contributes 1 but Q is still judged
         bool fine = miller_loop_consumer<4>((const VkTables*)nullptr, pinf ? (uint32_t)FL_A_INF : 0u, nm, fm, sc, lines, ready, w, red);
         fine = miller_lines_wait(ready, (uint32_t)(ZKV_MILLER_STEPS + 1)) && fine;
+        if (!fine && lane == 0) atomicAdd(&g_zkv_wait_faults, 1u);          // the producer vanished (see g_zkv_wait_faults): the call fails closed
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         okj = fine && *verdict != 0;
         if (okj && !pinf) w12_mul<4>(P, P, fm, w, false, red);

@@ -1967,6 +1967,16 @@ ZKV_EXPORT int zkv_ctx_aggregate_counters(zkv_ctx* c, uint64_t out[2]) {
     out[0] = v[0]; out[1] = v[1];
     return ZKV_OK;
 }
+ZKV_EXPORT int zkv_diag_wait_faults(int device, uint64_t* out) {
+    if (!out) return ZKV_ERR_INVALID_ARG;
+    *out = 0;
+    if (device < 0 || device >= zkv_device_count()) return ZKV_ERR_NO_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long v = 0;
+    if (zkv::read_wait_faults(&v) != 0) return ZKV_ERR_HIP;
+    *out = v;
+    return ZKV_OK;
+}
 ZKV_EXPORT int zkv_ctx_shard_peer_access(zkv_ctx* c, size_t shard) {
     if (!c || !is_sharded(c) || shard >= c->sh.size()) return ZKV_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);

@@ -117,6 +117,8 @@ struct PlonkKeyRaw; struct PlonkKey;
 void launch_plonk_setup(const PlonkKeyRaw* d_raw, PlonkKey* d_key, hipStream_t s);
 void launch_plonk_prep(const PrepArgs& a, const PlonkKey* d_key, const Workspace& ws, hipStream_t s);
 
+// k_wide.hip: consumer wavefronts that timed out waiting for their producer on the current device (always 0 unless a wavefront died)
+int read_wait_faults(unsigned long long* out);
 // multiplication-rate microbenchmark (k_diag.hip)
 void launch_diag_mulmod(int kind, unsigned blocks, uint32_t iters, uint32_t* out, unsigned long long* clk, hipStream_t s);
 void launch_diag_issue(int kind, unsigned blocks, uint32_t iters, uint32_t* out, unsigned long long* clk, hipStream_t s);

@@ -90,6 +90,9 @@ def test_argument_validation(z):
     from stylus_zkvm_verifiers_amd import _lib
     L = _lib.lib()
     assert L.zkv_host_register(None, 16) == _lib.ERR_INVALID_ARG and L.zkv_host_unregister(None) == _lib.ERR_INVALID_ARG
+    if z.device_count() == 0:
+        out = C.c_uint64(7)
+        assert L.zkv_diag_wait_faults(0, C.byref(out)) == _lib.ERR_NO_DEVICE and out.value == 0
     if z.device_count() == 0:                   # pinning is a device-runtime service: no device, no silent success
         buf = C.create_string_buffer(4096)
         assert L.zkv_host_register(C.addressof(buf), 4096) == _lib.ERR_NO_DEVICE

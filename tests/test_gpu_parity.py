@@ -96,6 +96,22 @@ def test_context_cases(zkv, verify_corpus):
         v.close()
 
 
+def test_no_wavefront_ever_gave_up_waiting(zkv, r0, real_proofs):
+    """zkv_diag_wait_faults: the two-wavefront kernels fail closed when a consumer's bounded wait for its producer runs out, and count it.
+    After a few hundred single and small-batch verifications (the kernels in question) the count is still zero: every reject in this suite
+    is a verdict, none a timeout."""
+    import ctypes as C
+    from stylus_zkvm_verifiers_amd import _lib
+    r = real_proofs['risc0']
+    for _ in range(8):
+        assert r0.verify(H(r['seal']), H(r['image_id']), H(r['journal_digest'])) is True
+    st, _ = r0.verify_batch([H(r['seal'])] * 300, [H(r['image_id'])] * 300, [H(r['journal_digest'])] * 300)
+    assert (st == 0).all()
+    out = C.c_uint64(123)
+    _lib.check(_lib.lib().zkv_diag_wait_faults(0, C.byref(out)), 'zkv_diag_wait_faults')
+    assert out.value == 0
+
+
 def test_empty_batch(r0, sp1):
     st, rv = r0.verify_batch([], [], [])
     assert len(st) == 0
