@@ -150,30 +150,56 @@ template <int S> ZKV_W_NI void w12_sqr(MRef f, WL wl, MRef red) {
 }
 // f <- f^2 for f in the cyclotomic subgroup (Granger-Scott): pair q needs one Fp4 squaring (A + B y)^2, y^2 = xi.
 // S = 4: the two products of the Fp4 squaring (A B and (A + B)(xi B + A)) are formed by the even and the odd slices side by side.
+// Round 4: the arithmetic of a step runs on 29-bit limbs (zkv_field.h "L9"): the three coefficients are unpacked once, the two operands of
+// the second product and the WHOLE result -- 3 (s - (1 + xi) ab) - 2z, or 6 ab + 2z, or 3 xi (2 ab) + 2z for pair 3 -- are one-pass linear
+// combinations with per-lane coefficients (the instruction stream stays uniform), and the result is packed once.  A step was two
+// xi-multiplications and three modular additions in front of the product and two xi-multiplications and eight additions behind it, each
+// a carry chain: about 900 instructions on the 189-step dependent chain of a single verification, now about 650.
 template <int S> ZKV_W_NI void w12_cyclo_sqr(MRef f, WL w, MRef red) {
     const int q = w.q;
     const int ia = (q == 0 || q == 4) ? 0 : (q == 2 || q == 3) ? 1 : 3;
     const int ib = ia == 0 ? 4 : ia == 1 ? 5 : 2;
     const bool odd = q >= 3;                              // this pair's result uses 2AB, otherwise A^2 + xi B^2
-    Fp2 A = m_ld_f2(f, ia), B = m_ld_f2(f, ib), z = m_ld_f2(f, q);
-    Fp2 ab, s;
+    const L9 A = l9_from_fp(m_ld_f2(f, ia).h), B = l9_from_fp(m_ld_f2(f, ib).h), z = l9_from_fp(m_ld_f2(f, q).h);
+    const bool im = zkv_parity() != 0;
+    const int32_t k1 = im ? 1 : -1, k3 = im ? -3 : 3;
+    L9 s1, s2;
+#pragma unroll
+    for (int i = 0; i < 9; i++) s1.l[i] = A.l[i] + B.l[i];               // lazy limbs: multiplicand only
+    {
+        const L9 pB = l9_partner(B);
+        const LTerm t[3] = {{A.l, 1}, {B.l, 9}, {pB.l, k1}};              // this lane's component of A + xi B
+        s2 = l9_lincomb(t, 4);
+    }
+    L9 ab, sp;
     if (S == 1) {
-        ab = f2_mul(A, B);
-        s = f2_mul(f2_add(A, B), f2_add(f2_mul_xi(B), A));
+        ab = l9_mul(A, B);
+        sp = l9_mul(s1, s2);
     } else {
         const bool second = (w.s & 1) != 0;
-        const Fp2 p = f2_mul(f2_sel(second, f2_add(A, B), A), f2_sel(second, f2_add(f2_mul_xi(B), A), B));
+        L9 x, y;
+#pragma unroll
+        for (int i = 0; i < 9; i++) { x.l[i] = second ? s1.l[i] : A.l[i]; y.l[i] = second ? s2.l[i] : B.l[i]; }
+        const L9 p = l9_mul(x, y);
+        // slices 0 and 2 (1 and 3) write the same value: limbs 0..7 in row 0 (1) of `red`, limb 8 in word 0 of row 2 (3)
+        const MRef r0 = m_off(red, 96 * (w.s & 1)), r8 = m_off(red, 96 * (2 + (w.s & 1)));
         wide_sync();
-        m_st_f2(m_off(red, 96 * (w.s & 1)), q, p);          // slices 0 and 2 (1 and 3) write the same value
+#pragma unroll
+        for (int i = 0; i < 8; i++) r0.st(16 * q + i, p.l[i]);
+        r8.st(16 * q, p.l[8]);
         wide_fence();
-        ab = m_ld_f2(red, q); s = m_ld_f2(m_off(red, 96), q);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { ab.l[i] = red.ld(16 * q + i); sp.l[i] = m_off(red, 96).ld(16 * q + i); }
+        ab.l[8] = m_off(red, 192).ld(16 * q); sp.l[8] = m_off(red, 288).ld(16 * q);
     }
-    Fp2 te = f2_sub(f2_sub(s, ab), f2_mul_xi(ab));
-    Fp2 T = f2_sel(odd, f2_dbl(ab), te);
-    T = f2_sel(q == 3, f2_mul_xi(T), T);
-    Fp2 u = f2_add(T, f2_sel(odd, z, f2_neg(z)));        // 3T + 2z (odd) / 3T - 2z (even)
+    // even pairs: 3 (s - 10 ab +- ab') - 2 z;  odd pairs: 6 ab + 2 z;  pair 3: 3 xi (2 ab) + 2 z = 54 ab -+ 6 ab' + 2 z
+    const L9 pab = l9_partner(ab);
+    const int32_t cS = odd ? 0 : 3, cAB = odd ? (q == 3 ? 54 : 6) : -30, cP = odd ? (q == 3 ? -2 * k3 : 0) : k3, cZ = odd ? 2 : -2;
+    const LTerm t[4] = {{sp.l, cS}, {ab.l, cAB}, {pab.l, cP}, {z.l, cZ}};
+    const L9 out = l9_lincomb(t, 72);
+    Fp2 o; o.h = l9_to_fp(out);
     wide_sync();
-    m_st_f2(f, q, f2_add(f2_dbl(u), T));
+    m_st_f2(f, q, o);
     wide_fence();
 }
 // f <- f * (c0 + c3 w + c4 w^3); with `one` the constant coefficient is 1 and c0 is not read
