@@ -8,6 +8,7 @@
 #include <mutex>
 #include <new>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <system_error>
@@ -719,6 +720,11 @@ static int run_host_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const uint6
         if (s0) { rel.resize(pn + 1); for (size_t i = 0; i <= pn; i++) rel[i] = off[p0 + i] - s0; o = rel.data(); }
         if (sp1 && v0) { prel.resize(pn + 1); for (size_t i = 0; i <= pn; i++) prel[i] = pv_off[p0 + i] - v0; po = prel.data(); }
         const size_t first = host_first_segment(pn, cap);
+        // ZKV_HOST_TRACE=1 (diagnostic): events around the segments' copies and kernels, printed to stderr after the pass
+        const bool trace = getenv("ZKV_HOST_TRACE") != nullptr;
+        std::vector<hipEvent_t> tev;
+        auto mark = [&](hipStream_t st) { if (!trace) return; hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); tev.push_back(e); } };
+        mark(c->stream);
         for (size_t base = 0, k = 0; base < pn; k++) {
             // (a third, intermediate segment of 2 * first was measured and dropped: 202.6 against 200.7 ms per 2^20 SP1 proofs,
             // alternating runs on one box)
@@ -733,6 +739,7 @@ static int run_host_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const uint6
                 if (po[base + m] > po[base]) HIP_TRY(hipMemcpyAsync(c->hb[4] + po[base], pv_blob + v0 + po[base], (size_t)(po[base + m] - po[base]), hipMemcpyHostToDevice, cs));
             }
             HIP_TRY(hipEventRecord(c->ev_seg[k & 1], cs));
+            mark(cs);
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_seg[k & 1], 0));
             PrepArgs a;
             memset(&a, 0, sizeof a);
@@ -749,11 +756,19 @@ static int run_host_batch(zkv_ctx* c, size_t n, const uint8_t* blob, const uint6
             a.status = c->d_st_all + base; a.recv = c->d_rv_all + 4 * base;
             base += m;
             enqueue_chunk(c, a, c->stream, base >= pn);
+            mark(c->stream);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipMemcpyAsync(status + p0, c->d_st_all, pn, hipMemcpyDeviceToHost, c->stream));
         if (recv) HIP_TRY(hipMemcpyAsync(recv + 4 * p0, c->d_rv_all, 4 * pn, hipMemcpyDeviceToHost, c->stream));
+        mark(c->stream);
         HIP_TRY(hipStreamSynchronize(c->stream));            // also: the staging buffers are free for the next pass
+        if (trace && tev.size() > 1) {
+            fprintf(stderr, "zkv host pass of %zu proofs (first segment %zu): events [start, (copy done, kernels done) per segment, statuses back], ms since start:", pn, first);
+            for (size_t i = 1; i < tev.size(); i++) { float ms = 0; (void)hipEventElapsedTime(&ms, tev[0], tev[i]); fprintf(stderr, " %.2f", ms); }
+            fprintf(stderr, "\n");
+        }
+        for (auto e : tev) (void)hipEventDestroy(e);
     }
     return ZKV_OK;
 }
