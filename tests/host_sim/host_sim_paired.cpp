@@ -141,3 +141,41 @@ extern "C" int hs2_miller2(const void* tables, int g, uint32_t mask, uint32_t ab
     *fine = j.fine[0];
     return j.ok[0];
 }
+
+// ---- resident 29-bit limbs (zkv_field.h "L9"): the one-pass linear combination and the limb product at the edge of their contracts.
+// hs2_lincomb: n <= 6 terms, each nine signed 32-bit limbs (a normalised value or a lazy limb-wise sum / difference) with a small integer
+// coefficient; c as at the call sites.  out9 = the nine limbs of the result.  One thread: the combination itself exchanges nothing.
+template <int N> static void lincomb_n(const uint32_t* xs, const int32_t* ks, int c, uint32_t* out9) {
+    LTerm t[N];
+    for (int j = 0; j < N; j++) { t[j].x = xs + 9 * j; t[j].k = ks[j]; }
+    const L9 r = l9_lincomb(t, c);
+    for (int i = 0; i < 9; i++) out9[i] = r.l[i];
+}
+extern "C" int hs2_lincomb(int n, const uint32_t* xs, const int32_t* ks, int c, uint32_t* out9) {
+    switch (n) {
+        case 1: lincomb_n<1>(xs, ks, c, out9); return 1;
+        case 2: lincomb_n<2>(xs, ks, c, out9); return 1;
+        case 3: lincomb_n<3>(xs, ks, c, out9); return 1;
+        case 4: lincomb_n<4>(xs, ks, c, out9); return 1;
+        case 5: lincomb_n<5>(xs, ks, c, out9); return 1;
+        case 6: lincomb_n<6>(xs, ks, c, out9); return 1;
+    }
+    return 0;
+}
+// hs2_l9_mul: the lane product l9_mul on a pair of threads.  in36: a0 a1 b0 b1 as nine limbs each (a: limbs below 2^30; b: normalised);
+// out18: the two components' nine limbs.
+struct L9Job { const uint32_t* in; uint32_t* out; };
+static void l9_lane(L9Job* j, uint32_t par) {
+    tl_par = par;
+    L9 a, b;
+    for (int i = 0; i < 9; i++) { a.l[i] = j->in[9 * par + i]; b.l[i] = j->in[18 + 9 * par + i]; }
+    const L9 r = l9_mul(a, b);
+    for (int i = 0; i < 9; i++) j->out[9 * par + i] = r.l[i];
+}
+extern "C" void hs2_l9_mul(const uint32_t* in36, uint32_t* out18) {
+    L9Job j; j.in = in36; j.out = out18;
+    g_cnt = 0;
+    std::thread t1(l9_lane, &j, 1u);
+    l9_lane(&j, 0u);
+    t1.join();
+}

@@ -375,6 +375,66 @@ def test_lane_pair_products_at_the_edge_of_their_contract(hs_pair):
         run(*(rng.randrange(2 * P) for _ in range(4)))
 
 
+def test_resident_limb_combinations_and_products_at_the_edge_of_their_contract(hs_pair):
+    """csrc/zkv_field.h "L9" (the final exponentiation's accumulator): l9_lincomb must return sum k_j x_j mod p with normalised limbs and a
+    value below 1.01 p for the coefficient sets of every call site, on operands at the extremes the call sites allow (0, p, 2p - 1, all-ones
+    limbs, lazy sums and differences of three such values) -- the quotient estimate has to hold there, not only on random values; l9_mul must
+    be exact for a multiplicand that is a lazy limb-wise sum (limbs up to 2^30 - 2) and a multiplier up to 7.9 p."""
+    rng = random.Random(0x5A4B56B2)
+    P = m.P
+    L = hs_pair
+    M29 = (1 << 29) - 1
+    def limbs(v): return [(v >> (29 * i)) & M29 for i in range(8)] + [v >> 232]
+    def val(l): return sum(int(x) << (29 * i) for i, x in enumerate(l))
+    def sval(l): return sum((int(x) - (1 << 32) if int(x) >= (1 << 31) else int(x)) << (29 * i) for i, x in enumerate(l))
+    edge = [0, 1, P - 1, P, P + 1, 2 * P - 1, (1 << 232) - 1, ((1 << 232) - 1) | (2 * P >> 232 << 232) if (((1 << 232) - 1) | (2 * P >> 232 << 232)) < 2 * P else 2 * P - 2]
+    def pick(): return rng.choice(edge) if rng.random() < 0.5 else rng.randrange(2 * P)
+    def lazy3(sign):                                  # x - y - z or x + y + z, limb by limb (what L9F6Raw holds): signed 32-bit limbs
+        x, y, z = (limbs(pick()) for _ in range(3))
+        return [(a + sign * (b + c)) & 0xffffffff for a, b, c in zip(x, y, z)], (3 if sign > 0 else 1, 2 if sign < 0 else 0)
+    L.hs2_lincomb.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    # (coefficients, c, which terms are lazy three-term sums) as at the call sites of zkv_tower_mem.h / zkv_tower_wide.h
+    sites = [((1, 9, 1), 4, ()), ((1, 9, -1), 4, ()), ((3, -30, 3, -2), 72, ()), ((3, -30, -3, -2), 72, ()), ((6, 2), 1, ()), ((54, -6, 2), 14, ()), ((54, 6, 2), 14, ()),
+             ((1, 9, 1), 48, (1, 2)), ((1, 9, -1), 48, (1, 2)), ((1, 9, 1), 8, (0,)), ((1,), 8, (0,)), ((1, 9, -1, -1), 52, (1, 2)), ((1, 9, 1, -1), 12, (0,)), ((1, -1), 12, (0,)),
+             ((0, 6, 0, 2), 72, ()), ((0, 54, 6, 2), 72, ()), ((1, 1), 1, ()), ((-1,), 3, ())]
+    for ks, c, lazy in sites:
+        for rep in range(60):
+            terms, total = [], 0
+            for j, k in enumerate(ks):
+                if j in lazy:
+                    l, _ = lazy3(-1 if rng.random() < 0.7 else 1)
+                else:
+                    l = limbs(pick() if rep else (2 * P - 1 if k < 0 else 0))        # rep 0: the most negative combination
+                terms.append(l); total += k * sval(l)
+            xs = (C.c_uint32 * (9 * len(ks)))(*[x for l in terms for x in l])
+            kk = (C.c_int32 * len(ks))(*ks)
+            out = (C.c_uint32 * 9)()
+            assert L.hs2_lincomb(len(ks), xs, kk, c, out) == 1
+            got = list(out)
+            assert all(x <= M29 for x in got[:8]), (ks, got)
+            v = val(got)
+            assert v % P == total % P and v < P + (P >> 6), (ks, c, rep, hex(v))
+    # the lane product: multiplicand limbs up to 2^30 - 2 (a lazy sum), multiplier normalised with a value up to 7.9 p
+    L.hs2_l9_mul.argtypes = [C.c_void_p, C.c_void_p]
+    RI = pow(1 << 261, -1, P)
+    big = [limbs(2 * P - 1), [M29] * 8 + [(2 * P - 1) >> 232], limbs(0), limbs(P)]
+    for rep in range(300):
+        def mcand():
+            x, y = (rng.choice(big) if rng.random() < 0.4 else limbs(rng.randrange(2 * P)) for _ in range(2))
+            return [a + b for a, b in zip(x, y)]
+        def mplier():
+            return limbs(rng.choice([0, P, 2 * P - 1, 4 * P - 1, 7 * P + (P >> 1), rng.randrange(4 * P)]))
+        a0, a1, b0, b1 = mcand(), mcand(), mplier(), mplier()
+        buf = (C.c_uint32 * 36)(*(a0 + a1 + b0 + b1))
+        out = (C.c_uint32 * 18)()
+        L.hs2_l9_mul(buf, out)
+        r0, r1 = val(out[:9]), val(out[9:])
+        A0, A1, B0, B1 = val(a0), val(a1), val(b0), val(b1)
+        assert all(x <= M29 for x in list(out[:8]) + list(out[9:17]))
+        assert r0 % P == (A0 * B0 - A1 * B1) * RI % P and r1 % P == (A0 * B1 + A1 * B0) * RI % P, rep
+        assert r0 < 2 * P and r1 < 2 * P
+
+
 def test_one_proof_per_lane_multipliers_at_the_edge_of_their_contract(hs):
     """fp_mul and the fused Fp2 product of the one-proof-per-lane kernels (three column products, two reductions, signed
     columns) on operands up to 4p - 1."""
