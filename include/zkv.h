@@ -295,7 +295,7 @@ int zkv_diag_issue_rate(int device, int kind, int waves_per_simd, uint32_t iters
 /* ------------------------------------------------------------------ shared */
 int zkv_ctx_vm(const zkv_ctx* ctx);                   /* ZKV_VM_* */
 /* Tuning knob (no reference counterpart): kernel mapping of the G2 / Miller / final-exponentiation stages.
- * 0 = automatic (default): one proof per pair of lanes; for chunks of at most ZKV_WIDE_BELOW proofs (environment, default 8192)
+ * 0 = automatic (default): one proof per pair of lanes; for chunks of at most ZKV_WIDE_BELOW proofs (environment, default 12288)
  * one proof per 16 lanes, which halves the latency of a small batch; for chunks of at most ZKV_WAVE_BELOW proofs (default 2048)
  * one proof per WAVEFRONT (64 lanes), the lowest latency -- the case of the reference's own API, one proof per call
  * (risc0/verifier.rs:78-92) -- and for chunks of at most ZKV_DUAL_BELOW proofs (default 768) the Miller loop gets a second
