@@ -29,7 +29,7 @@ __device__ __forceinline__ Fp2 ld_b_w(const Workspace& ws, int word0, size_t i, 
 }
 
 template <int SLICES> __device__ __forceinline__ void miller_w_body(size_t n, const VkTables* __restrict__ vk, const Workspace& ws, uint32_t* lds) {
-    constexpr int SLOT = 96 + 48 + 13 * 16 + (SLICES > 1 ? SLICES * 96 : 0);   // per proof: f (6 Fp2), T (3 Fp2), 13 scratch Fp2, the slices' rows
+    constexpr int SLOT = 96 + 48 + 13 * 16 + (SLICES > 1 ? W_RED_WORDS : 0);   // per proof: f (6 Fp2), T (3 Fp2), 13 scratch Fp2, the slices' rows (+ their ninth limbs)
     const WideLane w = wide_lane<SLICES>();
     if (w.i >= n) return;
     const uint32_t flags = ws.flags[w.i];
@@ -47,7 +47,7 @@ template <int SLICES> __device__ __forceinline__ void miller_w_body(size_t n, co
     w12_mul<SLICES>(out, fm, ab, w.w, false, red);
 }
 template <int SLICES> __device__ __forceinline__ void finalexp_w_body(size_t n, const Workspace& ws, uint8_t* __restrict__ status, uint32_t* lds) {
-    constexpr int SLOT = 96 + (SLICES > 1 ? SLICES * 96 : 0);
+    constexpr int SLOT = 96 + (SLICES > 1 ? W_RED_WORDS : 0);
     const WideLane w = wide_lane<SLICES>();
     if (w.i >= n) return;
     const uint32_t flags = ws.flags[w.i];
@@ -71,11 +71,11 @@ __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_finalexp_w(size_t n, Workspace
 // one proof per wavefront.  (Launch bounds as for the 16-lane kernels: with a larger register budget here the non-inlined inversion both
 // final exponentiations call is compiled into AGPRs and k_finalexp_w drops to one wavefront per SIMD -- 2.4 instead of 1.8 ms at 8,192 proofs.)
 __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_miller_w64(size_t n, const VkTables* __restrict__ vk, Workspace ws) {
-    __shared__ uint32_t lds[96 + 48 + 13 * 16 + 4 * 96];
+    __shared__ uint32_t lds[96 + 48 + 13 * 16 + W_RED_WORDS];
     miller_w_body<4>(n, vk, ws, lds);
 }
 __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_finalexp_w64(size_t n, Workspace ws, uint8_t* __restrict__ status) {
-    __shared__ uint32_t lds[96 + 4 * 96];
+    __shared__ uint32_t lds[96 + W_RED_WORDS];
     finalexp_w_body<4>(n, ws, status, lds);
 }
 
@@ -93,7 +93,7 @@ int read_wait_faults(unsigned long long* out) {
 // Two wavefronts per proof (workgroup of 128 lanes): wavefront 1 steps the running point and tabulates the line coefficients, wavefront 0
 // accumulates f (miller_lines_producer / miller_loop_consumer, zkv_tower_wide.h).  For chunks of at most ZKV_DUAL_BELOW proofs.
 __global__ __launch_bounds__(128, 2) void k_miller_w64d(size_t n, const VkTables* __restrict__ vk, Workspace ws, uint8_t* __restrict__ status) {
-    constexpr int F_WORDS = 96 + 64 + 4 * 96, T_WORDS = 48 + 13 * 16, LINE_WORDS = ZKV_MILLER_STEPS * 48;
+    constexpr int F_WORDS = 96 + 64 + W_RED_WORDS, T_WORDS = 48 + 13 * 16, LINE_WORDS = ZKV_MILLER_STEPS * 48;
     __shared__ uint32_t lds[F_WORDS + T_WORDS + LINE_WORDS + 4];
     const size_t i = blockIdx.x;
     if (i >= n) return;
@@ -148,7 +148,7 @@ ZKV_HD bool pair_all_w(bool mine) {
     return v == 0;
 }
 __global__ __launch_bounds__(128, 2) void k_pairing_pair_w64d(size_t n, uint32_t k, uint32_t j, const uint8_t* __restrict__ in, Workspace ws, uint8_t* __restrict__ ok) {
-    constexpr int F_WORDS = 96 + 64 + 4 * 96, T_WORDS = 48 + 13 * 16, LINE_WORDS = ZKV_MILLER_STEPS * 48;
+    constexpr int F_WORDS = 96 + 64 + W_RED_WORDS, T_WORDS = 48 + 13 * 16, LINE_WORDS = ZKV_MILLER_STEPS * 48;
     __shared__ uint32_t lds[F_WORDS + T_WORDS + LINE_WORDS + 4];
     const size_t i = blockIdx.x;
     if (i >= n) return;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(128, 2) void k_pairing_pair_w64d(size_t n, uint32_t
     if (!okj && lane == 0) ok[i] = 0;
 }
 __global__ __launch_bounds__(ZKV_BLOCK, 2) void k_pairing_finalexp_w64(size_t n, Workspace ws, const uint8_t* __restrict__ ok, uint8_t* __restrict__ result, uint32_t empty) {
-    __shared__ uint32_t lds[96 + 4 * 96];
+    __shared__ uint32_t lds[96 + W_RED_WORDS];
     const size_t i = blockIdx.x;
     if (i >= n) return;
     const uint32_t lane = threadIdx.x & 63u, half = lane & 1u;

@@ -126,24 +126,54 @@ template <int S> ZKV_W_NI void w12_mul(MRef d, MRef a, MRef b, WL w, bool conj_b
 }
 // f <- f^2 (generic): c_e = sum over unordered {i, j}, i + j = e mod 6, of a_i a_j (twice when i != j): at most four products per
 // pair.  Table entry = i | j << 3 | doubled << 6 | wrapped << 7 | valid << 8 for output power e, term t (index 4 e + t).
+// Round 4: on 29-bit limbs like w12_cyclo_sqr.  The four products of a coefficient (one per slice for S = 4) meet in ONE one-pass combination
+// whose per-lane coefficients carry the doubling of the mixed terms and the xi of the wrapped ones.  For S = 4 a slice parks limbs 0..7 of its
+// product in its row of `red` and limb 8 in the 48 words that follow the four rows (W_RED_WORDS).
+constexpr int W_RED_WORDS = 4 * 96 + 48;
 template <int S> ZKV_W_NI void w12_sqr(MRef f, WL wl, MRef red) {
     const uint16_t TERMS[24] = {256, 489, 482, 411, 328, 490, 483, 0, 336, 265, 491, 420, 344, 337, 492, 0, 352, 345, 274, 429, 360, 353, 346, 0};
     const int q = wl.q, e = w_pow(q);
-    Fp2 accn = f2_zero(), accw = f2_zero();
-    const Fp2 zero = f2_zero();
     static_assert(S == 1 || S == 4, "four terms per coefficient: one slice each, or all in one");
-#pragma unroll 1
-    for (int k = 0; k < 4 / S; k++) {
-        const int t = wl.s + k * S;
+    const uint32_t h = zkv_parity();
+    const int32_t k1 = h ? 1 : -1;
+    L9 p[4];
+    int32_t co[4], cp[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
         const uint32_t w = TERMS[4 * e + t];
-        Fp2 p = f2_mul(m_ld_f2(f, w_mem((int)(w & 7u))), m_ld_f2(f, w_mem((int)((w >> 3) & 7u))));
-        p = f2_sel(((w >> 6) & 1u) != 0, f2_dbl(p), p);
-        p = f2_sel(((w >> 8) & 1u) != 0, p, zero);
-        const bool wrap = ((w >> 7) & 1u) != 0;
-        accw = f2_add(accw, f2_sel(wrap, p, zero));
-        accn = f2_add(accn, f2_sel(wrap, zero, p));
+        const int32_t two = ((w >> 6) & 1u) ? 2 : 1;
+        const bool valid = ((w >> 8) & 1u) != 0, wrap = ((w >> 7) & 1u) != 0;
+        co[t] = valid ? two * (wrap ? 9 : 1) : 0;
+        cp[t] = (valid && wrap) ? two * k1 : 0;
     }
-    const Fp2 r = w_reduce<S>(red, f2_add(accn, f2_mul_xi(accw)), wl);
+    if (S == 1) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t w = TERMS[4 * e + t];
+            p[t] = l9_mul(l9_from_fp(m_ld_f2(f, w_mem((int)(w & 7u))).h), l9_from_fp(m_ld_f2(f, w_mem((int)((w >> 3) & 7u))).h));
+        }
+    } else {
+        const uint32_t w = TERMS[4 * e + wl.s];
+        const L9 mine = l9_mul(l9_from_fp(m_ld_f2(f, w_mem((int)(w & 7u))).h), l9_from_fp(m_ld_f2(f, w_mem((int)((w >> 3) & 7u))).h));
+        uint32_t* r8 = red.p - 8 * h + 4 * 96;                    // the ninth limbs: word 12 row + 2 q + half
+        wide_sync();
+        {
+            const MRef rs = m_off(red, 96 * wl.s);
+#pragma unroll
+            for (int i = 0; i < 8; i++) rs.st(16 * q + i, mine.l[i]);
+            r8[12 * wl.s + 2 * q + (int)h] = mine.l[8];
+        }
+        wide_fence();
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) p[t].l[i] = m_off(red, 96 * t).ld(16 * q + i);
+            p[t].l[8] = r8[12 * t + 2 * q + (int)h];
+        }
+    }
+    const L9 pp0 = l9_partner(p[0]), pp1 = l9_partner(p[1]), pp2 = l9_partner(p[2]), pp3 = l9_partner(p[3]);
+    const LTerm tm[8] = {{p[0].l, co[0]}, {p[1].l, co[1]}, {p[2].l, co[2]}, {p[3].l, co[3]}, {pp0.l, cp[0]}, {pp1.l, cp[1]}, {pp2.l, cp[2]}, {pp3.l, cp[3]}};
+    Fp2 r; r.h = l9_to_fp(l9_lincomb(tm, 20));
     wide_sync();
     m_st_f2(f, q, r);
     wide_fence();
@@ -204,26 +234,43 @@ template <int S> ZKV_W_NI void w12_cyclo_sqr(MRef f, WL w, MRef red) {
 }
 // f <- f * (c0 + c3 w + c4 w^3); with `one` the constant coefficient is 1 and c0 is not read
 // S = 4: slice 0 forms a0 c0 (or passes a0 on), slice 1 a1 c3, slice 2 a3 c4, slice 3 contributes zero: one round.
+// Round 4: on 29-bit limbs like w12_cyclo_sqr -- the (at most three) products of a coefficient meet in ONE one-pass combination whose
+// per-lane coefficients carry the xi of the wrapped terms (9 mine -+ the partner's), instead of an xi-multiplication computed by every
+// lane and selected, and three modular additions.
 template <int S> ZKV_W_NI void w12_mul_sparse(MRef f, const Fp2* c0, const Fp2* c3, const Fp2* c4, WL w, bool one, MRef red) {
     const int q = w.q, e = w_pow(q);
     const int e1 = e >= 1 ? e - 1 : e + 5, e3 = e >= 3 ? e - 3 : e + 3;
-    Fp2 a0 = m_ld_f2(f, q), a1 = m_ld_f2(f, w_mem(e1)), a3 = m_ld_f2(f, w_mem(e3));
-    Fp2 r;
+    const Fp2 a0 = m_ld_f2(f, q), a1 = m_ld_f2(f, w_mem(e1)), a3 = m_ld_f2(f, w_mem(e3));
+    const int32_t k1 = zkv_parity() != 0 ? 1 : -1;
+    const int32_t k3o = e < 1 ? 9 : 1, k3p = e < 1 ? k1 : 0, k4o = e < 3 ? 9 : 1, k4p = e < 3 ? k1 : 0;        // xi on the terms that wrapped past w^6
+    L9 t, p3, p4;
     if (S == 1) {
-        Fp2 t = one ? a0 : f2_mul(a0, *c0);
-        Fp2 p3 = f2_mul(a1, *c3), p4 = f2_mul(a3, *c4);
-        p3 = f2_sel(e < 1, f2_mul_xi(p3), p3);
-        p4 = f2_sel(e < 3, f2_mul_xi(p4), p4);
-        r = f2_add(f2_add(t, p3), p4);
+        t = one ? l9_from_fp(a0.h) : l9_mul(l9_from_fp(a0.h), l9_from_fp(c0->h));
+        p3 = l9_mul(l9_from_fp(a1.h), l9_from_fp(c3->h));
+        p4 = l9_mul(l9_from_fp(a3.h), l9_from_fp(c4->h));
     } else {
         const Fp2 x = f2_sel(w.s == 1, a1, f2_sel(w.s == 2, a3, a0));
         const Fp2 y = f2_sel(w.s == 1, *c3, f2_sel(w.s == 2, *c4, *c0));          // with `one`, c0 aliases c3: slice 0's product is dropped
-        Fp2 p = f2_mul(x, y);
-        p = f2_sel(w.s == 0 && one, a0, p);
-        p = f2_sel((w.s == 1 && e < 1) || (w.s == 2 && e < 3), f2_mul_xi(p), p);
-        p = f2_sel(w.s == 3, f2_zero(), p);
-        r = w_reduce<S>(red, p, w);
+        const L9 xl = l9_from_fp(x.h);
+        L9 p = l9_mul(xl, l9_from_fp(y.h));
+#pragma unroll
+        for (int i = 0; i < 9; i++) p.l[i] = (w.s == 0 && one) ? xl.l[i] : p.l[i];
+        // slices 0..2 park their product: limbs 0..7 in row s of `red`, limb 8 in word s of row 3 (slice 3 has no term)
+        wide_sync();
+        if (w.s < 3) {
+            const MRef rs = m_off(red, 96 * w.s);
+#pragma unroll
+            for (int i = 0; i < 8; i++) rs.st(16 * q + i, p.l[i]);
+            m_off(red, 288).st(16 * q + w.s, p.l[8]);
+        }
+        wide_fence();
+#pragma unroll
+        for (int i = 0; i < 8; i++) { t.l[i] = red.ld(16 * q + i); p3.l[i] = m_off(red, 96).ld(16 * q + i); p4.l[i] = m_off(red, 192).ld(16 * q + i); }
+        t.l[8] = m_off(red, 288).ld(16 * q); p3.l[8] = m_off(red, 288).ld(16 * q + 1); p4.l[8] = m_off(red, 288).ld(16 * q + 2);
     }
+    const L9 pp3 = l9_partner(p3), pp4 = l9_partner(p4);
+    const LTerm tm[5] = {{t.l, 1}, {p3.l, k3o}, {pp3.l, k3p}, {p4.l, k4o}, {pp4.l, k4p}};
+    Fp2 r; r.h = l9_to_fp(l9_lincomb(tm, 8));
     wide_sync();
     m_st_f2(f, q, r);
     wide_fence();

@@ -42,7 +42,7 @@ using namespace zkv;
 
 struct Job { const VkTables* t; uint32_t flags; const uint32_t* norm48; const uint32_t* b32; int accept[2 * PAIRS * MAX_SLICES]; };
 // group-shared memory: f, T, scratch, the slices' rows (LDS on the device) and the eight Fp12 slots of the final exponentiation (HBM on the device)
-static uint32_t g_lds[96 + 48 + 13 * 16 + MAX_SLICES * 96], g_acc[96 + MAX_SLICES * 96], g_full[8 * 96];
+static uint32_t g_lds[96 + 48 + 13 * 16 + MAX_SLICES * 96 + 48], g_acc[96 + MAX_SLICES * 96 + 48], g_full[8 * 96];      // + 48: the slices' ninth limbs (W_RED_WORDS)
 
 template <int S> static void lane(Job* j, uint32_t slice, uint32_t pair, uint32_t par) {
     tl_group = 0; tl_pair = slice * PAIRS + pair; tl_par = par;
