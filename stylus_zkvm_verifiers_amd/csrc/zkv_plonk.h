@@ -14,6 +14,9 @@
 namespace zkv {
 
 // ---------------------------------------------------------------- streaming SHA-256 for the transcripts (byte granular)
+// One copy of the block function in the instruction stream: byte() and word_be() are inlined at some 170 places of plonk_prepare, and
+// with the 64 unrolled rounds inlined into each of them the stage was 4 MB of straight-line code that every wavefront fetched once.
+ZKV_HD_NI void sha_stream_block(uint32_t* h, uint32_t* w) { sha256_compress(h, w); for (int i = 0; i < 16; i++) w[i] = 0; }
 struct ShaStream {
     uint32_t h[8], w[16]; uint32_t n;
     ZKV_HD void init() { sha256_init(h); n = 0; for (int i = 0; i < 16; i++) w[i] = 0; }
@@ -21,12 +24,12 @@ struct ShaStream {
         const uint32_t k = (n >> 2) & 15u;
         w[k] = (w[k] << 8) | (b & 255u);
         n++;
-        if ((n & 63u) == 0) { sha256_compress(h, w); for (int i = 0; i < 16; i++) w[i] = 0; }
+        if ((n & 63u) == 0) sha_stream_block(h, w);
     }
     ZKV_HD void word_be(uint32_t v) {                      // four bytes, most significant first
         if ((n & 3u) == 0) {
             w[(n >> 2) & 15u] = v; n += 4;
-            if ((n & 63u) == 0) { sha256_compress(h, w); for (int i = 0; i < 16; i++) w[i] = 0; }
+            if ((n & 63u) == 0) sha_stream_block(h, w);
         } else { byte(v >> 24); byte(v >> 16); byte(v >> 8); byte(v); }
     }
     ZKV_HD void limbs_be(const uint32_t* l) {               // a 256-bit value as 32 big-endian bytes
