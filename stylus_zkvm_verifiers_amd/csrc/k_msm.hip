@@ -1,10 +1,11 @@
-// Stage MSM: vk_x = base + sum s_b * IC_b via 8-bit fixed-base windows (tables stay L2-resident), then the
+// Stage MSM: vk_x = base + sum s_b * IC_b via fixed-base windows -- 16-bit ones for the big batches (Msm16: one 64-byte gather and one
+// addition per 16 bits of a scalar, the table in HBM / the memory-side cache), the L2-resident 8-bit rows otherwise -- then the
 // x/y, 1/y normalisation of A', vk_x and C with a single field inversion per proof.
 #include "zkv_internal.h"
 
 namespace zkv {
 
-__global__ __launch_bounds__(ZKV_BLOCK) void k_msm(size_t n, const VkTables* __restrict__ vk, const InstTab* __restrict__ inst_tab, Workspace ws) {
+__global__ __launch_bounds__(ZKV_BLOCK) void k_msm(size_t n, const VkTables* __restrict__ vk, Msm16 m16, const InstTab* __restrict__ inst_tab, Workspace ws) {
     size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t flags = ws.flags[i];
@@ -13,7 +14,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_msm(size_t n, const VkTables* __r
     auto word = [&](uint32_t b, uint32_t k) { return ws.prep[(size_t)(64 + 8 * b + k) * ws.cap + i]; };
     const G1A* base = &vk->base; uint32_t base_inf = vk->base_inf;
     if (inst_tab) { const InstTab& t = inst_tab[flags >> 8]; flags &= 0xFFu; base = &t.base; base_inf = t.base_inf; }     // verifier set: the instance index rides in the upper bits of the flags word
-    const G1J acc = msm_accumulate_w(*vk, word, *base, base_inf);
+    const G1J acc = m16.tab ? msm_accumulate_w16(*vk, m16, word, *base, base_inf) : msm_accumulate_w(*vk, word, *base, base_inf);
     PrepOut in;
     in.ax = ws_ld(ws.prep, ws.cap, 0, i); in.ay = ws_ld(ws.prep, ws.cap, 8, i);
     in.cx = ws_ld(ws.prep, ws.cap, 16, i); in.cy = ws_ld(ws.prep, ws.cap, 24, i);
@@ -80,7 +81,7 @@ void launch_msm_w(size_t n, const VkTables* d_tab, const InstTab* inst_tab, cons
 }
 
 // compute_vk_x alone (zkv_ctx_vk_x_batch): same tables and window walk as k_msm, affine result as 64 big-endian bytes.
-__global__ __launch_bounds__(ZKV_BLOCK) void k_vk_x(size_t n, const VkTables* __restrict__ vk, const InstTab* __restrict__ inst_tab,
+__global__ __launch_bounds__(ZKV_BLOCK) void k_vk_x(size_t n, const VkTables* __restrict__ vk, Msm16 m16, const InstTab* __restrict__ inst_tab,
                                                      const uint32_t* __restrict__ inst, const uint8_t* __restrict__ sig, uint8_t* __restrict__ out) {
     size_t i = (size_t)blockIdx.x * ZKV_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_vk_x(size_t n, const VkTables* __
     };
     const G1A* base = &vk->base; uint32_t base_inf = vk->base_inf;
     if (inst_tab) { const InstTab& t = inst_tab[inst[i]]; base = &t.base; base_inf = t.base_inf; }
-    G1J acc = msm_accumulate_w(*vk, word, *base, base_inf);
+    G1J acc = m16.tab ? msm_accumulate_w16(*vk, m16, word, *base, base_inf) : msm_accumulate_w(*vk, word, *base, base_inf);
     G1A a; uint32_t inf;
     g1j_to_affine(acc, a, inf);
     uint32_t r[8];
@@ -108,14 +109,14 @@ __global__ __launch_bounds__(ZKV_BLOCK) void k_vk_x(size_t n, const VkTables* __
         }
     }
 }
-void launch_vk_x(size_t n, const VkTables* d_tab, const InstTab* inst_tab, const uint32_t* inst, const uint8_t* sig, uint8_t* out, hipStream_t s) {
+void launch_vk_x(size_t n, const VkTables* d_tab, const Msm16& m16, const InstTab* inst_tab, const uint32_t* inst, const uint8_t* sig, uint8_t* out, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_vk_x, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, d_tab, inst_tab, inst, sig, out);
+    hipLaunchKernelGGL(k_vk_x, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, d_tab, m16, inst_tab, inst, sig, out);
 }
 
-void launch_msm(size_t n, const VkTables* d_tab, const InstTab* inst_tab, const Workspace& ws, hipStream_t s) {
+void launch_msm(size_t n, const VkTables* d_tab, const Msm16& m16, const InstTab* inst_tab, const Workspace& ws, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_msm, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, d_tab, inst_tab, ws);
+    hipLaunchKernelGGL(k_msm, dim3((unsigned)((n + ZKV_BLOCK - 1) / ZKV_BLOCK)), dim3(ZKV_BLOCK), 0, s, n, d_tab, m16, inst_tab, ws);
 }
 
 }  // namespace zkv

@@ -42,6 +42,20 @@ void launch_setup_instances(const VkRaw* d_raw, const InstConsts& k, const InstR
     hipLaunchKernelGGL(k_setup_instances, dim3((n_inst + 63) / 64), dim3(64), 0, s, d_raw, k, d_in, d_out, n_inst);
 }
 
+// wide vk_x windows: one lane per 64 entries (row, upper digit, quarter of the lower digits); after k_setup_msm
+__global__ __launch_bounds__(64) void k_setup_msm16(const VkTables* __restrict__ t, Msm16 m, G1A* __restrict__ tab, uint32_t rows) {
+    const uint32_t id = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t r = id >> 10, hi = (id >> 2) & 255u, q = id & 3u;
+    if (r >= rows) return;
+    uint32_t b = 0;
+    while (b + 1 < t->n_var && m.row0[b + 1] <= r) b++;
+    setup_msm16_chunk(*t, tab + ((size_t)r << 16), b, r - m.row0[b], hi, 64 * q);
+}
+void launch_setup_msm16(const VkTables* d_tab, const Msm16& m, G1A* tab, uint32_t rows, hipStream_t s) {
+    if (!rows) return;
+    hipLaunchKernelGGL(k_setup_msm16, dim3(rows * 16), dim3(64), 0, s, d_tab, m, tab, rows);
+}
+
 void launch_setup(const VkRaw* d_raw, VkTables* d_tab, hipStream_t s) {
     hipLaunchKernelGGL(k_setup_validate, dim3(1), dim3(64), 0, s, d_raw, d_tab);
     hipLaunchKernelGGL(k_setup_base, dim3(1), dim3(64), 0, s, d_raw, d_tab);

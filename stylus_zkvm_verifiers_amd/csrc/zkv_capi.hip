@@ -44,6 +44,8 @@ struct zkv_ctx {
     bool dev_ready = false;
     hipStream_t stream = nullptr;
     VkTables* d_tab = nullptr;
+    G1A* d_msm16 = nullptr;                                  // the vk_x stage's 16-bit window rows (Msm16; null: 8-bit walk)
+    Msm16 m16 = {nullptr, {0, 0, 0, 0, 0}};
     Workspace ws = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     hipStream_t side = nullptr;                              // small chunks: the G2 subgroup check runs beside the MSM
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -163,6 +165,12 @@ static size_t msm_wave_below() {
     const char* e = getenv("ZKV_MSM_WAVE_BELOW");
     return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)2048;
 }
+// Window width of the vk_x stage's fixed-base tables: 16 (default) adds rows of 65,536 entries (4 MB each: SP1 134 MB, RISC Zero 67 MB per
+// context) that halve the stage's additions; 8 keeps the L2-resident 8-bit rows only.
+static int msm_window_bits() {
+    const char* e = getenv("ZKV_MSM_WINDOW_BITS");
+    return (e && atoi(e) == 8) ? 8 : 16;
+}
 static size_t wide_below() {
     const char* e = getenv("ZKV_WIDE_BELOW");
     return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)12288;     // round 4 (profiles/round4_batch_sweep.txt): 16 lanes 6.9-7.2 ms against 7.3 for lane pairs up to here, 8.7 beyond
@@ -226,7 +234,8 @@ ZKV_EXPORT const char* zkv_version(void) { return "zkv-mi355x 0.1 (gfx950)"; }
 static void ctx_free_device(zkv_ctx* c) {
     if (!c->dev_ready && !c->stream) return;
     (void)hipSetDevice(c->device);
-    void** ptrs[] = {(void**)&c->d_tab, (void**)&c->ws.prep, (void**)&c->ws.norm, (void**)&c->ws.f, (void**)&c->ws.fe, (void**)&c->ws.flags,
+    c->m16 = {nullptr, {0, 0, 0, 0, 0}};
+    void** ptrs[] = {(void**)&c->d_tab, (void**)&c->d_msm16, (void**)&c->ws.prep, (void**)&c->ws.norm, (void**)&c->ws.f, (void**)&c->ws.fe, (void**)&c->ws.flags,
                      (void**)&c->ws.g2bad, (void**)&c->d_blob, (void**)&c->d_a, (void**)&c->d_b, (void**)&c->d_pv, (void**)&c->d_status,
                      (void**)&c->d_recv, (void**)&c->d_off, (void**)&c->d_pvoff, (void**)&c->d_cd[0], (void**)&c->d_cd[1], (void**)&c->d_kind,
                      (void**)&c->d_cdoff[0], (void**)&c->d_cdoff[1], (void**)&c->d_len, (void**)&c->d_pvlen, (void**)&c->d_st_all,
@@ -285,6 +294,21 @@ static int ctx_device_setup(zkv_ctx* c) {
         launch_setup(d_raw, c->d_tab, c->stream);
         HIP_TRY(hipGetLastError());
         const bool agg_vm = c->vm == ZKV_VM_RISC0 || c->vm == ZKV_VM_RISC0_SET || c->vm == ZKV_VM_SP1 || c->vm == ZKV_VM_GROTH16;
+        if (agg_vm && msm_window_bits() == 16) {
+            // 16-bit window rows for the vk_x stage of big batches: 4 MB per row, built from the 8-bit rows k_setup_msm has just written
+            Msm16 m = {nullptr, {0, 0, 0, 0, 0}};
+            uint32_t rows = 0;
+            for (uint32_t b = 0; b < raw.n_var && b < (uint32_t)MAX_VAR; b++) { m.row0[b] = rows; rows += (raw.var_windows[b] + 1) / 2; }
+            if (rows && rows <= MSM16_MAX_ROWS) {
+                const size_t bytes = (size_t)rows * 65536 * sizeof(G1A);
+                HIP_TRY(hipMalloc(&c->d_msm16, bytes));
+                HIP_TRY(hipMemsetAsync(c->d_msm16, 0, bytes, c->stream));
+                launch_setup_msm16(c->d_tab, m, c->d_msm16, rows, c->stream);
+                HIP_TRY(hipGetLastError());
+                m.tab = c->d_msm16;
+                c->m16 = m;
+            }
+        }
         if (agg_vm || c->vm == ZKV_VM_SP1_PLONK) {
             HIP_TRY(hipMalloc(&c->d_agg_cnt, 3 * sizeof(unsigned long long)));
             HIP_TRY(hipMemsetAsync(c->d_agg_cnt, 0, 3 * sizeof(unsigned long long), c->stream));
@@ -560,7 +584,7 @@ static void enqueue_agg(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool timed
     launch_finalexp_by_size(n2, c->ws2, c->d_status2, s);
     launch_agg_mark(a.n, sub, grp, c->ws, c->d_agg, c->d_status2, a.status, c->d_agg_cnt, c->d_agg_idx, s);
     launch_agg_gather(a.n, c->ws, c->d_agg, c->d_agg_cnt, c->d_agg_idx, c->ws3, c->d_status3, s);
-    launch_msm(a.n, c->d_tab, inst, c->ws3, s);
+    launch_msm(a.n, c->d_tab, c->m16, inst, c->ws3, s);
     launch_miller2(a.n, c->d_tab, c->ws3, c->d_status3, s);
     launch_finalexp2(a.n, c->ws3, c->d_status3, s);
     launch_agg_scatter(a.n, c->d_agg_cnt, c->d_agg_idx, c->d_status3, a.status, s);
@@ -624,7 +648,7 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
         // of the last `tail` through their own small-batch mapping (whose Miller kernels leave the subgroup test of B to k_g2chk2)
         const size_t head = a.n - tail;
         const Workspace wt = ws_from(c->ws, head);
-        launch_msm(a.n, c->d_tab, a.inst ? c->d_inst : nullptr, c->ws, s);
+        launch_msm(a.n, c->d_tab, c->m16, a.inst ? c->d_inst : nullptr, c->ws, s);
         if (timed) (void)hipEventRecord(c->ev[2], s);
         launch_g2chk2(tail, wt, a.status + head, s);
         if (timed) (void)hipEventRecord(c->ev[3], s);
@@ -652,7 +676,7 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
         (void)hipEventRecord(c->ev_join, c->side);
     }
     if (a.n <= msm_wave_below()) launch_msm_w(a.n, c->d_tab, a.inst ? c->d_inst : nullptr, c->ws, s);     // one proof per wavefront
-    else launch_msm(a.n, c->d_tab, a.inst ? c->d_inst : nullptr, c->ws, s);
+    else launch_msm(a.n, c->d_tab, c->m16, a.inst ? c->d_inst : nullptr, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[2], s);
     if (wide && !fork) launch_g2chk2(a.n, c->ws, a.status, s);
     if (timed) (void)hipEventRecord(c->ev[3], s);
@@ -1366,7 +1390,7 @@ ZKV_EXPORT int zkv_risc0_set_vk_x_batch(zkv_ctx* c, size_t n, const uint32_t* in
         if ((rc = grow(&c->d_pv, &c->pv_cap, m * 64 + 8)) != ZKV_OK) return rc;
         HIP_TRY(hipMemcpyAsync(c->d_blob, var_signals + 64 * base, 64 * m, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_inst_idx, instance + base, sizeof(uint32_t) * m, hipMemcpyHostToDevice, c->stream));
-        launch_vk_x(m, c->d_tab, c->d_inst, c->d_inst_idx, c->d_blob, c->d_pv, c->stream);
+        launch_vk_x(m, c->d_tab, c->m16, c->d_inst, c->d_inst_idx, c->d_blob, c->d_pv, c->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(out + 64 * base, c->d_pv, 64 * m, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1848,7 +1872,7 @@ ZKV_EXPORT int zkv_ctx_vk_x_batch(zkv_ctx* c, size_t n, const uint8_t* var_signa
         if ((rc = grow(&c->d_blob, &c->blob_cap, m * sig + 8)) != ZKV_OK) return rc;
         if ((rc = grow(&c->d_pv, &c->pv_cap, m * 64 + 8)) != ZKV_OK) return rc;
         if (sig) HIP_TRY(hipMemcpyAsync(c->d_blob, var_signals + sig * base, sig * m, hipMemcpyHostToDevice, c->stream));
-        launch_vk_x(m, c->d_tab, nullptr, nullptr, c->d_blob, c->d_pv, c->stream);
+        launch_vk_x(m, c->d_tab, c->m16, nullptr, nullptr, c->d_blob, c->d_pv, c->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(out + 64 * base, c->d_pv, 64 * m, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));

@@ -77,10 +77,11 @@ void launch_setup(const VkRaw* d_raw, VkTables* d_tab, hipStream_t s);
 void launch_prep_risc0(const PrepArgs& a, const Risc0Consts& k, const Workspace& ws, hipStream_t s);
 void launch_prep_sp1(const PrepArgs& a, const Workspace& ws, hipStream_t s);
 void launch_prep_groth16(const PrepArgs& a, const Workspace& ws, hipStream_t s);
-void launch_msm(size_t n, const VkTables* d_tab, const InstTab* inst_tab, const Workspace& ws, hipStream_t s);
+void launch_setup_msm16(const VkTables* d_tab, const Msm16& m, G1A* tab, uint32_t rows, hipStream_t s);
+void launch_msm(size_t n, const VkTables* d_tab, const Msm16& m16, const InstTab* inst_tab, const Workspace& ws, hipStream_t s);
 void launch_msm_w(size_t n, const VkTables* d_tab, const InstTab* inst_tab, const Workspace& ws, hipStream_t s);
 void launch_setup_instances(const VkRaw* d_raw, const InstConsts& k, const InstRaw* d_in, InstTab* d_out, uint32_t n_inst, hipStream_t s);
-void launch_vk_x(size_t n, const VkTables* d_tab, const InstTab* inst_tab, const uint32_t* inst, const uint8_t* sig, uint8_t* out, hipStream_t s);
+void launch_vk_x(size_t n, const VkTables* d_tab, const Msm16& m16, const InstTab* inst_tab, const uint32_t* inst, const uint8_t* sig, uint8_t* out, hipStream_t s);
 // lane-pair variants (k_pair.hip): one proof per two lanes, two waves per SIMD
 void launch_g2chk2(size_t n, const Workspace& ws, uint8_t* status, hipStream_t s);
 void launch_miller2(size_t n, const VkTables* d_tab, const Workspace& ws, uint8_t* status, hipStream_t s);

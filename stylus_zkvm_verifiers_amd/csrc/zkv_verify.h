@@ -51,6 +51,12 @@ struct VkTables {
     uint32_t f_alpha_beta[96];           // Miller value of (alpha, beta): Fp12 as g0 g1 g2 h0 h1 h2, (c0, c1) each
 };
 
+// Wide windows of the vk_x stage for big batches: entry (row0[b] + w, d) = d * 65536^w * IC_var[b], d = 1 .. 65535 -- half the additions of
+// the 8-bit walk.  4 MB per row (SP1: 32 rows, RISC Zero: 16), its own allocation built at context set-up from the 8-bit rows
+// (setup_msm16_chunk); tab == nullptr: not built (ZKV_MSM_WINDOW_BITS=8, or a generic key with more than MSM16_MAX_ROWS rows).
+constexpr uint32_t MSM16_MAX_ROWS = 32;
+struct Msm16 { const G1A* tab; uint32_t row0[MAX_VAR]; };
+
 // Verifier sets: raw parameters, set-up constants and the per-instance device table (see setup_instance).
 struct InstRaw { uint8_t control_root[32]; uint8_t control_id[32]; };
 struct InstConsts { uint8_t tag[32]; uint8_t vk_digest[32]; };   // sha256("risc0.Groth16ReceiptVerifierParameters"), VK digest
@@ -170,6 +176,26 @@ template <class WORD> ZKV_HD G1J msm_accumulate_w(const VkTables& vk, WORD word,
             uint32_t d = (word(b, w >> 2) >> ((w & 3) * 8)) & 255u;
             if (d) {
                 const G1A& e = vk.msm[b][w][d];
+                acc = g1j_add_affine(acc, e.x, e.y);
+            }
+        }
+    }
+    return acc;
+}
+// The same walk over 16-bit windows (Msm16): one 64-byte gather and one addition per 16 bits of a scalar.
+template <class WORD> ZKV_HD G1J msm_accumulate_w16(const VkTables& vk, const Msm16& m, WORD word, const G1A& base, uint32_t base_inf) {
+    G1J acc;
+    if (base_inf) acc = g1j_infinity();
+    else { acc.x = base.x; acc.y = base.y; acc.z = fp_one(); }
+#pragma unroll 1
+    for (uint32_t b = 0; b < vk.n_var; b++) {
+        const uint32_t nw = vk.var_windows[b];                  // 8-bit windows of this scalar (0: IC_b is infinity)
+#pragma unroll 1
+        for (uint32_t w = 0; 2 * w < nw; w++) {
+            uint32_t d = (word(b, w >> 1) >> ((w & 1) * 16)) & 0xffffu;
+            if (2 * w + 1 >= nw) d &= 0xffu;                    // an odd number of 8-bit windows: the last row has no upper half
+            if (d) {
+                const G1A e = m.tab[((size_t)(m.row0[b] + w) << 16) + d];
                 acc = g1j_add_affine(acc, e.x, e.y);
             }
         }
@@ -662,6 +688,41 @@ ZKV_HD void setup_msm_row(const VkRaw& vk, VkTables& t, int b, int w) {
         return;
     }
     setup_window_row(fp_from_raw(vk.ic[ici][0]), fp_from_raw(vk.ic[ici][1]), w, t.msm[b][w]);
+}
+// 64 entries of one 16-bit row: d = 256 hi + lo, lo = lo0 .. lo0 + 63, as (lo * 256^(2w) + hi * 256^(2w+1)) * IC_var[b] = the sum of one
+// entry of each of the two 8-bit rows the window covers.  The 64 chords share one field inversion (prefix products parked in the y
+// slots about to be written).  Neither the two points nor their negatives ever coincide: lo < 256 <= 256 hi and 256 hi + lo < r.
+ZKV_HD void setup_msm16_chunk(const VkTables& t, G1A* row, uint32_t b, uint32_t w, uint32_t hi, uint32_t lo0) {
+    const uint32_t nw = t.var_windows[b];
+    if (2 * w >= nw) return;                                    // also IC_b = infinity (var_windows 0): the row is never read
+    const G1A* L = t.msm[b][2 * w];
+    G1A* out = row + hi * 256 + lo0;
+    if (hi == 0) {
+#pragma unroll 1
+        for (uint32_t j = 0; j < 64; j++) out[j] = L[lo0 + j];
+        return;
+    }
+    if (2 * w + 1 >= nw) return;                                // no upper half: digits above 255 do not occur
+    const G1A H = t.msm[b][2 * w + 1][hi];
+    Fp prod = fp_one();
+#pragma unroll 1
+    for (uint32_t j = 0; j < 64; j++) {
+        if (lo0 + j == 0) continue;
+        out[j].y = prod;
+        prod = fp_mul(prod, fp_sub(L[lo0 + j].x, H.x));
+    }
+    Fp inv = fp_inv(prod);
+#pragma unroll 1
+    for (int j = 63; j >= 0; j--) {
+        if (lo0 + j == 0) { out[j] = H; continue; }
+        const G1A P = L[lo0 + j];
+        const Fp dinv = fp_mul(inv, out[j].y);
+        inv = fp_mul(inv, fp_sub(P.x, H.x));
+        const Fp lam = fp_mul(fp_sub(P.y, H.y), dinv);
+        const Fp x3 = fp_sub(fp_sub(fp_sqr(lam), H.x), P.x);
+        out[j].x = x3;
+        out[j].y = fp_sub(fp_mul(lam, fp_sub(H.x, x3)), H.y);
+    }
 }
 // One instance of a RISC Zero verifier set: what `initialize` derives from (control_root, bn254_control_id)
 // (risc0/verifier.rs:58-76) -- the selector (verifier.rs:128-144: tagged SHA-256 over control root, byte-reversed control

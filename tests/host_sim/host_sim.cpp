@@ -100,6 +100,31 @@ void hs_vk_x(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* s0, c
         for (int i = 0; i < 8; i++) for (int k = 0; k < 4; k++) out64[32 * c + 31 - 4 * i - k] = r[i] >> (8 * k);
     }
 }
+// The same through the 16-bit window rows (Msm16: setup_msm16_chunk + msm_accumulate_w16, what k_setup_msm16 / k_msm run for big batches).
+// Only the 64-entry chunks the two scalars touch are built, in a lazily zeroed allocation of the table's full size.
+void hs_vk_x16(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* s0, const uint8_t* s1, uint8_t* out64) {
+    VkTables* t = tables(vm, cr, cid);
+    PrepOut p; memset(&p, 0, sizeof p);
+    load_be256(p.s[0], s0); load_be256(p.s[1], s1);
+    Msm16 m = {nullptr, {0, 0, 0, 0, 0}};
+    uint32_t rows = 0;
+    for (uint32_t b = 0; b < t->n_var; b++) { m.row0[b] = rows; rows += (t->var_windows[b] + 1) / 2; }
+    G1A* tab = (G1A*)calloc((size_t)rows << 16, sizeof(G1A));
+    for (uint32_t b = 0; b < t->n_var; b++)
+        for (uint32_t w = 0; 2 * w < t->var_windows[b]; w++) {
+            const uint32_t d = (p.s[b][w >> 1] >> ((w & 1) * 16)) & 0xffffu;
+            setup_msm16_chunk(*t, tab + ((size_t)(m.row0[b] + w) << 16), b, w, d >> 8, d & 0xc0u);
+        }
+    m.tab = tab;
+    G1J acc = msm_accumulate_w16(*t, m, [&](uint32_t b, uint32_t k) { return p.s[b][k]; }, t->base, t->base_inf);
+    free(tab);
+    G1A a; uint32_t inf; g1j_to_affine(acc, a, inf);
+    uint32_t r[8];
+    for (int c = 0; c < 2; c++) {
+        fp_to_raw(r, c ? a.y : a.x);
+        for (int i = 0; i < 8; i++) for (int k = 0; k < 4; k++) out64[32 * c + 31 - 4 * i - k] = r[i] >> (8 * k);
+    }
+}
 // verify_proof_with_key for an arbitrary key through the kernel stage functions (tables rebuilt per call: test only)
 int hs_groth16_generic(const uint8_t* vk_words, int n_ic, int negate_a, const uint8_t* words, const uint8_t* signals) {
     static VkTables* t = (VkTables*)malloc(sizeof(VkTables));

@@ -292,6 +292,30 @@ def test_windowed_vk_x_matches_oracle_on_random_signals(hs, real_proofs):
         assert out.raw == ol.groth16_vk_x(1, [m.be32(a), m.be32(b)]), (hex(a), hex(b))
 
 
+def test_sixteen_bit_window_rows_give_the_same_vk_x(hs, real_proofs):
+    """The 16-bit window rows of the vk_x stage (Msm16: 65,536 entries per row, built from pairs of 8-bit rows by chords that share an
+    inversion) against the oracle's ecMul/ecAdd chain: digits with an empty lower or upper byte, 0xffff, the first and the last entry of a
+    64-entry build chunk, and random scalars; both verification keys (16 and 32 eight-bit windows per scalar)."""
+    import oracle_lib as ol
+    r = real_proofs['risc0']
+    cr, cid = H(r['control_root']), H(r['bn254_control_id'])
+    fixed = [H(x) for x in r['signals']]
+    rng = random.Random(12)
+    edge = [0, 1, 0xff, 0x100, 0x101, 0xff00, 0xffff, 0x0140, 0x017f, 0x8000, (0xffff << 112) | 0x3f, (1 << 128) - 1, 0x00ff0100ff00ffff0001]
+    cases = [(a, b) for a in edge[:7] for b in edge[6:]] + [(rng.randrange(1 << 128), rng.randrange(1 << 128)) for _ in range(12)]
+    for a, b in cases:
+        out = C.create_string_buffer(64)
+        hs.hs_vk_x16(0, cr, cid, m.be32(a), m.be32(b), out)
+        sig = [fixed[0], fixed[1], m.be32(a), m.be32(b), fixed[4]]
+        assert out.raw == ol.groth16_vk_x(0, sig), (hex(a), hex(b))
+    cases = [(0, 0), (1, 1), (m.R - 1, m.R - 1), (m.R - 1, 0), (1 << 252, (1 << 253) - 1), (0xff00 << 240, 0x00ff << 232)]
+    cases += [(rng.randrange(m.R), rng.randrange(1 << 253)) for _ in range(12)]
+    for a, b in cases:
+        out = C.create_string_buffer(64)
+        hs.hs_vk_x16(1, None, None, m.be32(a), m.be32(b), out)
+        assert out.raw == ol.groth16_vk_x(1, [m.be32(a), m.be32(b)]), (hex(a), hex(b))
+
+
 from trapdoor_cases import generic_cases as _generic_cases  # noqa: E402
 
 
