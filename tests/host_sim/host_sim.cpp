@@ -32,6 +32,22 @@ static VkTables* tables(int vm, const uint8_t* cr, const uint8_t* cid) {
 }
 
 static unsigned long long g_stage_muls[5], g_stage_mads[5];
+
+// The 16-bit window rows (Msm16) for the scalars of ONE proof: only the 64-entry chunks its digits touch are built, in a lazily zeroed
+// allocation of the table's full size.  The caller frees m.tab.
+static Msm16 msm16_for(const VkTables& t, const PrepOut& p) {
+    Msm16 m = {nullptr, {0, 0, 0, 0, 0}};
+    uint32_t rows = 0;
+    for (uint32_t b = 0; b < t.n_var; b++) { m.row0[b] = rows; rows += (t.var_windows[b] + 1) / 2; }
+    G1A* tab = (G1A*)calloc((size_t)rows << 16, sizeof(G1A));
+    for (uint32_t b = 0; b < t.n_var; b++)
+        for (uint32_t w = 0; 2 * w < t.var_windows[b]; w++) {
+            const uint32_t d = (p.s[b][w >> 1] >> ((w & 1) * 16)) & 0xffffu;
+            setup_msm16_chunk(t, tab + ((size_t)(m.row0[b] + w) << 16), b, w, d >> 8, d & 0xc0u);
+        }
+    m.tab = tab;
+    return m;
+}
 extern "C" {
 // Montgomery multiplications spent in each stage (prep, msm, g2chk, miller, finalexp) by the last hs_groth16 call
 void hs_stage_muls(unsigned long long* out) { for (int i = 0; i < 5; i++) out[i] = g_stage_muls[i]; }
@@ -52,8 +68,12 @@ int hs_groth16(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* wor
     g_stage_muls[0] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter; g_stage_mads[0] = zkv_mad_counter - d0; d0 = zkv_mad_counter;
     if (!(p.flags & FL_B_INF) && !g2_in_subgroup(p.bx, p.by)) return 0;
     g_stage_muls[2] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter; g_stage_mads[2] = zkv_mad_counter - d0; d0 = zkv_mad_counter;
+    // the vk_x stage as big batches run it (k_msm on the 16-bit window rows); building this proof's part of the rows is set-up, not counted
     G1Norm n; uint32_t fl = p.flags;
-    msm_normalize(*t, p, fl, n);
+    const Msm16 m16 = msm16_for(*t, p);
+    c0 = zkv_fp_mul_counter; d0 = zkv_mad_counter;
+    msm_normalize_acc(msm_accumulate_w16(*t, m16, [&](uint32_t b, uint32_t k) { return p.s[b][k]; }, t->base, t->base_inf), p, fl, n);
+    free((void*)m16.tab);
     g_stage_muls[1] = zkv_fp_mul_counter - c0; c0 = zkv_fp_mul_counter; g_stage_mads[1] = zkv_mad_counter - d0; d0 = zkv_mad_counter;
     // same slot structure as the kernels: f and T in one buffer (LDS on the device), 5 Fp12 slots for the final exp
     static thread_local uint32_t buf[96 + 48], slots[8 * 96];
@@ -100,24 +120,14 @@ void hs_vk_x(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* s0, c
         for (int i = 0; i < 8; i++) for (int k = 0; k < 4; k++) out64[32 * c + 31 - 4 * i - k] = r[i] >> (8 * k);
     }
 }
-// The same through the 16-bit window rows (Msm16: setup_msm16_chunk + msm_accumulate_w16, what k_setup_msm16 / k_msm run for big batches).
-// Only the 64-entry chunks the two scalars touch are built, in a lazily zeroed allocation of the table's full size.
+// The same through the 16-bit window rows (Msm16: setup_msm16_chunk + msm_accumulate_w16, what k_setup_msm16 / k_msm run for big batches)
 void hs_vk_x16(int vm, const uint8_t* cr, const uint8_t* cid, const uint8_t* s0, const uint8_t* s1, uint8_t* out64) {
     VkTables* t = tables(vm, cr, cid);
     PrepOut p; memset(&p, 0, sizeof p);
     load_be256(p.s[0], s0); load_be256(p.s[1], s1);
-    Msm16 m = {nullptr, {0, 0, 0, 0, 0}};
-    uint32_t rows = 0;
-    for (uint32_t b = 0; b < t->n_var; b++) { m.row0[b] = rows; rows += (t->var_windows[b] + 1) / 2; }
-    G1A* tab = (G1A*)calloc((size_t)rows << 16, sizeof(G1A));
-    for (uint32_t b = 0; b < t->n_var; b++)
-        for (uint32_t w = 0; 2 * w < t->var_windows[b]; w++) {
-            const uint32_t d = (p.s[b][w >> 1] >> ((w & 1) * 16)) & 0xffffu;
-            setup_msm16_chunk(*t, tab + ((size_t)(m.row0[b] + w) << 16), b, w, d >> 8, d & 0xc0u);
-        }
-    m.tab = tab;
+    const Msm16 m = msm16_for(*t, p);
     G1J acc = msm_accumulate_w16(*t, m, [&](uint32_t b, uint32_t k) { return p.s[b][k]; }, t->base, t->base_inf);
-    free(tab);
+    free((void*)m.tab);
     G1A a; uint32_t inf; g1j_to_affine(acc, a, inf);
     uint32_t r[8];
     for (int c = 0; c < 2; c++) {
