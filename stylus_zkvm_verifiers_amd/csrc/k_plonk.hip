@@ -68,14 +68,19 @@ __global__ __launch_bounds__(ZKV_BLOCK, ZKV_PLONK_WAVES) void k_plonk_prep(PrepA
     a.status[i] = st;
 }
 
-// one lane per row (point, a) of the joint P / phi(P) tables, after k_plonk_setup has tabulated the multiples
+// the multiples of one point per block (one lane works: the levels of the row are sequential), then one lane per row (point, a) of the
+// joint P / phi(P) tables
+__global__ __launch_bounds__(64) void k_plonk_mult(PlonkKey* __restrict__ key) {
+    if (threadIdx.x == 0 && blockIdx.x <= PK_POINTS) plonk_setup_mult(*key, (int)blockIdx.x);
+}
 __global__ __launch_bounds__(64) void k_plonk_joint(PlonkKey* __restrict__ key) {
     const int t = (int)(blockIdx.x * 64 + threadIdx.x);
-    if (t < (PK_POINTS + 1) * 9) plonk_joint_row(*key, t / 9, t % 9);
+    if (t < (PK_POINTS + 1) * (PK_JA + 1)) plonk_joint_row(*key, t / (PK_JA + 1), t % (PK_JA + 1));
 }
 void launch_plonk_setup(const PlonkKeyRaw* d_raw, PlonkKey* d_key, hipStream_t s) {
     hipLaunchKernelGGL(k_plonk_setup, dim3(1), dim3(64), 0, s, d_raw, d_key);
-    hipLaunchKernelGGL(k_plonk_joint, dim3(((PK_POINTS + 1) * 9 + 63) / 64), dim3(64), 0, s, d_key);
+    hipLaunchKernelGGL(k_plonk_mult, dim3(PK_POINTS + 1), dim3(64), 0, s, d_key);
+    hipLaunchKernelGGL(k_plonk_joint, dim3(((PK_POINTS + 1) * (PK_JA + 1) + 63) / 64), dim3(64), 0, s, d_key);
 }
 void launch_plonk_prep(const PrepArgs& a, const PlonkKey* d_key, const Workspace& ws, hipStream_t s) {
     if (!a.n) return;

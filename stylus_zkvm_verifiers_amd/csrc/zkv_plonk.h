@@ -60,13 +60,15 @@ struct PlonkKey {
     uint32_t nb_public, n_c, valid, pad;
     G1A pts[PK_POINTS]; uint32_t inf[PK_POINTS];
     uint32_t raw[PK_POINTS][2][8];  // the same points as canonical integers, for the transcripts
-    G1A mult[PK_POINTS + 1][8];     // k * P, k = 1..8, affine, for the nine key points and (last row) the G1 generator: the
-                                    // signed-window tables of the FIXED terms of the multi-scalar multiplications
-    uint32_t mult_inf[PK_POINTS + 1][8];
-    Fp mult_bx[PK_POINTS + 1][8];   // beta * x of the same entries: the tables of phi(P) = (beta x, y) = lambda P (GLV)
-    G1A joint[PK_POINTS + 1][9][17];        // a P + b phi(P), a = 0..8, b = -8..8 (index b + 8), affine: ONE addition per window serves both
-                                    // GLV halves of a fixed term (33 instead of 66 per term); (0, 0) unused.  98 KB per context
+    // Tables of the FIXED terms of the multi-scalar multiplications -- the nine key points and (last row) the G1 generator:
+    G1A mult[PK_POINTS + 1][256];   // m * P, affine (m = 0 unused; 1 .. PK_JA feed the joint rows), built like a vk_x window row
+    uint32_t mult_inf[PK_POINTS + 1];
+    // a P + b phi(P), a = 0 .. 136, b = -136 .. 136 (index b + 136), affine; phi(P) = (beta x, y) = lambda P (GLV).  ONE addition serves
+    // both GLV halves of a fixed term over TWO 4-bit windows (16 e' + e with signed digits |e| <= 8): 17 additions per term instead of
+    // the 66 of a per-half walk (round 3's 9 x 17 table served one window: 33).  (0, 0) unused.  2.4 MB per point, 24 MB per context.
+    G1A joint[PK_POINTS + 1][137][273];
 };
+constexpr int PK_JA = 136, PK_JB = 273;
 constexpr int PK_GEN = PK_POINTS;
 // A G1 point as the precompiles take it: coordinates < P, on the curve or (0,0) = infinity.  Returns false when invalid.
 ZKV_HD bool plonk_g1(const uint32_t x[8], const uint32_t y[8], G1A& out, uint32_t& inf) {
@@ -90,51 +92,64 @@ ZKV_HD void plonk_setup_key(const PlonkKeyRaw& r, PlonkKey& k) {
         ok = plonk_g1(r.pts[p][0], r.pts[p][1], k.pts[p], k.inf[p]) && ok;
     }
     k.valid = ok ? 1u : 0u;
-    // window tables (a key point may have small order only if it is the point at infinity: the curve has prime order)
-#pragma unroll 1
-    for (int p = 0; p <= PK_POINTS; p++) {
-        G1A base; uint32_t binf = 0;
-        if (p == PK_GEN) { base.x = fp_one(); Fp two = fp_zero(); two.v[0] = 2; base.y = fp_from_raw(two.v); }
-        else { base = k.pts[p]; binf = k.inf[p]; }
-        G1J acc = g1j_infinity();
-#pragma unroll 1
-        for (int m = 0; m < 8; m++) {
-            if (!binf && ok) acc = g1j_add_affine(acc, base.x, base.y);
-            g1j_to_affine(acc, k.mult[p][m], k.mult_inf[p][m]);
-            const Fp beta = ZKV_GLV_BETA;
-            k.mult_bx[p][m] = fp_mul(k.mult[p][m].x, beta);
-        }
-    }
+}
+// The multiples of point p (a key point, or the generator for p = PK_GEN) the joint rows are made of: independent per point, one lane
+// each at set-up.  A key point has small order only if it is the point at infinity (the curve has prime order).
+ZKV_HD void plonk_setup_mult(PlonkKey& k, int p) {
+    G1A base; uint32_t binf = 0;
+    if (p == PK_GEN) { base.x = fp_one(); Fp two = fp_zero(); two.v[0] = 2; base.y = fp_from_raw(two.v); }
+    else { base = k.pts[p]; binf = k.inf[p]; }
+    k.mult_inf[p] = (binf || !k.valid) ? 1u : 0u;
+    if (k.mult_inf[p]) return;
+    setup_window_row(base.x, base.y, 0, k.mult[p]);
 }
 
-// Row a of the joint table of key point p (needs mult / mult_bx of that point): independent per (p, a), one lane each at set-up.
+// Row a of the joint table of point p (needs mult[p]): independent per (p, a), one lane each at set-up.  The 273 chords of a row share one
+// field inversion (prefix products parked in the y slots about to be written).  a P = +-b phi(P) never happens: a -+ b lambda = 0 mod r
+// has no solution with |a|, |b| <= 136 other than a = b = 0.
 ZKV_HD void plonk_joint_row(PlonkKey& k, int p, int a) {
+    G1A* row = k.joint[p][a];
+    const Fp beta = ZKV_GLV_BETA;
+    if (k.mult_inf[p]) return;                               // a term at infinity is skipped by the walk: its rows are never read
+    const G1A A = k.mult[p][a];                              // a = 0: unused
+    Fp prod = fp_one();
 #pragma unroll 1
-    for (int b = -8; b <= 8; b++) {
-        G1A e; e.x = fp_zero(); e.y = fp_zero();
-        if (!k.mult_inf[p][0] && (a || b)) {
-            G1J acc = g1j_infinity();
-            if (a) { acc.x = k.mult[p][a - 1].x; acc.y = k.mult[p][a - 1].y; acc.z = fp_one(); }
-            if (b) {
-                const int m = (b < 0 ? -b : b) - 1;
-                acc = g1j_add_affine(acc, k.mult_bx[p][m], b < 0 ? fp_neg(k.mult[p][m].y) : k.mult[p][m].y);
-            }
-            uint32_t inf; g1j_to_affine(acc, e, inf);       // never infinity: a + b lambda != 0 mod r for |a|, |b| <= 8
-        }
-        k.joint[p][a][b + 8] = e;
+    for (int j = 0; j < PK_JB; j++) {
+        const int b = j - PK_JA, m = b < 0 ? -b : b;
+        if (!a || !b) continue;
+        row[j].y = prod;
+        prod = fp_mul(prod, fp_sub(fp_mul(k.mult[p][m].x, beta), A.x));
+    }
+    Fp inv = fp_inv(prod);
+#pragma unroll 1
+    for (int j = PK_JB - 1; j >= 0; j--) {
+        const int b = j - PK_JA, m = b < 0 ? -b : b;
+        if (!a && !b) { row[j].x = fp_zero(); row[j].y = fp_zero(); continue; }
+        if (!b) { row[j] = A; continue; }
+        const Fp bx = fp_mul(k.mult[p][m].x, beta), by = b < 0 ? fp_neg(k.mult[p][m].y) : k.mult[p][m].y;      // b phi(P)
+        if (!a) { row[j].x = bx; row[j].y = by; continue; }
+        const Fp den = fp_sub(bx, A.x);
+        const Fp dinv = fp_mul(inv, row[j].y);
+        inv = fp_mul(inv, den);
+        const Fp lam = fp_mul(fp_sub(by, A.y), dinv);
+        const Fp x3 = fp_sub(fp_sub(fp_sqr(lam), A.x), bx);
+        row[j].x = x3;
+        row[j].y = fp_sub(fp_mul(lam, fp_sub(A.x, x3)), A.y);
     }
 }
 
-ZKV_HD void plonk_setup_joint(PlonkKey& k) {                // all rows in sequence (host builds; the device runs one lane per row)
+ZKV_HD void plonk_setup_tables(PlonkKey& k) {               // everything in sequence (host builds; the device runs one lane per point / row)
+#pragma unroll 1
+    for (int p = 0; p <= PK_POINTS; p++) plonk_setup_mult(k, p);
 #pragma unroll 1
     for (int p = 0; p <= PK_POINTS; p++)
 #pragma unroll 1
-        for (int a = 0; a < 9; a++) plonk_joint_row(k, p, a);
+        for (int a = 0; a <= PK_JA; a++) plonk_joint_row(k, p, a);
 }
 
 // ---------------------------------------------------------------- G1 helpers
 // One term of a multi-scalar multiplication: an affine point (or infinity) and a canonical 256-bit scalar.
-struct MsmTerm { Fp x, y; uint32_t inf; uint32_t k[8]; const G1A* fixed; };      // fixed: the key's joint table [9][17] of the point, or null
+struct MsmTerm { Fp x, y; uint32_t inf; uint32_t k[8]; const G1A* fixed; };      // fixed: the key's joint table [137][273] of the point, or null
 
 // 33 signed 4-bit digits of a magnitude below 2^131, packed 4 bits each as d + 8
 ZKV_HD void glv_digits(const uint32_t (&m)[5], uint32_t (&dig)[5]) {
@@ -258,9 +273,16 @@ template <int N, int NV> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&
             const int d2 = (int)((dig[i][1][win >> 3] >> (4 * (win & 7))) & 15u) - 8;
             const int e1 = (negs[i] & 1u) ? -d1 : d1, e2 = (negs[i] & 2u) ? -d2 : d2;         // digits of k1 and k2
             if (t[i].fixed) {                                    // wave-uniform: the same term index in every lane
-                if (e1 == 0 && e2 == 0) continue;
-                const bool flip = e1 < 0;                        // -(|e1| P + (-e2) phi P)
-                const G1A e = t[i].fixed[(flip ? -e1 : e1) * 17 + (flip ? -e2 : e2) + 8];
+                if (win & 1) continue;                           // fixed terms take windows win + 1 and win together (the top one alone)
+                int E1 = e1, E2 = e2;
+                if (win < 32) {
+                    const int w1 = win + 1;
+                    const int h1 = (int)((dig[i][0][w1 >> 3] >> (4 * (w1 & 7))) & 15u) - 8, h2 = (int)((dig[i][1][w1 >> 3] >> (4 * (w1 & 7))) & 15u) - 8;
+                    E1 += 16 * ((negs[i] & 1u) ? -h1 : h1); E2 += 16 * ((negs[i] & 2u) ? -h2 : h2);
+                }
+                if (E1 == 0 && E2 == 0) continue;
+                const bool flip = E1 < 0;                        // -(|E1| P + (-E2) phi P)
+                const G1A e = t[i].fixed[(flip ? -E1 : E1) * PK_JB + (flip ? -E2 : E2) + PK_JA];
                 acc = g1j_add_affine(acc, e.x, flip ? fp_neg(e.y) : e.y);
                 continue;
             }
@@ -273,7 +295,7 @@ template <int N, int NV> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&
 }
 ZKV_HD void plonk_term(MsmTerm& t, const G1A& p, uint32_t inf, const Fr& k) { t.x = p.x; t.y = p.y; t.inf = inf; t.fixed = nullptr; fr_to_raw(t.k, k); }
 ZKV_HD void plonk_key_term(MsmTerm& t, const PlonkKey& key, int p, const Fr& k) {      // a key point (or PK_GEN): table from the context
-    t.x = key.mult[p][0].x; t.y = key.mult[p][0].y; t.inf = key.mult_inf[p][0]; t.fixed = &key.joint[p][0][0]; fr_to_raw(t.k, k);
+    t.x = key.mult[p][1].x; t.y = key.mult[p][1].y; t.inf = key.mult_inf[p]; t.fixed = &key.joint[p][0][0]; fr_to_raw(t.k, k);
 }
 // affine form + canonical coordinates for the transcripts
 struct G1Bytes { uint32_t x[8], y[8]; };

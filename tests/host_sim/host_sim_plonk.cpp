@@ -25,12 +25,15 @@ int hsp_prepare(const uint8_t* vk, size_t vk_len, const uint8_t* proof, const ui
     for (int k = 0; k < 7; k++) host::be_to_limbs(w7[k], vk + 32 * k);
     const size_t n_c = w7[5][0];
     if (n_c > 1 || vk_len != 7 * 32 + (8 + n_c) * 64 + 256) return -1;
-    static PlonkKeyRaw raw; static PlonkKey key;
+    static PlonkKeyRaw raw, last; static PlonkKey key; static bool have = false;
     memset(&raw, 0, sizeof raw);
     memcpy(raw.size, w7[0], 32); memcpy(raw.size_inv, w7[1], 32); memcpy(raw.gen, w7[2], 32); memcpy(raw.coset, w7[3], 32);
     raw.nb_public = w7[4][0]; raw.n_c = w7[5][0]; raw.cci = w7[6][0];
     for (size_t p = 0; p < 8 + n_c; p++) { host::be_to_limbs(raw.pts[p][0], vk + 224 + 64 * p); host::be_to_limbs(raw.pts[p][1], vk + 256 + 64 * p); }
-    plonk_setup_key(raw, key); plonk_setup_joint(key);
+    if (!have || memcmp(&raw, &last, sizeof raw) != 0) {     // the tables of a key (24 MB, 374 k chords) are built once per key
+        plonk_setup_key(raw, key); plonk_setup_tables(key);
+        last = raw; have = true;
+    }
     uint32_t w[27][8], pb[2][8];
     for (int k = 0; k < 27; k++) host::be_to_limbs(w[k], proof + 32 * k);
     host::be_to_limbs(pb[0], pub); host::be_to_limbs(pb[1], pub + 32);
