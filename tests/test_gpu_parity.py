@@ -265,6 +265,37 @@ def test_both_kernel_mappings_agree_on_a_2p13_batch(zkv, real_proofs):
     assert (out[2][:k] == ost).all()
 
 
+def test_both_window_widths_of_the_vk_x_stage_agree(zkv, real_proofs, monkeypatch):
+    """The vk_x stage of a batch above ZKV_MSM_WAVE_BELOW walks 16-bit window rows by default and the 8-bit rows with
+    ZKV_MSM_WINDOW_BITS=8 (read when a context is set up): the same statuses on 8,192 seeded RISC Zero proofs (accept <=> untouched),
+    and compute_vk_x itself byte for byte on random signals, all different."""
+    import random
+    import torch
+    import spec_model as m
+    from stylus_zkvm_verifiers_amd import synth
+    dev = torch.device('cuda', 0)
+    r = real_proofs['risc0']
+    n = 1 << 13
+    seals, mut, mclass, flip = synth.make_batch('risc0', H(r['seal']), n, 0x16B175, pool=8, mutate_every=16)
+    ids = np.tile(np.frombuffer(H(r['image_id']), dtype=np.uint8), (n, 1))
+    jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (n, 1)); jds[flip, 0] ^= 1
+    d_seals, d_ids, d_jds = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (seals, ids, jds))
+    rng = random.Random(99)
+    pairs = [(m.be32(rng.randrange(1 << 128)), m.be32(rng.randrange(1 << 128))) for _ in range(64)]
+    out, vkx = {}, {}
+    for bits in ('16', '8'):
+        monkeypatch.setenv('ZKV_MSM_WINDOW_BITS', bits)
+        v = zkv.RiscZeroVerifier(); v.initialize(H(r['control_root']), H(r['bn254_control_id']))
+        d_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+        v.verify_batch_dev(n, d_seals.data_ptr(), d_ids.data_ptr(), d_jds.data_ptr(), d_st.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out[bits] = d_st.cpu().numpy()
+        vkx[bits] = list(v.vk_x_batch(pairs))
+        v.close()
+    assert (out['16'] == out['8']).all() and ((out['16'] == 0) == ~mut).all()
+    assert vkx['16'] == vkx['8'] and len(set(vkx['16'])) == len(pairs)
+
+
 def test_vk_x_batch_matches_oracle(zkv, r0, sp1, real_proofs):
     """compute_vk_x on the GPU (windowed fixed-base tables built by the set-up kernels) against the oracle's ecMul/ecAdd chain
     for random and edge-case signals -- the valid proofs of the corpus all share one set of public inputs."""
