@@ -55,7 +55,10 @@ const char* zkv_version(void);
 /* ------------------------------------------------------------------ RISC Zero verifier instance
  * Replaces the `RiscZeroVerifier` storage struct + `IRiscZeroVerifier` (risc0/verifier.rs:18-52). */
 
-/* An un-initialised verifier bound to HIP device `device` (storage with initialized = false). */
+/* An un-initialised verifier bound to HIP device `device` (storage with initialized = false).
+ * Device memory of a context, allocated at its first compute call: the key's tables (Groth16: 3 MB, plus the 16-bit window rows of the
+ * vk_x stage -- 67 MB for RISC Zero, 134 MB for SP1, ZKV_MSM_WINDOW_BITS=8 leaves them out; SP1 PLONK: 24 MB) and a workspace that grows
+ * with the largest chunk it has seen (about 4 KB per proof, chunks of at most 2^20 proofs). */
 zkv_ctx* zkv_risc0_ctx_new(int device);
 /* IRiscZeroVerifier::initialize (risc0/verifier.rs:58-76): *status = OK or ALREADY_INITIALIZED. */
 int zkv_risc0_initialize(zkv_ctx* ctx, const uint8_t control_root[32], const uint8_t bn254_control_id[32], uint8_t* status);
