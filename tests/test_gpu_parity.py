@@ -296,6 +296,31 @@ def test_both_window_widths_of_the_vk_x_stage_agree(zkv, real_proofs, monkeypatc
     assert vkx['16'] == vkx['8'] and len(set(vkx['16'])) == len(pairs)
 
 
+def test_entries_of_every_16_bit_window_row_against_the_oracle(zkv, r0, sp1, real_proofs):
+    """The device-built 16-bit window rows entry by entry: a signal that is one 16-bit digit d at window w makes compute_vk_x return
+    base + d * 65536^w * IC_b, i.e. exactly one table entry added to the base point.  Per row: the corners of the 64-entry build
+    chunks (lower byte 0, 1, 63, 64, 255; upper byte 0, 1, 255) and 600 random digits, against the oracle's ecMul / ecAdd chain."""
+    import random
+    import oracle_lib as ol
+    import spec_model as m
+    rng = random.Random(1616)
+    fixed = [H(x) for x in real_proofs['risc0']['signals']]
+    for vm, ctx, bits in ((0, r0, 128), (1, sp1, 256)):
+        sigs = []
+        for b in range(2):
+            for w in range(bits // 16):
+                digs = [(hi << 8) | lo for hi in (0, 1, 255) for lo in (0, 1, 63, 64, 255)] + [rng.randrange(1, 1 << 16) for _ in range(600)]
+                for d in digs:
+                    v = d << (16 * w)
+                    if vm == 1 and v >= (m.R if b == 0 else 1 << 253):
+                        continue                                  # not a signal the SP1 entry point can carry
+                    sigs.append((v, 0) if b == 0 else (0, v))
+        got = ctx.vk_x_batch([(m.be32(a), m.be32(b)) for a, b in sigs])
+        for (a, b), g in zip(sigs, got):
+            want = ol.groth16_vk_x(0, [fixed[0], fixed[1], m.be32(a), m.be32(b), fixed[4]]) if vm == 0 else ol.groth16_vk_x(1, [m.be32(a), m.be32(b)])
+            assert g == want, (vm, hex(a), hex(b))
+
+
 def test_vk_x_batch_matches_oracle(zkv, r0, sp1, real_proofs):
     """compute_vk_x on the GPU (windowed fixed-base tables built by the set-up kernels) against the oracle's ecMul/ecAdd chain
     for random and edge-case signals -- the valid proofs of the corpus all share one set of public inputs."""
