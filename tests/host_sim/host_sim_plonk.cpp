@@ -12,19 +12,12 @@ using namespace zkv;
 static void wr_be(uint8_t* p, const uint32_t l[8]) { for (int i = 0; i < 8; i++) for (int k = 0; k < 4; k++) p[31 - 4 * i - k] = (uint8_t)(l[i] >> (8 * k)); }
 
 static unsigned long long g_counts[3];
-extern "C" {
-// work of the last hsp_prepare call inside plonk_prepare: Fp multiplications, Fr multiplications, and the 32 x 32 + 64 multiply-adds
-// (v_mad_u64_u32 on the device) both are made of -- the figures behind roofline.mulmod / roofline.achieved of bench.py --workload plonk_2p18
-void hsp_prepare_counts(unsigned long long* out) { for (int i = 0; i < 3; i++) out[i] = g_counts[i]; }
-// vk: the serialisation of include/zkv.h (7 words, 8 + n_c points, 256 bytes of G2); proof: 27 x 32 bytes; pub: 2 x 32 bytes.
-// Returns -1 for a malformed key, 0 when the stage rejects, 1 when it produced the pairing inputs: out = D.x D.y Q.x Q.y (128 bytes,
-// (0,0) = infinity).
-int hsp_prepare(const uint8_t* vk, size_t vk_len, const uint8_t* proof, const uint8_t* pub, uint8_t* out128) {
-    if (vk_len < 7 * 32) return -1;
+static PlonkKey* key_for(const uint8_t* vk, size_t vk_len) {
+    if (vk_len < 7 * 32) return nullptr;
     uint32_t w7[7][8];
     for (int k = 0; k < 7; k++) host::be_to_limbs(w7[k], vk + 32 * k);
     const size_t n_c = w7[5][0];
-    if (n_c > 1 || vk_len != 7 * 32 + (8 + n_c) * 64 + 256) return -1;
+    if (n_c > 1 || vk_len != 7 * 32 + (8 + n_c) * 64 + 256) return nullptr;
     static PlonkKeyRaw raw, last; static PlonkKey key; static bool have = false;
     memset(&raw, 0, sizeof raw);
     memcpy(raw.size, w7[0], 32); memcpy(raw.size_inv, w7[1], 32); memcpy(raw.gen, w7[2], 32); memcpy(raw.coset, w7[3], 32);
@@ -34,6 +27,19 @@ int hsp_prepare(const uint8_t* vk, size_t vk_len, const uint8_t* proof, const ui
         plonk_setup_key(raw, key); plonk_setup_tables(key);
         last = raw; have = true;
     }
+    return &key;
+}
+extern "C" {
+// work of the last hsp_prepare call inside plonk_prepare: Fp multiplications, Fr multiplications, and the 32 x 32 + 64 multiply-adds
+// (v_mad_u64_u32 on the device) both are made of -- the figures behind roofline.mulmod / roofline.achieved of bench.py --workload plonk_2p18
+void hsp_prepare_counts(unsigned long long* out) { for (int i = 0; i < 3; i++) out[i] = g_counts[i]; }
+// vk: the serialisation of include/zkv.h (7 words, 8 + n_c points, 256 bytes of G2); proof: 27 x 32 bytes; pub: 2 x 32 bytes.
+// Returns -1 for a malformed key, 0 when the stage rejects, 1 when it produced the pairing inputs: out = D.x D.y Q.x Q.y (128 bytes,
+// (0,0) = infinity).
+int hsp_prepare(const uint8_t* vk, size_t vk_len, const uint8_t* proof, const uint8_t* pub, uint8_t* out128) {
+    PlonkKey* kp = key_for(vk, vk_len);
+    if (!kp) return -1;
+    PlonkKey& key = *kp;
     uint32_t w[27][8], pb[2][8];
     for (int k = 0; k < 27; k++) host::be_to_limbs(w[k], proof + 32 * k);
     host::be_to_limbs(pb[0], pub); host::be_to_limbs(pb[1], pub + 32);
@@ -70,5 +76,15 @@ void hsp_fr_inv(const uint8_t* a, uint8_t* out) {
     host::be_to_limbs(x, a);
     fr_to_raw(r, fr_inv(fr_from_raw_reduce(x)));
     wr_be(out, r);
+}
+// entry (a, b) of the joint table of key point p (PK_GEN = 9: the generator): a P + b phi(P) as 64 big-endian bytes; 1 if the point has a table
+int hsp_joint_entry(const uint8_t* vk, size_t vk_len, int p, int a, int b, uint8_t* out64) {
+    PlonkKey* kp = key_for(vk, vk_len);
+    if (!kp || p < 0 || p > PK_POINTS || a < 0 || a > PK_JA || b < -PK_JA || b > PK_JA) return -1;
+    if (kp->mult_inf[p]) return 0;
+    const G1A e = kp->joint[p][a][b + PK_JA];
+    uint32_t r[8];
+    fp_to_raw(r, e.x); wr_be(out64, r); fp_to_raw(r, e.y); wr_be(out64 + 32, r);
+    return 1;
 }
 }

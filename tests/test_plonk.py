@@ -79,6 +79,34 @@ def test_glv_split_of_the_msm_scalars(hsp):
         assert m1 < 1 << 128 and m2 < 1 << 128, hex(k)
 
 
+def test_joint_tables_of_the_fixed_terms(pool, hsp):
+    """The tables the fixed terms of the multi-scalar multiplications read -- a P + b phi(P), a = 0..136, b = -136..136, for the key's
+    points and the generator, built with one inversion per row -- against (a + b lambda) P of the spec model: the corners and edges of
+    every table and random entries."""
+    import random
+    import spec_model as sm
+    lam = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23
+    vk = H(pool['vk'])
+    n_c = int.from_bytes(vk[5 * 32:6 * 32], 'big')
+    pts = [(int.from_bytes(vk[224 + 64 * p:256 + 64 * p], 'big'), int.from_bytes(vk[256 + 64 * p:288 + 64 * p], 'big')) for p in range(8 + n_c)]
+    rng = random.Random(0x7AB1E)
+    hsp.hsp_joint_entry.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    for p in list(range(8 + n_c)) + [9]:
+        P = (1, 2) if p == 9 else pts[p]
+        if P == (0, 0):                                       # a selector commitment at infinity: the term is skipped, it has no table
+            assert hsp.hsp_joint_entry(vk, len(vk), p, 1, 1, C.create_string_buffer(64)) == 0
+            continue
+        ab = [(a, b) for a in (0, 1, 2, 135, 136) for b in (-136, -135, -1, 0, 1, 17, 136) if (a, b) != (0, 0)]
+        ab += [(rng.randrange(137), rng.randrange(-136, 137)) for _ in range(40)]
+        for a, b in ab:
+            if (a, b) == (0, 0):
+                continue
+            out = C.create_string_buffer(64)
+            assert hsp.hsp_joint_entry(vk, len(vk), p, a, b, out) == 1
+            want = sm.g1_mul(P, (a + b * lam) % sm.R)
+            assert (int.from_bytes(out.raw[:32], 'big'), int.from_bytes(out.raw[32:], 'big')) == want, (p, a, b)
+
+
 def test_c_oracle_equals_the_golden_statuses(cases):
     vk, vh = H(cases['vk']), H(cases['verifier_hash'])
     for c in cases['cases']:
