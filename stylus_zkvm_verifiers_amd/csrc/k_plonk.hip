@@ -51,16 +51,17 @@ __global__ __launch_bounds__(ZKV_BLOCK, ZKV_PLONK_WAVES) void k_plonk_prep(PrepA
         PlonkOut o;
         const TabRef tab = {a.plonk_tab + i * (size_t)PLONK_TAB_WORDS};             // this proof's contiguous table region (3,840 bytes)
         if (plonk_prepare(*key, w, pub, o, tab)) {
-            // x/y and 1/y of the two points (one inversion), as the Miller loop's fixed pairs expect them
+            // x/y = X Z / Y and 1/y = Z^3 / Y of the two points, as the Miller loop's fixed pairs expect them: one inversion for both
             const Fp one = fp_one();
-            const Fp yd = o.d_inf ? one : o.d.y, yq = o.q_inf ? one : o.q.y;
+            const bool d_inf = fp_is_zero(o.d.z), q_inf = fp_is_zero(o.q.z);
+            const Fp yd = d_inf ? one : o.d.y, yq = q_inf ? one : o.q.y;
             const Fp inv = fp_inv(fp_mul(yd, yq));
             const Fp iyd = fp_mul(inv, yq), iyq = fp_mul(inv, yd);
             const Fp z = fp_zero();
             ws_st(ws.norm, ws.cap, 0, i, z); ws_st(ws.norm, ws.cap, 8, i, z);
-            ws_st(ws.norm, ws.cap, 16, i, fp_mul(o.d.x, iyd)); ws_st(ws.norm, ws.cap, 24, i, iyd);
-            ws_st(ws.norm, ws.cap, 32, i, fp_mul(o.q.x, iyq)); ws_st(ws.norm, ws.cap, 40, i, iyq);
-            flags = FL_ALIVE | FL_A_INF | FL_B_INF | (o.d_inf ? FL_L_INF : 0u) | (o.q_inf ? FL_C_INF : 0u);
+            ws_st(ws.norm, ws.cap, 16, i, fp_mul(fp_mul(o.d.x, o.d.z), iyd)); ws_st(ws.norm, ws.cap, 24, i, fp_mul(fp_mul(fp_sqr(o.d.z), o.d.z), iyd));
+            ws_st(ws.norm, ws.cap, 32, i, fp_mul(fp_mul(o.q.x, o.q.z), iyq)); ws_st(ws.norm, ws.cap, 40, i, fp_mul(fp_mul(fp_sqr(o.q.z), o.q.z), iyq));
+            flags = FL_ALIVE | FL_A_INF | FL_B_INF | (d_inf ? FL_L_INF : 0u) | (q_inf ? FL_C_INF : 0u);
         }
     }
     ws.flags[i] = flags;

@@ -149,7 +149,9 @@ ZKV_HD void plonk_setup_tables(PlonkKey& k) {               // everything in seq
 
 // ---------------------------------------------------------------- G1 helpers
 // One term of a multi-scalar multiplication: an affine point (or infinity) and a canonical 256-bit scalar.
-struct MsmTerm { Fp x, y; uint32_t inf; uint32_t k[8]; const G1A* fixed; };      // fixed: the key's joint table [137][273] of the point, or null
+// fixed: the key's joint table [137][273] of the point, or null for a proof point, whose per-proof table sits in slot `slot` of the lane's
+// table region -- to be built by this multiplication, or (`ready`) left there, affine, by an earlier one of the same proof.
+struct MsmTerm { Fp x, y; uint32_t inf; uint32_t k[8]; const G1A* fixed; int slot; uint32_t ready; };
 
 // 33 signed 4-bit digits of a magnitude below 2^131, packed 4 bits each as d + 8
 ZKV_HD void glv_digits(const uint32_t (&m)[5], uint32_t (&dig)[5]) {
@@ -180,6 +182,7 @@ ZKV_HD void glv_digits(const uint32_t (&m)[5], uint32_t (&dig)[5]) {
 // 2^18 proofs (profiles/round3_f_plonk_2p18_rocprofv3_pmc_summary.md) for 0.26 GB of input.
 constexpr int PLONK_TAB_SLOTS = 5;                       // the most proof points any of the four multi-scalar multiplications has
 constexpr int PLONK_TAB_WORDS = PLONK_TAB_SLOTS * 8 * 24;
+constexpr int Z_SLOT = PLONK_TAB_SLOTS - 1;              // the slot the folding multiplication (slots 0..2) does not touch
 struct TabRef { uint32_t* p; };
 ZKV_HD Fp tab_ld(const TabRef& t, int slot, int e, int field) {
     const uint32_t* q = t.p + ((slot * 8 + e) * 3 + field) * 8;
@@ -213,18 +216,18 @@ ZKV_HD void plonk_msm_table(const TabRef& tb, int slot, const MsmTerm& t) {
     tab_st_j(tb, slot, 6, g1j_add_affine(m5, t.x, t.y));
     tab_st_j(tb, slot, 7, g1j_dbl(m3));
 }
-// NV: how many of the N terms can be proof points (the others take the key's joint tables): only those get a per-proof table, which
-// is what lives in the lane's private memory (round 2 sized it by N: 7.7 of the kernel's 14.8 KB per lane).
+// NV: how many tables this multiplication BUILDS at most (their slots are below NV): the prefix products of their normalisation are
+// what lives in the lane's private memory.  Two proof points enter two multiplications each (Z, H_zeta_omega): the second use finds the
+// table of the first (MsmTerm::ready) -- the callers place them in slots the multiplications in between leave alone.
 template <int N, int NV> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&t)[N], int n, const TabRef& tab) {
     static_assert(NV <= PLONK_TAB_SLOTS, "table region too small");
     uint32_t dig[N][2][5];                                // per half 33 signed digits, packed 4 bits each as d + 8 (0..15)
     uint32_t negs[N];                                     // bit 0 / 1: the first / second half is negative
-    int slot[N];                                          // term -> its table in tab[] (proof points), -1 otherwise
-    { int nv = 0; for (int i = 0; i < N; i++) slot[i] = (i < n && !t[i].fixed && nv < NV) ? nv++ : -1; }
+    bool build = false;
 #pragma unroll 1
     for (int i = 0; i < n; i++) {
         if (t[i].inf) continue;
-        if (!t[i].fixed) plonk_msm_table(tab, slot[i], t[i]);
+        if (!t[i].fixed && !t[i].ready) { plonk_msm_table(tab, t[i].slot, t[i]); build = true; }
         uint32_t m1[5], m2[5], n1, n2;
         glv_split(t[i].k, m1, n1, m2, n2);
         glv_digits(m1, dig[i][0]); glv_digits(m2, dig[i][1]);
@@ -233,22 +236,22 @@ template <int N, int NV> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&
     // The per-proof tables become affine with ONE inversion for the whole multi-scalar multiplication (Montgomery's trick over the
     // seven Z of 2P..8P of every proof point: 7 multiplications per entry), so that all additions of a term are mixed additions
     // (11 instead of 16 multiplications).  Entries are never infinity: G1 has prime order.  z then holds beta * x.
-    {
+    if (build) {
         const Fp beta = ZKV_GLV_BETA;
         Fp pre[NV][7];
         Fp run = fp_one();
 #pragma unroll 1
         for (int i = 0; i < n; i++) {
-            if (t[i].inf || t[i].fixed) continue;
-            const int s = slot[i];
+            if (t[i].inf || t[i].fixed || t[i].ready) continue;
+            const int s = t[i].slot;
 #pragma unroll 1
             for (int m = 1; m < 8; m++) { pre[s][m - 1] = run; run = fp_mul(run, tab_ld(tab, s, m, 2)); }
         }
         Fp inv = fp_inv(run);
 #pragma unroll 1
         for (int i = n - 1; i >= 0; i--) {
-            if (t[i].inf || t[i].fixed) continue;
-            const int s = slot[i];
+            if (t[i].inf || t[i].fixed || t[i].ready) continue;
+            const int s = t[i].slot;
 #pragma unroll 1
             for (int m = 7; m >= 1; m--) {
                 const Fp zi = fp_mul(inv, pre[s][m - 1]);
@@ -286,16 +289,18 @@ template <int N, int NV> ZKV_HD G1J plonk_msm(const G1J& start, const MsmTerm (&
                 acc = g1j_add_affine(acc, e.x, flip ? fp_neg(e.y) : e.y);
                 continue;
             }
-            const int s = slot[i];
+            const int s = t[i].slot;
             if (e1) { const int m = (e1 < 0 ? -e1 : e1) - 1; const Fp y = tab_ld(tab, s, m, 1); acc = g1j_add_affine(acc, tab_ld(tab, s, m, 0), e1 < 0 ? fp_neg(y) : y); }
             if (e2) { const int m = (e2 < 0 ? -e2 : e2) - 1; const Fp y = tab_ld(tab, s, m, 1); acc = g1j_add_affine(acc, tab_ld(tab, s, m, 2), e2 < 0 ? fp_neg(y) : y); }
         }
     }
     return g1j_add(acc, start);
 }
-ZKV_HD void plonk_term(MsmTerm& t, const G1A& p, uint32_t inf, const Fr& k) { t.x = p.x; t.y = p.y; t.inf = inf; t.fixed = nullptr; fr_to_raw(t.k, k); }
+ZKV_HD void plonk_term(MsmTerm& t, const G1A& p, uint32_t inf, const Fr& k, int slot, uint32_t ready = 0) {
+    t.x = p.x; t.y = p.y; t.inf = inf; t.fixed = nullptr; t.slot = slot; t.ready = ready; fr_to_raw(t.k, k);
+}
 ZKV_HD void plonk_key_term(MsmTerm& t, const PlonkKey& key, int p, const Fr& k) {      // a key point (or PK_GEN): table from the context
-    t.x = key.mult[p][1].x; t.y = key.mult[p][1].y; t.inf = key.mult_inf[p]; t.fixed = &key.joint[p][0][0]; fr_to_raw(t.k, k);
+    t.x = key.mult[p][1].x; t.y = key.mult[p][1].y; t.inf = key.mult_inf[p]; t.fixed = &key.joint[p][0][0]; t.slot = -1; t.ready = 0; fr_to_raw(t.k, k);
 }
 // affine form + canonical coordinates for the transcripts
 struct G1Bytes { uint32_t x[8], y[8]; };
@@ -334,8 +339,9 @@ ZKV_HD Fr plonk_hash_to_field(const uint32_t x[8], const uint32_t y[8]) {
 
 // ---------------------------------------------------------------- the verifier up to the pairing
 // words: the 27 proof words as canonical limbs.  pub: the two public inputs (program vkey unreduced, public-values hash).
-// Returns false => VerificationFailed.  On success D and Q are the pairing's G1 inputs (Q already negated), either may be infinity.
-struct PlonkOut { G1A d, q; uint32_t d_inf, q_inf; };
+// Returns false => VerificationFailed.  On success D and Q are the pairing's G1 inputs (Q already negated), Jacobian, Z = 0 for infinity:
+// what the Miller loop wants of them -- x / y and 1 / y -- takes one inversion for both (k_plonk_prep), affine coordinates would take two more.
+struct PlonkOut { G1J d, q; };
 ZKV_HD_NI bool plonk_prepare(const PlonkKey& key, const uint32_t (&w)[27][8], const uint32_t (&pub)[2][8], PlonkOut& out, const TabRef& tab) {
     if (!key.valid) return false;
     if (!raw_lt_r(pub[0]) || !raw_lt_r(pub[1])) return false;
@@ -418,9 +424,9 @@ ZKV_HD_NI bool plonk_prepare(const PlonkKey& key, const uint32_t (&w)[27][8], co
         MsmTerm t[10];
         plonk_key_term(t[0], key, PK_QL, l); plonk_key_term(t[1], key, PK_QR, r);
         plonk_key_term(t[2], key, PK_QM, fr_mul(l, r)); plonk_key_term(t[3], key, PK_QO, o);
-        plonk_key_term(t[4], key, PK_S3, _s1); plonk_term(t[5], pp[6], pinf[6], coeff_z);
-        plonk_term(t[6], pp[3], pinf[3], k0); plonk_term(t[7], pp[4], pinf[4], k1); plonk_term(t[8], pp[5], pinf[5], k2);
-        if (n_c) plonk_term(t[9], pp[9], pinf[9], qcpz);
+        plonk_key_term(t[4], key, PK_S3, _s1); plonk_term(t[5], pp[6], pinf[6], coeff_z, Z_SLOT);     // Z's table stays for the last multiplication but one
+        plonk_term(t[6], pp[3], pinf[3], k0, 0); plonk_term(t[7], pp[4], pinf[4], k1, 1); plonk_term(t[8], pp[5], pinf[5], k2, 2);
+        if (n_c) plonk_term(t[9], pp[9], pinf[9], qcpz, 3);
         plonk_affine((plonk_msm<10, 5>(qk, t, n_c ? 10 : 9, tab)), lin_a, lin_inf, lin_b);
     }
     // ---- fold the openings at zeta: gamma_kzg = H("gamma" || zeta || digests || values || zu)
@@ -444,7 +450,7 @@ ZKV_HD_NI bool plonk_prepare(const PlonkKey& key, const uint32_t (&w)[27][8], co
         folded_eval = fr_add(lin_eval, fr_add(fr_add(fr_mul(g, l), fr_mul(g2, r)), fr_add(fr_mul(g3, o), fr_add(fr_mul(g4, s1), fr_mul(g5, s2)))));
         if (n_c) folded_eval = fr_add(folded_eval, fr_mul(g6, qcpz));
         MsmTerm t[6];
-        plonk_term(t[0], pp[0], pinf[0], g); plonk_term(t[1], pp[1], pinf[1], g2); plonk_term(t[2], pp[2], pinf[2], g3);
+        plonk_term(t[0], pp[0], pinf[0], g, 0); plonk_term(t[1], pp[1], pinf[1], g2, 1); plonk_term(t[2], pp[2], pinf[2], g3, 2);
         plonk_key_term(t[3], key, PK_S1, g4); plonk_key_term(t[4], key, PK_S2, g5);
         if (n_c) plonk_key_term(t[5], key, PK_QCP, g6);
         G1J linj = g1j_infinity();
@@ -463,22 +469,21 @@ ZKV_HD_NI bool plonk_prepare(const PlonkKey& key, const uint32_t (&w)[27][8], co
     G1J dj, qj;
     {
         MsmTerm t[4];
-        plonk_term(t[0], pp[6], pinf[6], lam);
+        plonk_term(t[0], pp[6], pinf[6], lam, Z_SLOT, 1);                    // built by the first multiplication
         plonk_key_term(t[1], key, PK_GEN, fr_neg(evals));
-        plonk_term(t[2], pp[7], pinf[7], zeta);
-        plonk_term(t[3], pp[8], pinf[8], fr_mul(lam, fr_mul(zeta, key.gen)));
+        plonk_term(t[2], pp[7], pinf[7], zeta, 0);
+        plonk_term(t[3], pp[8], pinf[8], fr_mul(lam, fr_mul(zeta, key.gen)), 1);
         G1J fj = g1j_infinity();
         if (!fold_inf) { fj.x = fold_a.x; fj.y = fold_a.y; fj.z = fp_one(); }
         dj = plonk_msm<4, 3>(fj, t, 4, tab);
         MsmTerm u1[1];
-        plonk_term(u1[0], pp[8], pinf[8], lam);
+        plonk_term(u1[0], pp[8], pinf[8], lam, 1, 1);                        // H_zeta_omega's table: just built
         G1J hz = g1j_infinity();
         if (!pinf[7]) { hz.x = pp[7].x; hz.y = pp[7].y; hz.z = fp_one(); }
         qj = plonk_msm<1, 1>(hz, u1, 1, tab);
         qj.y = fp_neg(qj.y);
     }
-    g1j_to_affine(dj, out.d, out.d_inf);
-    g1j_to_affine(qj, out.q, out.q_inf);
+    out.d = dj; out.q = qj;
     return true;
 }
 

@@ -52,8 +52,10 @@ int hsp_prepare(const uint8_t* vk, size_t vk_len, const uint8_t* proof, const ui
     if (!okp) return 0;
     memset(out128, 0, 128);
     uint32_t r[8];
-    if (!o.d_inf) { fp_to_raw(r, o.d.x); wr_be(out128, r); fp_to_raw(r, o.d.y); wr_be(out128 + 32, r); }
-    if (!o.q_inf) { fp_to_raw(r, o.q.x); wr_be(out128 + 64, r); fp_to_raw(r, o.q.y); wr_be(out128 + 96, r); }
+    G1A d, q; uint32_t d_inf, q_inf;
+    g1j_to_affine(o.d, d, d_inf); g1j_to_affine(o.q, q, q_inf);
+    if (!d_inf) { fp_to_raw(r, d.x); wr_be(out128, r); fp_to_raw(r, d.y); wr_be(out128 + 32, r); }
+    if (!q_inf) { fp_to_raw(r, q.x); wr_be(out128 + 64, r); fp_to_raw(r, q.y); wr_be(out128 + 96, r); }
     return 1;
 }
 // Fr product through the device code (Montgomery in, Montgomery out) on canonical inputs: a * b mod r
