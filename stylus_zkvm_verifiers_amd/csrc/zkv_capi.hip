@@ -301,12 +301,16 @@ static int ctx_device_setup(zkv_ctx* c) {
             for (uint32_t b = 0; b < raw.n_var && b < (uint32_t)MAX_VAR; b++) { m.row0[b] = rows; rows += (raw.var_windows[b] + 1) / 2; }
             if (rows && rows <= MSM16_MAX_ROWS) {
                 const size_t bytes = (size_t)rows * 65536 * sizeof(G1A);
-                HIP_TRY(hipMalloc(&c->d_msm16, bytes));
-                HIP_TRY(hipMemsetAsync(c->d_msm16, 0, bytes, c->stream));
-                launch_setup_msm16(c->d_tab, m, c->d_msm16, rows, c->stream);
-                HIP_TRY(hipGetLastError());
-                m.tab = c->d_msm16;
-                c->m16 = m;
+                if (hipMalloc(&c->d_msm16, bytes) == hipSuccess) {
+                    HIP_TRY(hipMemsetAsync(c->d_msm16, 0, bytes, c->stream));
+                    launch_setup_msm16(c->d_tab, m, c->d_msm16, rows, c->stream);
+                    HIP_TRY(hipGetLastError());
+                    m.tab = c->d_msm16;
+                    c->m16 = m;
+                } else {                                         // no room for the rows (many contexts on one device): the 8-bit walk, same results
+                    (void)hipGetLastError();
+                    c->d_msm16 = nullptr;
+                }
             }
         }
         if (agg_vm || c->vm == ZKV_VM_SP1_PLONK) {
