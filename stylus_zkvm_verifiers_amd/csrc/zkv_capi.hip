@@ -176,18 +176,43 @@ static size_t wide_below() {
     return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)12288;     // round 4 (profiles/round4_batch_sweep.txt): 16 lanes 6.9-7.2 ms against 7.3 for lane pairs up to here, 8.7 beyond
 }
 // One lane-pair wavefront holds 32 proofs and a SIMD holds two wavefronts: a launch of up to 32,768 proofs puts one wavefront on
-// every SIMD (7.4 ms for the Miller loop and the final exponentiation together), the next 32,768 a second one (10.9 ms).  A chunk that
-// only just starts a new layer -- 32,768 k + r proofs with a small r -- would pay a whole wavefront's latency for r proofs; instead the
-// last r proofs run AFTER the others through the mapping their own number selects (one proof per wavefront, 16 lanes per proof: 2-3.5 ms).
-// Worth it up to r = ZKV_TAIL_SPLIT_BELOW (default 3,072: 7.4 + 3.5 against 10.9 ms), for chunks of up to 2^18 proofs (beyond that the
-// last layer is a few per cent of the launch).  0 disables.
+// every SIMD (7.3 ms for the Miller loop and the final exponentiation together), the next 32,768 a second one (10.8 ms for both), and so
+// on: T(k layers) grows by 3.5 ms from odd to even k and by 7 ms from even to odd.  A chunk of 32,768 k + r proofs with a small r would
+// pay a whole layer for r proofs; instead the last r proofs take the mapping their own number selects (one or two wavefronts per proof,
+// 16 lanes per proof: 2-6.4 ms alone):
+//  * k odd: the last layer of the others is ONE lane-pair wavefront per SIMD, which issues at 0.74 of the rate of two -- the tail's
+//    kernels run BESIDE it on the second stream (234 + 201 VGPRs fit a SIMD together): 33,792 proofs 10.7 -> 7.8 ms (9.7 with the tail
+//    after the others), 36,864 10.7 -> 8.0, 40,960 10.7 -> 9.8.  Worth it up to r = ZKV_TAIL_SPLIT_BELOW (default 8,192) for one layer and
+//    half of that for three and more, for chunks of up to ZKV_TAIL_SPLIT_MAX proofs (default 2^18: beyond, the odd layer is a few per
+//    cent of the launch and the tail disturbs more than it fills);
+//  * k even: every SIMD is full, and kernels launched beside would take register space from lane-pair wavefronts at the start and push
+//    them into a layer of their own at the end -- the tail runs AFTER the others: 69,632 proofs 18.9 -> 14.2 ms, 135,168 30.0 -> 26.6,
+//    263,168 50.3 -> 46.4.  Worth it up to r = ZKV_TAIL_SPLIT_EVEN_BELOW (default 12,288 = the most the 16-lane kernels take: 6.4 ms
+//    against the 7 ms of a layer of lone wavefronts), any chunk size.
+// ZKV_TAIL_SPLIT_BELOW=0 disables both; ZKV_TAIL_BESIDE=0 runs every tail after the others (profiles/round4_tail_beside.txt).
+static bool tail_beside() {
+    const char* e = getenv("ZKV_TAIL_BESIDE");
+    return !(e && atoi(e) == 0);
+}
+static size_t tail_split_max() {
+    const char* e = getenv("ZKV_TAIL_SPLIT_MAX");
+    return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)1 << 18);
+}
 static size_t tail_split_below() {
     const char* e = getenv("ZKV_TAIL_SPLIT_BELOW");
-    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)3072;
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)8192;
 }
-static size_t tail_of_chunk(size_t n) {
-    const size_t layer = 32768, r = n % layer;
-    return (n > layer && n <= ((size_t)1 << 18) && r && r <= tail_split_below()) ? r : 0;
+static size_t tail_split_even_below() {
+    const char* e = getenv("ZKV_TAIL_SPLIT_EVEN_BELOW");
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)12288;
+}
+// how many proofs at the end of an n-proof chunk take the small-batch mapping (0: none), and whether beside the others or after them
+static size_t tail_of_chunk(size_t n, bool* beside) {
+    const size_t layer = 32768, k = n / layer, r = n % layer;
+    *beside = false;
+    if (n <= layer || !r || !tail_split_below()) return 0;
+    if (k & 1) { *beside = tail_beside(); return (n <= tail_split_max() && r <= (k == 1 ? tail_split_below() : tail_split_below() / 2)) ? r : 0; }
+    return r <= tail_split_even_below() ? r : 0;
 }
 // The workspace rows of proofs [off, off + ...) of a chunk: word k of proof i sits at base[k * cap + i], so the same capacity with every
 // base advanced by `off` elements addresses them as proofs 0, 1, ...
@@ -646,7 +671,8 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
     else launch_prep_sp1(a, c->ws, s);
     if (timed) (void)hipEventRecord(c->ev[1], s);
     if (c->agg_on && c->agg_key_ok && c->agg_cap >= c->ws.cap && c->lanes == 0 && a.n >= agg_min() && agg_wanted(c)) { enqueue_agg(c, a, s, timed); return; }
-    const size_t tail = c->lanes == 0 ? tail_of_chunk(a.n) : 0;
+    bool tail_runs_beside = false;
+    const size_t tail = c->lanes == 0 ? tail_of_chunk(a.n, &tail_runs_beside) : 0;
     if (tail) {
         // all proofs through the vk_x stage, then the Miller loops and final exponentiations of the first a.n - tail proofs on lane pairs and
         // of the last `tail` through their own small-batch mapping (whose Miller kernels leave the subgroup test of B to k_g2chk2)
@@ -654,13 +680,19 @@ static void enqueue_chunk(zkv_ctx* c, const PrepArgs& a, hipStream_t s, bool tim
         const Workspace wt = ws_from(c->ws, head);
         launch_msm(a.n, c->d_tab, c->m16, a.inst ? c->d_inst : nullptr, c->ws, s);
         if (timed) (void)hipEventRecord(c->ev[2], s);
-        launch_g2chk2(tail, wt, a.status + head, s);
+        // the tail's kernels on the second stream beside the lane-pair kernels of the others (odd number of layers), or after them
+        // (tail_of_chunk); disjoint workspace rows and status bytes either way
+        const bool beside = tail_runs_beside && c->side != nullptr;
+        hipStream_t st = beside ? c->side : s;
+        if (beside) { (void)hipEventRecord(c->ev_fork, s); (void)hipStreamWaitEvent(c->side, c->ev_fork, 0); }
+        launch_g2chk2(tail, wt, a.status + head, st);
         if (timed) (void)hipEventRecord(c->ev[3], s);
         launch_miller2(head, c->d_tab, c->ws, a.status, s);
-        launch_miller_by_size(c, tail, wt, a.status + head, s);
+        launch_miller_by_size(c, tail, wt, a.status + head, st);
         if (timed) (void)hipEventRecord(c->ev[4], s);
         launch_finalexp2(head, c->ws, a.status, s);
-        launch_finalexp_by_size(tail, wt, a.status + head, s);
+        launch_finalexp_by_size(tail, wt, a.status + head, st);
+        if (beside) { (void)hipEventRecord(c->ev_join, c->side); (void)hipStreamWaitEvent(s, c->ev_join, 0); }
         if (timed) (void)hipEventRecord(c->ev[5], s);
         return;
     }

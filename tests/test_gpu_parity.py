@@ -955,33 +955,36 @@ def test_last_small_chunk_switches_kernels_inside_one_batch(zkv, real_proofs):
 
 
 def test_chunks_that_only_just_start_a_new_layer_split_off_their_tail(zkv, r0, real_proofs):
-    """32,768 k + r proofs with a small r: the last r proofs run through the small-batch mapping their number selects, after the lane-pair
-    kernels of the others (zkv_capi.hip tail_of_chunk).  Statuses must equal the construction's and the unsplit run's (ZKV_TAIL_SPLIT_BELOW=0)
-    at the split points: r = 1 and 700 (two wavefronts per proof), 2,000 (one wavefront per proof), 3,072 (16 lanes per proof), and just past
-    the limit (3,073: no split); mutations of every class, so the tail holds early rejects, subgroup failures and pairing failures."""
+    """32,768 k + r proofs with a small r: the last r proofs run through the small-batch mapping their number selects -- BESIDE the lane-pair
+    kernels of the others on the context's second stream when k is odd, after them when k is even (zkv_capi.hip tail_of_chunk).  Statuses
+    must equal the construction's and the unsplit run's (ZKV_TAIL_SPLIT_BELOW=0) at the split points: k = 1 with r = 1 and 700 (two
+    wavefronts per proof), 2,000 (one wavefront per proof), 8,192 (16 lanes per proof) and 8,193 (no split); k = 2 with r = 3,072, 12,288 and
+    12,289 (no split); k = 3 with r = 4,096 and 4,097 (no split).  Mutations of every class, so the tail holds early rejects, subgroup failures
+    and pairing failures.  Twice, so that the second stream's kernels of one call meet the next call's."""
     import torch
     from stylus_zkvm_verifiers_amd import synth
     dev = torch.device('cuda', 0)
     stream = torch.cuda.current_stream().cuda_stream
     r = real_proofs['risc0']
-    nmax = 65536 + 3073
+    nmax = 98304 + 4097
     seals, mut, _, flip = synth.make_batch_parallel('risc0', H(r['seal']), nmax, 0x5A4B56F1, mutate_every=5)
     ids = np.tile(np.frombuffer(H(r['image_id']), dtype=np.uint8), (nmax, 1))
     jds = np.tile(np.frombuffer(H(r['journal_digest']), dtype=np.uint8), (nmax, 1)); jds[flip, 0] ^= 1
     d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (seals, ids, jds)]
-    def run(n):
-        st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
-        r0.verify_batch_dev(n, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), st.data_ptr(), 0, stream)
+    def run(n, times=1):
+        sts = [torch.full((n,), 255, dtype=torch.uint8, device=dev) for _ in range(times)]
+        for st in sts:                                            # back to back, no synchronisation in between
+            r0.verify_batch_dev(n, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), st.data_ptr(), 0, stream)
         torch.cuda.synchronize()
-        return st.cpu().numpy()
-    for n in (32768 + 1, 32768 + 700, 32768 + 2000, 65536 + 3072, 65536 + 3073):
-        got = run(n)
+        return [st.cpu().numpy() for st in sts]
+    for n in (32768 + 1, 32768 + 700, 32768 + 2000, 32768 + 8192, 32768 + 8193, 65536 + 3072, 65536 + 12288, 65536 + 12289, 98304 + 4096, 98304 + 4097):
+        got, again = run(n, 2)
         os.environ['ZKV_TAIL_SPLIT_BELOW'] = '0'
         try:
-            plain = run(n)
+            plain = run(n)[0]
         finally:
             del os.environ['ZKV_TAIL_SPLIT_BELOW']
-        assert (got == plain).all(), (n, np.flatnonzero(got != plain)[:8])
+        assert (got == plain).all() and (again == plain).all(), (n, np.flatnonzero(got != plain)[:8], np.flatnonzero(again != plain)[:8])
         assert ((got == 0) == ~mut[:n]).all() and len(set(got[-700:])) >= 2, n
 
 
